@@ -1,0 +1,97 @@
+"""ctypes binding of libclipbert_hip.so (the C ABI declared in include/clipbert_hip.h).
+
+There is NO fallback: if the shared library is missing or fails to load, importing any op raises.
+Build it with ``python -m clipbert_amd.build`` (or ``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libclipbert_hip.so")
+
+CB_F32, CB_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
+ROWK, ROWK_GATHER, KROW, KROW_TAPS, KROW_GATHER = 0, 1, 2, 3, 4
+
+vp, i32, i64, f32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("dtype", i32), ("M", i32), ("N", i32), ("K", i32), ("a_mode", i32), ("b_mode", i32),
+        ("A", vp), ("B", vp), ("lda", i64), ("ldb", i64), ("a_tab", vp), ("b_tab", vp),
+        ("R", i32), ("S", i32), ("Cin", i32), ("H", i32), ("W", i32),
+        ("sH", i64), ("sW", i64), ("flip_taps", i32), ("reserved0", i32),
+        ("C", vp), ("ldc", i64), ("c_rowmap", vp), ("c_f32", i32), ("accumulate", i32),
+        ("split_k", i32), ("act", i32), ("scale", vp), ("shift", vp), ("residual", vp), ("ldr", i64),
+        ("relu_after", i32), ("reserved1", i32), ("mask", vp), ("ldm", i64), ("C2", vp), ("ldc2", i64),
+        ("alpha", f32), ("dropout_p", f32), ("dropout_seed", u64), ("tile", i32), ("reserved2", i32),
+    ]
+
+
+_SIGNATURES = {
+    "cb_gemm": [C.POINTER(GemmDesc), vp],
+    "cb_build_pixel_table": [vp, i32, i32, i32, i32, i32, i64, i64, i64, vp],
+    "cb_stem_pack": [i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "cb_image_norm": [vp, vp, vp, vp, i64, i64, vp],
+    "cb_maxpool_fwd": [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "cb_maxpool2_bwd": [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "cb_relu_scale_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],
+    "cb_layernorm_fwd": [i32, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
+    "cb_layernorm_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, f32, u64, vp],
+    "cb_text_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "cb_visual_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
+                            i32, i32, i32, f32, vp],
+    "cb_text_embed_bwd": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "cb_visual_embed_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "cb_attention_fwd": [i32, vp, vp, vp, vp, i32, i32, i32, f32, u64, vp],
+    "cb_attention_bwd": [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, u64, vp],
+    "cb_cross_entropy": [vp, vp, vp, vp, vp, i64, i32, i64, vp],
+    "cb_colsum": [i32, vp, i64, vp, i64, i32, vp],
+    "cb_cast": [i32, vp, i32, vp, i64, vp],
+    "cb_gelu_bwd": [i32, vp, vp, vp, i64, vp],
+    "cb_act_bwd": [i32, i32, vp, vp, vp, i64, vp],
+    "cb_adamw": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, f32, vp],
+    "cb_sq_sum": [vp, i64, vp, vp],
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES) + ("cb_last_error", "cb_version")
+
+
+def bind(cdll, strict: bool = True):
+    """Attach argtypes/restype for every entry point of the C ABI; raises if a symbol is missing."""
+    for name, args in _SIGNATURES.items():
+        if not strict and not hasattr(cdll, name):
+            continue
+        fn = getattr(cdll, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    cdll.cb_last_error.argtypes = []
+    cdll.cb_last_error.restype = C.c_char_p
+    cdll.cb_version.argtypes = []
+    cdll.cb_version.restype = C.c_int
+    return cdll
+
+
+_LIB = None
+
+
+def load(path: str = LIB_PATH):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: the HIP library is required (no fallback path exists). "
+            "Build it with `python -m clipbert_amd.build`.")
+    return bind(C.CDLL(path))
+
+
+def get():
+    global _LIB
+    if _LIB is None:
+        _LIB = load()
+    return _LIB
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = get().cb_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what or 'libclipbert_hip'} failed: {msg}")

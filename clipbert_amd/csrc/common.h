@@ -1,0 +1,84 @@
+// Shared device/host helpers for libclipbert_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "clipbert_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+// ---- error reporting (thread-local message, never throws across the ABI) ----------------------
+int cb_fail(const char* fmt, ...);   // records the message, returns -1
+int cb_launch_status(const char* what);
+#define CB_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) return cb_fail(__VA_ARGS__); \
+    } while (0)
+
+static inline hipStream_t cb_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- scalar conversions ----------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+// 4 consecutive elements <-> f32x4
+__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4(const bf16* p) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    return r;
+}
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16* p, f32x4 v) {
+    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+// ---- activations -----------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ float apply_act(int act, float v) {
+    switch (act) {
+        case CB_ACT_RELU: return v > 0.f ? v : 0.f;
+        case CB_ACT_GELU: return gelu_erf(v);
+        case CB_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+// ---- stateless dropout mask: keep(seed, index) -------------------------------------------------
+__device__ __forceinline__ uint32_t cb_hash(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+// returns the multiplier: 0 (dropped) or 1/(1-p) (kept)
+__device__ __forceinline__ float dropout_mult(uint64_t seed, uint64_t idx, float p) {
+    float u = (float)(cb_hash(seed, idx) >> 8) * (1.0f / 16777216.0f);
+    return u < p ? 0.f : 1.0f / (1.0f - p);
+}
+
+// ---- wave reductions (64 lanes) -----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}

@@ -1,0 +1,491 @@
+// GEMM / implicit-GEMM convolution family for gfx950 (MI355X): forward (NT), data-gradient (NN) and
+// weight-gradient (TN) forms of Linear and NHWC convolution share one MFMA core.
+//
+//   C[m,n] (op)= epilogue( sum_k A(m,k) * B(n,k) )
+//
+// * 256 threads = 4 waves (2x2); block tile BMxBN (128x128 or 64x64), K step 32.
+// * LDS tiles are [rows][32] with k contiguous, so MFMA fragments are one 16-byte ds_read_b128 per lane
+//   (bf16) -- the 16-byte segment index is XOR-swizzled with f((row>>2)&3), f = {0,3,2,1}, which
+//   makes every ds_read_b128 lane group hit 16 distinct slots of the 256-byte bank row.
+// * Operands whose memory image has the reduction index OUTERMOST (weights in dgrad, both operands in
+//   wgrad) are transposed in registers (4x8 16-bit blocks) on their way into LDS -- no transposed
+//   copies of weights or activations are ever materialised in HBM.
+// * Convolution operands are gathered through a per-output-pixel table (cb_build_pixel_table), so the
+//   kernel has no integer divisions per row; a K step never straddles a filter tap (Cin % 32 == 0).
+// * MFMA operands are swapped (acc = mfma(Bfrag, Afrag)) so each lane owns 4 CONSECUTIVE n of one
+//   row m: the epilogue reads scale/shift/residual and writes C with 8/16-byte accesses.
+// * bf16: v_mfma_f32_16x16x32_bf16; fp32 parity mode: v_mfma_f32_16x16x4_f32 (exact fp32).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int NTHREADS = 256;
+
+template <typename T> struct Tr;
+template <> struct Tr<bf16> { static constexpr int EPS = 8, SEGS = 4, ROWB = 64, RB = 8; };
+template <> struct Tr<float> { static constexpr int EPS = 4, SEGS = 8, ROWB = 144, RB = 4; };
+
+template <typename T> __device__ __forceinline__ int lds_off(int row, int seg);
+template <> __device__ __forceinline__ int lds_off<bf16>(int row, int seg) {
+    return row * 64 + ((seg ^ ((4 - ((row >> 2) & 3)) & 3)) << 4);
+}
+template <> __device__ __forceinline__ int lds_off<float>(int row, int seg) { return row * 144 + (seg << 4); }
+
+struct GP {
+    const void* A; const void* B; void* C; void* C2; const void* residual; const void* mask;
+    const float* scale; const float* shift;
+    const cb_pixel* a_tab; const cb_pixel* b_tab; const int32_t* c_rowmap;
+    int64_t lda, ldb, ldc, ldc2, ldr, ldm, sH, sW;
+    int M, N, K;
+    int a_mode, b_mode;
+    int R, S, Ct, H, W, flip;
+    int c_f32, accumulate, split_k, act, relu_after;
+    float alpha, dropout_p;
+    uint64_t seed;
+    int a_vec, b_vec, c_vec;
+    int ktiles;
+};
+
+template <typename T> __device__ __forceinline__ u32x4 load_guarded(const T* src, int nvalid) {
+    constexpr int EPS = Tr<T>::EPS;
+    union { u32x4 v; T e[EPS]; } u;
+#pragma unroll
+    for (int i = 0; i < EPS; ++i) u.e[i] = (i < nvalid) ? src[i] : (T)0.f;
+    return u.v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ROWK loader: tile rows are GEMM rows, 16-byte segments run along k.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int ROWS> struct RowkLoader {
+    using X = Tr<T>;
+    static constexpr int NS = ROWS * X::SEGS / NTHREADS;
+    static_assert(ROWS * X::SEGS % NTHREADS == 0, "tile/threads mismatch");
+    int64_t off[NS];
+    int ih[NS], iw[NS];
+    bool ok[NS];
+    u32x4 r[NS];
+
+    __device__ __forceinline__ void init(const GP& p, bool gather, const cb_pixel* tab, int64_t ld, int row0,
+                                         int bound, int tid) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            int idx = tid + i * NTHREADS;
+            int row = row0 + idx / X::SEGS;
+            ok[i] = row < bound;
+            ih[i] = 0; iw[i] = 0;
+            if (gather) {
+                cb_pixel px = {0, 0, 0};
+                if (ok[i]) px = tab[row];
+                off[i] = px.off; ih[i] = px.ih0; iw[i] = px.iw0;
+            } else {
+                off[i] = (int64_t)row * ld;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(const GP& p, const T* base, bool gather, bool vec, int kt, int tid) {
+        int k0 = kt * BK, c0 = k0, rr = 0, ss = 0, klim = p.K;
+        int64_t tapoff = 0;
+        if (gather) {
+            int tap = k0 / p.Ct;
+            c0 = k0 - tap * p.Ct;
+            rr = tap / p.S; ss = tap - rr * p.S;
+            tapoff = rr * p.sH + ss * p.sW;
+            klim = p.Ct;
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            int seg = (tid + i * NTHREADS) % X::SEGS;
+            int kk = c0 + seg * X::EPS;
+            bool v = ok[i] && kk < klim;
+            if (gather) v = v && (unsigned)(ih[i] + rr) < (unsigned)p.H && (unsigned)(iw[i] + ss) < (unsigned)p.W;
+            const T* src = base + off[i] + tapoff + kk;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            if (!v) r[i] = z;
+            else if (vec) r[i] = *reinterpret_cast<const u32x4*>(src);
+            else r[i] = load_guarded<T>(src, klim - kk);
+        }
+    }
+    __device__ __forceinline__ void store(unsigned char* tile, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            int idx = tid + i * NTHREADS;
+            *reinterpret_cast<u32x4*>(tile + lds_off<T>(idx / X::SEGS, idx % X::SEGS)) = r[i];
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// KROW loader: memory has the reduction index outermost; each thread moves a (4 k) x (RB rows) block
+// and transposes it in registers.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int ROWS> struct KrowLoader {
+    using X = Tr<T>;
+    static constexpr int RBLK = ROWS / X::RB;              // row blocks per tile
+    static constexpr int CNT = RBLK * (BK / 4);            // thread-blocks per tile
+    static constexpr int NI = (CNT + NTHREADS - 1) / NTHREADS;
+    u32x4 r[NI][4];
+
+    __device__ __forceinline__ void load(const GP& p, const T* base, int mode, const cb_pixel* tab, int64_t ld,
+                                         bool vec, int row0, int bound, int kt, int tid) {
+        u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            int b = tid + it * NTHREADS;
+            if (b >= CNT) { r[it][0] = z; r[it][1] = z; r[it][2] = z; r[it][3] = z; continue; }
+            int rb = b % RBLK, kb = b / RBLK;
+            int row = row0 + rb * X::RB;           // global row of the first element
+            int nvalid = bound - row;              // rows valid from here
+            int kbase = kt * BK + kb * 4;
+            // per-tile-uniform tap decomposition (weights of a transposed conv)
+            int64_t rowoff = row;
+            int rr = 0, ss = 0, tapk = 0;
+            if (mode == CB_KROW_TAPS) {
+                int tap = (kt * BK) / p.Ct;
+                tapk = tap * p.Ct;
+                int tapw = p.flip ? (p.R * p.S - 1 - tap) : tap;
+                rowoff = (int64_t)tapw * bound + row;      // weights [Ct][taps][bound]
+            } else if (mode == CB_KROW_GATHER) {
+                int tap = row / p.Ct;
+                int c = row - tap * p.Ct;
+                rr = tap / p.S; ss = tap - rr * p.S;
+                rowoff = rr * p.sH + ss * p.sW + c;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int k = kbase + j;
+                bool v = k < p.K && nvalid > 0;
+                const T* src;
+                if (mode == CB_KROW_GATHER) {
+                    cb_pixel px = {0, 0, 0};
+                    if (v) px = tab[k];
+                    v = v && (unsigned)(px.ih0 + rr) < (unsigned)p.H && (unsigned)(px.iw0 + ss) < (unsigned)p.W;
+                    src = base + px.off + rowoff;
+                } else {
+                    src = base + (int64_t)(k - tapk) * ld + rowoff;
+                }
+                if (!v) r[it][j] = z;
+                else if (vec && nvalid >= X::RB) r[it][j] = *reinterpret_cast<const u32x4*>(src);
+                else r[it][j] = load_guarded<T>(src, nvalid);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(unsigned char* tile, int tid) const {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            int b = tid + it * NTHREADS;
+            if (b >= CNT) continue;
+            int rb = b % RBLK, kb = b / RBLK;
+            int row = rb * X::RB;
+            if constexpr (sizeof(T) == 2) {
+                // r[it][j][d] holds rows (2d, 2d+1) at k = kb*4 + j
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    uint32_t a0 = r[it][0][d], a1 = r[it][1][d], a2 = r[it][2][d], a3 = r[it][3][d];
+                    u32x2 even = {(a0 & 0xffffu) | (a1 << 16), (a2 & 0xffffu) | (a3 << 16)};
+                    u32x2 odd = {(a0 >> 16) | (a1 & 0xffff0000u), (a2 >> 16) | (a3 & 0xffff0000u)};
+                    *reinterpret_cast<u32x2*>(tile + lds_off<T>(row + 2 * d, kb >> 1) + (kb & 1) * 8) = even;
+                    *reinterpret_cast<u32x2*>(tile + lds_off<T>(row + 2 * d + 1, kb >> 1) + (kb & 1) * 8) = odd;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u32x4 o = {r[it][0][e], r[it][1][e], r[it][2][e], r[it][3][e]};
+                    *reinterpret_cast<u32x4*>(tile + lds_off<T>(row + e, kb)) = o;
+                }
+            }
+        }
+    }
+};
+
+template <typename T, int BM, int BN, bool A_KROW, bool B_KROW>
+__global__ void __launch_bounds__(256) gemm_kernel(GP p) {
+    using X = Tr<T>;
+    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+    constexpr int TILE_A = BM * X::ROWB, TILE_B = BN * X::ROWB;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (TILE_A + TILE_B)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kt_per = (p.ktiles + p.split_k - 1) / p.split_k;
+    const int kt_begin = blockIdx.z * kt_per;
+    const int kt_end = (kt_begin + kt_per < p.ktiles) ? kt_begin + kt_per : p.ktiles;
+    if (kt_begin >= kt_end) return;
+
+    const T* Ab = reinterpret_cast<const T*>(p.A);
+    const T* Bb = reinterpret_cast<const T*>(p.B);
+
+    RowkLoader<T, BM> la;
+    RowkLoader<T, BN> lb;
+    KrowLoader<T, BM> ka;
+    KrowLoader<T, BN> kb;
+    if constexpr (!A_KROW) la.init(p, p.a_mode == CB_ROWK_GATHER, p.a_tab, p.lda, m0, p.M, tid);
+    if constexpr (!B_KROW) lb.init(p, false, nullptr, p.ldb, n0, p.N, tid);
+
+    auto load_tiles = [&](int kt) {
+        if constexpr (A_KROW) ka.load(p, Ab, CB_KROW, nullptr, p.lda, p.a_vec, m0, p.M, kt, tid);
+        else la.load(p, Ab, p.a_mode == CB_ROWK_GATHER, p.a_vec, kt, tid);
+        if constexpr (B_KROW) kb.load(p, Bb, p.b_mode, p.b_tab, p.ldb, p.b_vec, n0, p.N, kt, tid);
+        else lb.load(p, Bb, false, p.b_vec, kt, tid);
+    };
+    auto store_tiles = [&](int buf) {
+        unsigned char* As = smem + buf * (TILE_A + TILE_B);
+        unsigned char* Bs = As + TILE_A;
+        if constexpr (A_KROW) ka.store(As, tid); else la.store(As, tid);
+        if constexpr (B_KROW) kb.store(Bs, tid); else lb.store(Bs, tid);
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
+
+    load_tiles(kt_begin);
+    store_tiles(0);
+    __syncthreads();
+
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        const bool more = kt + 1 < kt_end;
+        if (more) load_tiles(kt + 1);
+        const unsigned char* As = smem + cur * (TILE_A + TILE_B);
+        const unsigned char* Bs = As + TILE_A;
+        if constexpr (sizeof(T) == 2) {
+            bf16x8 af[FM], bfr[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off<T>(wm * WM + i * 16 + (lane & 15), lane >> 4));
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<T>(wn * WN + j * 16 + (lane & 15), lane >> 4));
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                float af[FM], bfr[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    af[i] = *reinterpret_cast<const float*>(As + lds_off<T>(wm * WM + i * 16 + (lane & 15), kk) + (lane >> 4) * 4);
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    bfr[j] = *reinterpret_cast<const float*>(Bs + lds_off<T>(wn * WN + j * 16 + (lane & 15), kk) + (lane >> 4) * 4);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (more) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns n = nb..nb+3 of row m ------------------------------------------------
+    const float alpha = p.alpha;
+    const T* res = reinterpret_cast<const T*>(p.residual);
+    const T* msk = reinterpret_cast<const T*>(p.mask);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * WM + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const int64_t orow = p.c_rowmap ? (int64_t)p.c_rowmap[m] : (int64_t)m;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int nb = n0 + wn * WN + j * 16 + 4 * (lane >> 4);
+            if (nb >= p.N) continue;
+            f32x4 v = acc[i][j] * alpha;
+            const bool full = p.c_vec && (nb + 3 < p.N);
+            if (full) {
+                if (p.scale) v = v * load4(p.scale + nb);
+                if (p.shift) v = v + load4(p.shift + nb);
+                if (p.C2) store4(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + nb, v);
+                if (p.act != CB_ACT_NONE) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = apply_act(p.act, v[r]);
+                }
+                if (p.dropout_p > 0.f) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= dropout_mult(p.seed, (uint64_t)m * p.N + nb + r, p.dropout_p);
+                }
+                if (res) v = v + load4(res + orow * p.ldr + nb);
+                if (p.relu_after) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+                }
+                if (msk) {
+                    f32x4 mk = load4(msk + orow * p.ldm + nb);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
+                }
+                if (p.c_f32) {
+                    float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + nb;
+                    if (p.split_k > 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) atomicAdd(c + r, v[r]);
+                    } else {
+                        if (p.accumulate) v = v + load4(c);
+                        store4(c, v);
+                    }
+                } else {
+                    T* c = reinterpret_cast<T*>(p.C) + orow * p.ldc + nb;
+                    if (p.accumulate) v = v + load4(c);
+                    store4(c, v);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = nb + r;
+                    if (n >= p.N) continue;
+                    float x = v[r];
+                    if (p.scale) x *= p.scale[n];
+                    if (p.shift) x += p.shift[n];
+                    if (p.C2) reinterpret_cast<T*>(p.C2)[orow * p.ldc2 + n] = from_f32<T>(x);
+                    x = apply_act(p.act, x);
+                    if (p.dropout_p > 0.f) x *= dropout_mult(p.seed, (uint64_t)m * p.N + n, p.dropout_p);
+                    if (res) x += to_f32(res[orow * p.ldr + n]);
+                    if (p.relu_after) x = x > 0.f ? x : 0.f;
+                    if (msk) x = to_f32(msk[orow * p.ldm + n]) > 0.f ? x : 0.f;
+                    if (p.c_f32) {
+                        float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + n;
+                        if (p.split_k > 1) atomicAdd(c, x);
+                        else *c = p.accumulate ? (*c + x) : x;
+                    } else {
+                        T* c = reinterpret_cast<T*>(p.C) + orow * p.ldc + n;
+                        *c = from_f32<T>(p.accumulate ? (to_f32(*c) + x) : x);
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) pixel_table_kernel(cb_pixel* tab, int total, int OH, int OW, int stride,
+                                                          int pad, int64_t sN, int64_t sH, int64_t sW) {
+    int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= total) return;
+    int ow = m % OW, t = m / OW;
+    int oh = t % OH, n = t / OH;
+    int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
+    cb_pixel px;
+    px.off = (int32_t)((int64_t)n * sN + (int64_t)ih0 * sH + (int64_t)iw0 * sW);
+    px.ih0 = (int16_t)ih0;
+    px.iw0 = (int16_t)iw0;
+    tab[m] = px;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename T, int BM, int BN>
+int launch_gemm(const GP& p, bool a_krow, bool b_krow, hipStream_t st) {
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.split_k);
+    dim3 block(NTHREADS);
+    if (!a_krow && !b_krow) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, false>), grid, block, 0, st, p);
+    else if (!a_krow && b_krow) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, true>), grid, block, 0, st, p);
+    else if (a_krow && b_krow) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, true, true>), grid, block, 0, st, p);
+    else return cb_fail("cb_gemm: unsupported operand mode combination (A KROW with B ROWK)");
+    return cb_launch_status("cb_gemm");
+}
+
+}  // namespace
+
+extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
+    CB_REQUIRE(d != nullptr, "cb_gemm: null descriptor");
+    CB_REQUIRE(d->dtype == CB_F32 || d->dtype == CB_BF16, "cb_gemm: bad dtype %d", d->dtype);
+    CB_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, "cb_gemm: negative dims");
+    if (d->M == 0 || d->N == 0) return 0;
+    CB_REQUIRE(d->A && d->B && d->C, "cb_gemm: null operand");
+    const int esz = d->dtype == CB_BF16 ? 2 : 4;
+    const int eps = 16 / esz;
+    GP p{};
+    p.A = d->A; p.B = d->B; p.C = d->C; p.C2 = d->C2; p.residual = d->residual; p.mask = d->mask;
+    p.scale = d->scale; p.shift = d->shift; p.a_tab = d->a_tab; p.b_tab = d->b_tab; p.c_rowmap = d->c_rowmap;
+    p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldc2 = d->ldc2; p.ldr = d->ldr; p.ldm = d->ldm;
+    p.sH = d->sH; p.sW = d->sW;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.a_mode = d->a_mode; p.b_mode = d->b_mode;
+    p.R = d->R > 0 ? d->R : 1; p.S = d->S > 0 ? d->S : 1; p.Ct = d->Cin; p.H = d->H; p.W = d->W; p.flip = d->flip_taps;
+    p.c_f32 = d->c_f32; p.accumulate = d->accumulate; p.split_k = d->split_k > 0 ? d->split_k : 1;
+    p.act = d->act; p.relu_after = d->relu_after;
+    p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
+    p.dropout_p = d->dropout_p; p.seed = d->dropout_seed;
+    p.ktiles = (d->K + BK - 1) / BK;
+
+    const bool a_krow = d->a_mode == CB_KROW;
+    const bool b_krow = d->b_mode == CB_KROW || d->b_mode == CB_KROW_TAPS || d->b_mode == CB_KROW_GATHER;
+    CB_REQUIRE(d->a_mode == CB_ROWK || d->a_mode == CB_ROWK_GATHER || d->a_mode == CB_KROW, "cb_gemm: bad a_mode %d", d->a_mode);
+    CB_REQUIRE(d->b_mode == CB_ROWK || b_krow, "cb_gemm: bad b_mode %d", d->b_mode);
+    const int taps = p.R * p.S;
+    const bool tapped = d->a_mode == CB_ROWK_GATHER || d->b_mode == CB_KROW_TAPS || d->b_mode == CB_KROW_GATHER;
+    if (tapped) {
+        CB_REQUIRE(p.Ct > 0, "cb_gemm: Cin (channels per tap) must be set for conv modes");
+        CB_REQUIRE(taps == 1 || p.Ct % BK == 0, "cb_gemm: channels per tap (%d) must be a multiple of %d", p.Ct, BK);
+        CB_REQUIRE(p.Ct % eps == 0, "cb_gemm: channels per tap (%d) must be a multiple of %d", p.Ct, eps);
+    }
+    if (d->a_mode == CB_ROWK_GATHER) {
+        CB_REQUIRE(d->a_tab, "cb_gemm: a_tab missing");
+        CB_REQUIRE(d->K == taps * p.Ct, "cb_gemm: K (%d) != R*S*Cin (%d)", d->K, taps * p.Ct);
+        CB_REQUIRE(d->sH % eps == 0 && d->sW % eps == 0 && aligned16(d->A), "cb_gemm: gather strides/base must be 16-byte multiples");
+        p.a_vec = 1;
+    } else if (d->a_mode == CB_ROWK) {
+        p.a_vec = (d->lda % eps == 0) && (d->K % eps == 0) && aligned16(d->A);
+    } else {
+        p.a_vec = (d->lda % eps == 0) && aligned16(d->A);
+    }
+    if (d->b_mode == CB_ROWK) {
+        p.b_vec = (d->ldb % eps == 0) && (d->K % eps == 0) && aligned16(d->B);
+    } else if (d->b_mode == CB_KROW) {
+        p.b_vec = (d->ldb % eps == 0) && aligned16(d->B);
+    } else if (d->b_mode == CB_KROW_TAPS) {
+        CB_REQUIRE(d->K == taps * p.Ct, "cb_gemm: K (%d) != R*S*Ct (%d)", d->K, taps * p.Ct);
+        p.b_vec = (d->ldb % eps == 0) && (d->N % eps == 0) && aligned16(d->B);
+    } else {
+        CB_REQUIRE(d->b_tab, "cb_gemm: b_tab missing");
+        CB_REQUIRE(d->N == taps * p.Ct, "cb_gemm: N (%d) != R*S*Cin (%d)", d->N, taps * p.Ct);
+        CB_REQUIRE(d->sH % eps == 0 && d->sW % eps == 0 && aligned16(d->B), "cb_gemm: gather strides/base must be 16-byte multiples");
+        p.b_vec = 1;
+    }
+    if (p.split_k > 1) {
+        CB_REQUIRE(d->c_f32, "cb_gemm: split_k > 1 needs an fp32 output");
+        CB_REQUIRE(!d->C2 && !d->residual && !d->mask && d->act == CB_ACT_NONE && !d->relu_after && !d->shift && d->dropout_p <= 0.f,
+                   "cb_gemm: split_k > 1 supports only scale/alpha in the epilogue");
+        if (p.split_k > p.ktiles) p.split_k = p.ktiles;
+    }
+    CB_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "cb_gemm: dropout_p out of range");
+    // vector epilogue: every touched row pointer must be 16-byte (fp32) / 8-byte (bf16) aligned at n%4==0
+    const int cesz = d->c_f32 ? 4 : esz;
+    bool cv = (d->ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->C) % (4 * cesz)) == 0);
+    if (d->C2) cv = cv && (d->ldc2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->C2) % (4 * esz)) == 0);
+    if (d->residual) cv = cv && (d->ldr % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->residual) % (4 * esz)) == 0);
+    if (d->mask) cv = cv && (d->ldm % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->mask) % (4 * esz)) == 0);
+    if (d->scale) cv = cv && aligned16(d->scale);
+    if (d->shift) cv = cv && aligned16(d->shift);
+    p.c_vec = cv;
+
+    hipStream_t st = cb_stream(stream);
+    if (d->dtype == CB_F32) return launch_gemm<float, 64, 64>(p, a_krow, b_krow, st);
+    int tile = d->tile;
+    if (tile == 0) {
+        int64_t blocks128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * p.split_k;
+        tile = blocks128 >= 192 ? 1 : 2;
+    }
+    if (tile == 1) return launch_gemm<bf16, 128, 128>(p, a_krow, b_krow, st);
+    return launch_gemm<bf16, 64, 64>(p, a_krow, b_krow, st);
+}
+
+extern "C" int cb_build_pixel_table(cb_pixel* tab, int32_t N, int32_t OH, int32_t OW, int32_t stride, int32_t pad,
+                                    int64_t sN, int64_t sH, int64_t sW, void* stream) {
+    CB_REQUIRE(tab && N > 0 && OH > 0 && OW > 0 && stride > 0, "cb_build_pixel_table: bad arguments");
+    int64_t total = (int64_t)N * OH * OW;
+    CB_REQUIRE(total < (1ll << 31), "cb_build_pixel_table: too many pixels");
+    CB_REQUIRE((int64_t)N * sN < (1ll << 31), "cb_build_pixel_table: image offsets exceed 31 bits");
+    hipLaunchKernelGGL(pixel_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, cb_stream(stream), tab,
+                       (int)total, OH, OW, stride, pad, sN, sH, sW);
+    return cb_launch_status("cb_build_pixel_table");
+}

@@ -1,0 +1,195 @@
+/* clipbert_hip.h -- C ABI of libclipbert_hip.so, the MI355X (gfx950) implementation of the ClipBERT
+ * forward/backward hot path.
+ *
+ * The reference (jayleicn/ClipBERT) has no FFI / plugin registry of its own: its seam is the Python
+ * nn.Module API of src/modeling.  Each entry point below therefore names the
+ * reference function(s) whose arithmetic it replaces; clipbert_amd/modeling.py keeps the reference's
+ * module names / signatures / state-dict keys and reaches these entry points through ctypes
+ * (INTEGRATION.md shows the binding a maintainer of the reference would add).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer borrowed from the caller (torch.Tensor.data_ptr()); nothing is
+ *    allocated, retained or freed inside; no torch types appear in any signature;
+ *  - kernels are enqueued on `stream` (a hipStream_t passed as void*) and the call returns at once;
+ *  - return 0 on success, negative on error (cb_last_error() gives a thread-local message); nothing
+ *    throws across the ABI;
+ *  - `dtype` selects the storage / MFMA input type of activations and compute-weights:
+ *    CB_BF16 (performance mode, bf16 in, fp32 accumulate on v_mfma_f32_16x16x32_bf16) or
+ *    CB_F32 (parity mode, exact fp32 on v_mfma_f32_16x16x4_f32).  Statistics, softmax, losses,
+ *    gradients of parameters and optimizer state are always fp32;
+ *  - activations are NHWC / token-major; conv weights are KRSC ([Cout][R][S][Cin], i.e. the
+ *    channels_last memory image of the reference's OIHW nn.Parameter); Linear weights are (out,in).
+ */
+#ifndef CLIPBERT_HIP_H
+#define CLIPBERT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { CB_F32 = 0, CB_BF16 = 1 };
+enum { CB_ACT_NONE = 0, CB_ACT_RELU = 1, CB_ACT_GELU = 2, CB_ACT_TANH = 3 };
+
+/* operand addressing modes of cb_gemm (reduction index = k) */
+enum {
+    CB_ROWK = 0,        /* element (row,k) at base + row*ld + k            (k contiguous)            */
+    CB_ROWK_GATHER = 1, /* row -> pixel via table; k = (tap, c): base + tab[row].off + r*sH + s*sW + c */
+    CB_KROW = 2,        /* element (row,k) at base + k*ld + row            (row contiguous)           */
+    CB_KROW_TAPS = 3,   /* weights KRSC read for dgrad: k = (tap, co): base + co*ld + tap'*Cin + row  */
+    CB_KROW_GATHER = 4  /* k -> pixel via table; row = (tap, c): base + tab[k].off + r*sH + s*sW + c  */
+};
+
+/* one entry per output pixel of a convolution, built by cb_build_pixel_table */
+typedef struct { int32_t off; int16_t ih0; int16_t iw0; } cb_pixel;
+
+/* Describes C[M,N] (op)= epilogue( sum_k A(m,k) * B(n,k) ).  All strides in ELEMENTS. */
+typedef struct {
+    int32_t dtype;            /* CB_F32 | CB_BF16 : type of A, B, residual, mask, C (unless c_f32)     */
+    int32_t M, N, K;          /* K = full reduction length (taps * Cin for convolutions)              */
+    int32_t a_mode, b_mode;
+    const void* A; const void* B;
+    int64_t lda, ldb;
+    const cb_pixel* a_tab;    /* CB_ROWK_GATHER: M entries */
+    const cb_pixel* b_tab;    /* CB_KROW_GATHER: K entries */
+    /* tap geometry shared by the gather / taps modes */
+    int32_t R, S, Cin;        /* K (or N for KROW_GATHER) = R*S*Cin                                  */
+    int32_t H, W;             /* bounds of the gathered image                                        */
+    int64_t sH, sW;           /* element strides of one image row / one pixel                        */
+    int32_t flip_taps;        /* CB_KROW_TAPS: read weight tap (R-1-r, S-1-s) (transposed conv)      */
+    int32_t reserved0;
+    /* output */
+    void* C; int64_t ldc;
+    const int32_t* c_rowmap;  /* optional: output row m is written at row c_rowmap[m]                */
+    int32_t c_f32;            /* 1: C is fp32 regardless of dtype (parameter gradients, logits)      */
+    int32_t accumulate;       /* 1: C += result (plain RMW; with split_k > 1: fp32 atomics)          */
+    int32_t split_k;          /* >= 1; > 1 requires c_f32 && accumulate semantics (C pre-initialised) */
+    int32_t act;              /* CB_ACT_* applied before the residual add                            */
+    const float* scale;       /* optional per-n multiplier (FrozenBN scale)                          */
+    const float* shift;       /* optional per-n addend (bias / FrozenBN shift)                       */
+    const void* residual; int64_t ldr;    /* optional, added after act                               */
+    int32_t relu_after;       /* ReLU after the residual add (ResNet block output)                    */
+    int32_t reserved1;
+    const void* mask; int64_t ldm;        /* optional: result zeroed where mask[m,n] <= 0 (ReLU bwd)  */
+    void* C2; int64_t ldc2;   /* optional second output: value BEFORE act (GELU backward needs it)   */
+    float alpha;              /* multiplies the accumulator first (1.0 if 0)                         */
+    float dropout_p;          /* > 0: inverted dropout on the value before the residual add          */
+    uint64_t dropout_seed;
+    int32_t tile;             /* 0 auto, 1 = 128x128, 2 = 64x64                                      */
+    int32_t reserved2;
+} cb_gemm_desc;
+
+/* GEMM / implicit-GEMM convolution, all forms.  Replaces torch.nn.Linear / F.conv2d (+ apex-amp
+ * cuBLAS/cuDNN) at: BertSelfAttention q/k/v (src/modeling/transformers.py:238-249), BertSelfOutput
+ * :297-301, BertIntermediate :363-366, BertOutput :377-381, BertPooler :470-476, heads
+ * (src/modeling/modeling.py:534-539, transformers.py:504-515), detectron2 ResNet convs + FrozenBN
+ * (src/modeling/grid_feat.py:95) and grid_encoder conv (:43-45,99), and their autograd backward. */
+int cb_gemm(const cb_gemm_desc* d, void* stream);
+
+/* Output-pixel table of a convolution: entry m=(n,oh,ow) -> offset of input pixel
+ * (n, oh*stride-pad, ow*stride-pad) and its (ih0, iw0).  sN/sH/sW in elements. */
+int cb_build_pixel_table(cb_pixel* tab, int32_t N, int32_t OH, int32_t OW, int32_t stride, int32_t pad,
+                         int64_t sN, int64_t sH, int64_t sW, void* stream);
+
+/* Stem input pack: (N,3,H,W) fp32 RGB mean-subtracted (or uint8 RGB with mean/std) -> zero-padded
+ * NHWC4 image (N, H+2*pad(+), W+2*pad(+), 4) in BGR order, dtype T.  Fuses ImageNorm
+ * (src/datasets/data_utils.py:266-276), .float() (dataloader.py:104) and the RGB->BGR gather
+ * (src/modeling/grid_feat.py:92-94).  src_u8 = 1: src is uint8 and (v - mean[c]) / std[c] is applied. */
+int cb_stem_pack(int32_t dtype, const void* src, int32_t src_u8, const float* mean3, const float* std3,
+                 void* dst, int32_t N, int32_t H, int32_t W, int32_t Hp, int32_t Wp, int32_t pad,
+                 void* stream);
+
+/* ImageNorm alone (a1): uint8 (n) -> fp32 (x - mean[c]) / std[c], NCHW with plane size hw. */
+int cb_image_norm(const uint8_t* src, float* dst, const float* mean3, const float* std3,
+                  int64_t n_images, int64_t hw, void* stream);
+
+/* Max pooling on NHWC (detectron2 BasicStem max_pool2d k3 s2 p1; grid_encoder MaxPool2d(2,2) +
+ * ReLU, src/modeling/grid_feat.py:46-47).  relu = 1 applies ReLU after pooling. */
+int cb_maxpool_fwd(int32_t dtype, const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C,
+                   int32_t OH, int32_t OW, int32_t k, int32_t stride, int32_t pad, int32_t relu,
+                   void* stream);
+/* Backward of the above for k=2,s=2 (non-overlapping windows): dx gets dy at the arg-max, 0
+ * elsewhere (including rows/cols dropped by floor mode); gated by y > 0 when relu = 1. */
+int cb_maxpool2_bwd(int32_t dtype, const void* x, const void* y, const void* dy, void* dx, int32_t N,
+                    int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t relu, void* stream);
+
+/* g = dy * (y > 0) * scale[c]  (ReLU + FrozenBN backward); optional second output dz = dy * (y > 0)
+ * and third g2 = dz * scale2[c] (projection shortcut).  rows x C, contiguous. */
+int cb_relu_scale_bwd(int32_t dtype, const void* dy, const void* y, const float* scale, void* g,
+                      void* dz, const float* scale2, void* g2, int64_t rows, int32_t C, void* stream);
+
+/* LayerNorm over the last dim (apex FusedLayerNorm, src/modeling/transformers.py:32,148).
+ * y = (x - mean) * rstd * gamma + beta, fp32 statistics; mean/rstd (rows) are saved when non-null. */
+int cb_layernorm_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y,
+                     float* mean, float* rstd, int64_t rows, int32_t D, float eps, void* stream);
+/* dx = LN backward; dgamma/dbeta (fp32, D) are ACCUMULATED with atomics.  dx2 (optional) receives
+ * dx with inverted-dropout mask (seed, p) applied -- the gradient of the dropped GEMM output. */
+int cb_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                     const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int32_t D,
+                     void* dx2, float dropout_p, uint64_t dropout_seed, void* stream);
+
+/* Text embedding (BertEmbeddings.forward, src/modeling/transformers.py:172-199): out row
+ * (b*L_total + t) = LN(word[ids[b,t]] + pos[t] + type[0]); pre-LN sum saved in `pre` when non-null. */
+int cb_text_embed_fwd(int32_t dtype, const int64_t* ids, const void* word, const void* pos, const void* type0,
+                      const float* gamma, const float* beta, void* out, void* pre, float* mean, float* rstd,
+                      int32_t B, int32_t Lt, int32_t L_total, int32_t D, float eps, void* stream);
+/* Visual embedding (VisualInputEmbedding.forward, src/modeling/modeling.py:62-101,124-153) fused
+ * with repeat_tensor_rows (src/datasets/data_utils.py:344-357): out row (b*L_total + Lt + p) =
+ * LN(mean_t grid[src_row[b], t, sel[p]] + row_emb[h] + col_emb[w] + type[0]).  sel (optional) is the
+ * sorted pixel sub-sample of pre-training (modeling.py:80-88). */
+int cb_visual_embed_fwd(int32_t dtype, const void* grid, const int32_t* src_row, const int32_t* sel,
+                        const void* row_emb, const void* col_emb, const void* type0, const float* gamma,
+                        const float* beta, void* out, void* pre, float* mean, float* rstd, int32_t B,
+                        int32_t T, int32_t Hg, int32_t Wg, int32_t Lv, int32_t Lt, int32_t L_total, int32_t D,
+                        float eps, void* stream);
+/* Backward of both embeddings given d(pre) rows in a (B, L_total, D) buffer: scatter-adds (fp32
+ * atomics) into the embedding-table gradients and into dgrid (fp32, zero-initialised by caller). */
+int cb_text_embed_bwd(int32_t dtype, const void* dpre, const int64_t* ids, float* dword, float* dpos,
+                      float* dtype0, int32_t B, int32_t Lt, int32_t L_total, int32_t D, void* stream);
+int cb_visual_embed_bwd(int32_t dtype, const void* dpre, const int32_t* src_row, const int32_t* sel,
+                        float* dgrid, float* drow, float* dcol, float* dtype0, int32_t B, int32_t T,
+                        int32_t Hg, int32_t Wg, int32_t Lv, int32_t Lt, int32_t L_total, int32_t D,
+                        void* stream);
+
+/* Self-attention core (BertSelfAttention.forward, src/modeling/transformers.py:257-282) on the fused
+ * QKV buffer (B*L, 3*H*64): scores = QK^T / 8 + (1 - mask) * -10000, fp32 softmax, ctx = P V, heads
+ * merged into ctx (B*L, H*64).  lse (B,H,L) fp32 is saved for the backward when non-null. */
+int cb_attention_fwd(int32_t dtype, const void* qkv, const float* key_mask, void* ctx, float* lse,
+                     int32_t B, int32_t L, int32_t H, float dropout_p, uint64_t dropout_seed, void* stream);
+int cb_attention_bwd(int32_t dtype, const void* qkv, const float* key_mask, const void* ctx, const void* dctx,
+                     const float* lse, void* dqkv, int32_t B, int32_t L, int32_t H, float dropout_p,
+                     uint64_t dropout_seed, void* stream);
+
+/* Row-wise softmax cross-entropy with ignore_index (CrossEntropyLoss(reduction="none"),
+ * src/modeling/modeling.py:287-298,562-566): loss[r] and (optional) dlogits = (softmax - onehot) *
+ * dloss[r].  logits fp32 (rows, C). */
+int cb_cross_entropy(const float* logits, const int64_t* labels, float* loss, float* dlogits,
+                     const float* dloss, int64_t rows, int32_t C, int64_t ignore_index, void* stream);
+
+/* Column sums: out[n] (+)= sum_m g[m,n]  (bias gradients).  fp32 atomics into out. */
+int cb_colsum(int32_t dtype, const void* g, int64_t ldg, float* out, int64_t M, int32_t N, void* stream);
+
+/* Elementwise helpers on contiguous buffers. */
+int cb_cast(int32_t src_dtype, const void* src, int32_t dst_dtype, void* dst, int64_t n, void* stream);
+int cb_gelu_bwd(int32_t dtype, const void* dy, const void* pre, void* dx, int64_t n, void* stream);
+int cb_act_bwd(int32_t dtype, int32_t act, const void* dy, const void* y, void* dx, int64_t n, void* stream);
+
+/* Fused AdamW over a flat fp32 parameter range (src/optimization/adamw.py:40-103) with global-norm
+ * clipping (run_video_retrieval.py:477-482): p, g, m, v are fp32 arrays of n elements; `w16`
+ * (optional) receives the bf16 compute copy.  grad_sq_sum: device scalar holding sum(g^2) over ALL
+ * parameters (cb_sq_sum); clip coefficient = min(1, max_norm / (sqrt(sum) + 1e-6)); max_norm <= 0
+ * disables clipping.  grad_scale multiplies g first (1/world_size when gradients were summed). */
+int cb_adamw(float* p, const float* g, float* m, float* v, void* w16, int64_t n, float lr, float beta1,
+             float beta2, float eps, float weight_decay, int32_t step, const float* grad_sq_sum,
+             float max_norm, float grad_scale, void* stream);
+int cb_sq_sum(const float* g, int64_t n, float* out_accum, void* stream);
+
+const char* cb_last_error(void);
+int cb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIPBERT_HIP_H */

@@ -20,3 +20,23 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def emul_lib():
+    """The product HIP sources compiled against the host lane-level emulator (tests/emul)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emul"))
+    import build_emul
+    import ctypes
+    from clipbert_amd import _lib
+    path = build_emul.build()
+    return _lib.bind(ctypes.CDLL(path), strict=False)
+
+
+@pytest.fixture()
+def emul(emul_lib, monkeypatch):
+    """Route clipbert_amd.ops through the emulator build (CPU tensors, host pointers) for one test."""
+    from clipbert_amd import _lib, ops
+    monkeypatch.setattr(_lib, "_LIB", emul_lib)
+    monkeypatch.setattr(ops, "_ALLOW_HOST_POINTERS", True)
+    return emul_lib

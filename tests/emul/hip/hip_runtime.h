@@ -1,0 +1,202 @@
+// Lane-level HOST emulator of the HIP device environment -- TEST INFRASTRUCTURE ONLY.
+//
+// The product kernels in clipbert_amd/csrc/*.hip are pure gfx950 HIP (no dual paths).  Because
+// the build container has no GPU, the CPU test-suite compiles those SAME source files with the host
+// clang++ against this header (-I tests/emul shadows <hip/hip_runtime.h>) into
+// tests/emul/_build/libclipbert_emul.so and drives them through the same C ABI.  This checks the
+// index arithmetic, tiling, boundary handling and numerics of every kernel on CPU.  It is never
+// loaded by clipbert_amd/ (the product loader only opens libclipbert_hip.so and fails loudly).
+//
+// Model: each GPU thread is a cooperative fiber; a block's fibers run round-robin on one OS thread
+// and switch only at collective points (__syncthreads, MFMA, shuffles).  Blocks of a grid are spread
+// over a few OS threads.  MFMA fragment layouts follow cdna_hip_programming.md section 3.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <type_traits>
+
+struct dim3 {
+    unsigned x, y, z;
+    constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline const char* hipGetErrorString(hipError_t) { return "emul"; }
+static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+enum hipMemcpyKind { hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
+    memmove(d, s, n); return 0;
+}
+
+namespace emul {
+constexpr int kWave = 64;
+struct Wave {
+    int arrive = 0;
+    int gen = 0;
+    int nlanes = 64;
+    alignas(16) unsigned char buf[2][kWave][64];
+};
+struct Fiber {
+    void* sp = nullptr;
+    dim3 tid;
+    int lane = 0;
+    int wave = 0;
+    bool done = false;
+};
+struct Block {
+    dim3 bid, bdim, gdim;
+    int nthreads = 0;
+    int bar_arrive = 0;
+    int bar_gen = 0;
+    Wave* waves = nullptr;
+};
+extern thread_local Fiber* cur;
+extern thread_local Block* blk;
+void yield();
+// run `body` once per thread of every block of the grid
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+
+inline void block_barrier() {
+    Block* b = blk;
+    int g = b->bar_gen;
+    if (++b->bar_arrive == b->nthreads) { b->bar_arrive = 0; b->bar_gen++; return; }
+    while (b->bar_gen == g) yield();
+}
+// deposit `bytes` (<= 64) for this lane, wait for the whole wave, return the wave's table
+inline unsigned char (*wave_collect(const void* mine, int bytes))[64] {
+    Wave& w = blk->waves[cur->wave];
+    int g = w.gen, par = g & 1;
+    memcpy(w.buf[par][cur->lane], mine, bytes);
+    if (++w.arrive == w.nlanes) { w.arrive = 0; w.gen++; }
+    else while (w.gen == g) yield();
+    return w.buf[par];
+}
+}  // namespace emul
+
+#define threadIdx (emul::cur->tid)
+#define blockIdx (emul::blk->bid)
+#define blockDim (emul::blk->bdim)
+#define gridDim (emul::blk->gdim)
+constexpr int warpSize = 64;
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+
+namespace emul {
+template <class K, class... A> inline void launch_kernel(dim3 g, dim3 b, K k, A... a) {
+    launch(g, b, [&]() { k(a...); });
+}
+}  // namespace emul
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    emul::launch_kernel((grid), (block), (kernel), __VA_ARGS__)
+
+static inline void __syncthreads() { emul::block_barrier(); }
+static inline void __builtin_amdgcn_s_barrier() { emul::block_barrier(); }
+static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline void __builtin_amdgcn_s_setprio(int) {}
+template <class T> static inline T __builtin_amdgcn_readfirstlane(T v) { return v; }
+
+// ---- shuffles ------------------------------------------------------------------------------
+template <class T> static inline T __shfl(T v, int src, int width = 64) {
+    static_assert(sizeof(T) <= 64, "");
+    auto tab = emul::wave_collect(&v, sizeof(T));
+    int lane = emul::cur->lane;
+    int base = lane & ~(width - 1);
+    T r; memcpy(&r, tab[base + (src & (width - 1))], sizeof(T));
+    return r;
+}
+template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) {
+    auto tab = emul::wave_collect(&v, sizeof(T));
+    int lane = emul::cur->lane;
+    int src = lane ^ mask;
+    if ((src & ~(width - 1)) != (lane & ~(width - 1))) src = lane;
+    T r; memcpy(&r, tab[src], sizeof(T));
+    return r;
+}
+template <class T> static inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    auto tab = emul::wave_collect(&v, sizeof(T));
+    int lane = emul::cur->lane;
+    int src = lane + (int)delta;
+    if ((src & ~(width - 1)) != (lane & ~(width - 1))) src = lane;
+    T r; memcpy(&r, tab[src], sizeof(T));
+    return r;
+}
+
+// ---- MFMA ----------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 emul_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float emul_f32x4;
+
+// D = A(16x32) * B(32x16) + C.  A: lane l holds A[l&15][8*(l>>4)+j]; B: lane l holds
+// B[8*(l>>4)+j][l&15]; C/D: lane l reg r -> row 4*(l>>4)+r, col l&15.
+static inline emul_f32x4 emul_mfma_f32_16x16x32_bf16(emul_bf16x8 a, emul_bf16x8 b, emul_f32x4 c, int, int, int) {
+    struct { emul_bf16x8 a, b; } mine{a, b};
+    auto tab = emul::wave_collect(&mine, sizeof(mine));
+    int l = emul::cur->lane, col = l & 15;
+    emul_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (l >> 4) + r;
+        float acc = 0.f;
+        for (int k = 0; k < 32; ++k) {
+            emul_bf16x8 av, bv;
+            memcpy(&av, tab[row + 16 * (k >> 3)], 16);
+            memcpy(&bv, tab[col + 16 * (k >> 3)] + 16, 16);
+            acc += (float)av[k & 7] * (float)bv[k & 7];
+        }
+        d[r] += acc;
+    }
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emul_mfma_f32_16x16x32_bf16
+
+// f32-input MFMA: A lane l holds A[l&15][l>>4]; B lane l holds B[l>>4][l&15]; k = 0..3.
+static inline emul_f32x4 emul_mfma_f32_16x16x4f32(float a, float b, emul_f32x4 c, int, int, int) {
+    struct { float a, b; } mine{a, b};
+    auto tab = emul::wave_collect(&mine, sizeof(mine));
+    int l = emul::cur->lane, col = l & 15;
+    emul_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (l >> 4) + r;
+        float acc = d[r];
+        for (int k = 0; k < 4; ++k) {
+            float av, bv;
+            memcpy(&av, tab[row + 16 * k], 4);
+            memcpy(&bv, tab[col + 16 * k] + 4, 4);
+            acc = fmaf(av, bv, acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 emul_mfma_f32_16x16x4f32
+
+// ---- atomics -------------------------------------------------------------------------------
+static inline float atomicAdd(float* p, float v) {
+    uint32_t* u = reinterpret_cast<uint32_t*>(p);
+    uint32_t old = __atomic_load_n(u, __ATOMIC_RELAXED);
+    for (;;) {
+        float f; memcpy(&f, &old, 4); f += v;
+        uint32_t nu; memcpy(&nu, &f, 4);
+        if (__atomic_compare_exchange_n(u, &old, nu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+            float o; memcpy(&o, &old, 4); return o;
+        }
+    }
+}
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+
+// ---- math ----------------------------------------------------------------------------------
+#define __expf(x) expf(x)
+#define __logf(x) logf(x)
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __fdividef(float a, float b) { return a / b; }

@@ -42,14 +42,13 @@ _SIGNATURES = {
     "cb_text_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "cb_visual_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
                             i32, i32, i32, f32, vp],
-    "cb_text_embed_bwd": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "cb_text_embed_bwd": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, vp],
     "cb_visual_embed_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "cb_attention_fwd": [i32, vp, vp, vp, vp, i32, i32, i32, f32, u64, vp],
-    "cb_attention_bwd": [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, u64, vp],
+    "cb_attention_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, u64, vp],
     "cb_cross_entropy": [vp, vp, vp, vp, vp, i64, i32, i64, vp],
     "cb_colsum": [i32, vp, i64, vp, i64, i32, vp],
     "cb_cast": [i32, vp, i32, vp, i64, vp],
-    "cb_gelu_bwd": [i32, vp, vp, vp, i64, vp],
     "cb_act_bwd": [i32, i32, vp, vp, vp, i64, vp],
     "cb_adamw": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, f32, vp],
     "cb_sq_sum": [vp, i64, vp, vp],

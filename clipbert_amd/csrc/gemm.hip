@@ -199,6 +199,72 @@ template <typename T, int ROWS> struct KrowLoader {
     }
 };
 
+
+// ---------------------------------------------------------------------------------------------
+// Epilogue of one 4-wide accumulator fragment (row m, columns nb..nb+3).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void epilogue_vec(const GP& p, f32x4 v, int m, int64_t orow, int nb) {
+    v = v * p.alpha;
+    if (p.scale) v = v * load4(p.scale + nb);
+    if (p.shift) v = v + load4(p.shift + nb);
+    if (p.C2) store4(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + nb, v);
+    if (p.act != CB_ACT_NONE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act(p.act, v[r]);
+    }
+    if (p.dropout_p > 0.f) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= dropout_mult(p.seed, (uint64_t)m * p.N + nb + r, p.dropout_p);
+    }
+    if (p.residual) v = v + load4(reinterpret_cast<const T*>(p.residual) + orow * p.ldr + nb);
+    if (p.relu_after) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+    }
+    if (p.mask) {
+        f32x4 mk = load4(reinterpret_cast<const T*>(p.mask) + orow * p.ldm + nb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
+    }
+    if (p.c_f32) {
+        float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + nb;
+        if (p.split_k > 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(c + r, v[r]);
+        } else {
+            if (p.accumulate) v = v + load4(c);
+            store4(c, v);
+        }
+    } else {
+        T* c = reinterpret_cast<T*>(p.C) + orow * p.ldc + nb;
+        if (p.accumulate) v = v + load4(c);
+        store4(c, v);
+    }
+}
+
+// one element (ragged / unaligned edge path; reached through the LDS-staged slow epilogue below)
+template <typename T>
+__device__ __forceinline__ void epilogue_elem(const GP& p, float x, int m, int64_t orow, int n) {
+    x *= p.alpha;
+    if (p.scale) x *= p.scale[n];
+    if (p.shift) x += p.shift[n];
+    if (p.C2) reinterpret_cast<T*>(p.C2)[orow * p.ldc2 + n] = from_f32<T>(x);
+    x = apply_act(p.act, x);
+    if (p.dropout_p > 0.f) x *= dropout_mult(p.seed, (uint64_t)m * p.N + n, p.dropout_p);
+    if (p.residual) x += to_f32(reinterpret_cast<const T*>(p.residual)[orow * p.ldr + n]);
+    if (p.relu_after) x = x > 0.f ? x : 0.f;
+    if (p.mask) x = to_f32(reinterpret_cast<const T*>(p.mask)[orow * p.ldm + n]) > 0.f ? x : 0.f;
+    if (p.c_f32) {
+        float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + n;
+        if (p.split_k > 1) atomicAdd(c, x);
+        else *c = p.accumulate ? (*c + x) : x;
+    } else {
+        T* c = reinterpret_cast<T*>(p.C) + orow * p.ldc + n;
+        *c = from_f32<T>(p.accumulate ? (to_f32(*c) + x) : x);
+    }
+}
+
 template <typename T, int BM, int BN, bool A_KROW, bool B_KROW>
 __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
     using X = Tr<T>;
@@ -288,78 +354,41 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
     }
 
     // ---- epilogue: lane owns n = nb..nb+3 of row m ------------------------------------------------
-    const float alpha = p.alpha;
-    const T* res = reinterpret_cast<const T*>(p.residual);
-    const T* msk = reinterpret_cast<const T*>(p.mask);
+    const bool fast = p.c_vec && (n0 + BN <= p.N);      // block-uniform
+    if (fast) {
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wm * WM + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
-        const int64_t orow = p.c_rowmap ? (int64_t)p.c_rowmap[m] : (int64_t)m;
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * WM + i * 16 + (lane & 15);
+            const bool mok = m < p.M;
+            const int64_t orow = (mok && p.c_rowmap) ? (int64_t)p.c_rowmap[m] : (int64_t)m;
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int nb = n0 + wn * WN + j * 16 + 4 * (lane >> 4);
-            if (nb >= p.N) continue;
-            f32x4 v = acc[i][j] * alpha;
-            const bool full = p.c_vec && (nb + 3 < p.N);
-            if (full) {
-                if (p.scale) v = v * load4(p.scale + nb);
-                if (p.shift) v = v + load4(p.shift + nb);
-                if (p.C2) store4(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + nb, v);
-                if (p.act != CB_ACT_NONE) {
+            for (int j = 0; j < FN; ++j) {
+                const int nb = n0 + wn * WN + j * 16 + 4 * (lane >> 4);
+                if (mok) epilogue_vec<T>(p, acc[i][j], m, orow, nb);
+            }
+        }
+    } else {
+        // ragged N edge or unaligned output: stage the accumulators through LDS (free after the main
+        // loop), half the tile rows at a time, then run a plain bounds-checked per-element loop.
+        float* stage = reinterpret_cast<float*>(smem);
+        static_assert(WM * BN * 4 <= 2 * (TILE_A + TILE_B), "staging does not fit");
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = apply_act(p.act, v[r]);
-                }
-                if (p.dropout_p > 0.f) {
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();
+            if (wm == h) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= dropout_mult(p.seed, (uint64_t)m * p.N + nb + r, p.dropout_p);
-                }
-                if (res) v = v + load4(res + orow * p.ldr + nb);
-                if (p.relu_after) {
+                for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-                }
-                if (msk) {
-                    f32x4 mk = load4(msk + orow * p.ldm + nb);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
-                }
-                if (p.c_f32) {
-                    float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + nb;
-                    if (p.split_k > 1) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) atomicAdd(c + r, v[r]);
-                    } else {
-                        if (p.accumulate) v = v + load4(c);
-                        store4(c, v);
-                    }
-                } else {
-                    T* c = reinterpret_cast<T*>(p.C) + orow * p.ldc + nb;
-                    if (p.accumulate) v = v + load4(c);
-                    store4(c, v);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = nb + r;
-                    if (n >= p.N) continue;
-                    float x = v[r];
-                    if (p.scale) x *= p.scale[n];
-                    if (p.shift) x += p.shift[n];
-                    if (p.C2) reinterpret_cast<T*>(p.C2)[orow * p.ldc2 + n] = from_f32<T>(x);
-                    x = apply_act(p.act, x);
-                    if (p.dropout_p > 0.f) x *= dropout_mult(p.seed, (uint64_t)m * p.N + n, p.dropout_p);
-                    if (res) x += to_f32(res[orow * p.ldr + n]);
-                    if (p.relu_after) x = x > 0.f ? x : 0.f;
-                    if (msk) x = to_f32(msk[orow * p.ldm + n]) > 0.f ? x : 0.f;
-                    if (p.c_f32) {
-                        float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + n;
-                        if (p.split_k > 1) atomicAdd(c, x);
-                        else *c = p.accumulate ? (*c + x) : x;
-                    } else {
-                        T* c = reinterpret_cast<T*>(p.C) + orow * p.ldc + n;
-                        *c = from_f32<T>(p.accumulate ? (to_f32(*c) + x) : x);
-                    }
+                    for (int j = 0; j < FN; ++j)
+                        *reinterpret_cast<f32x4*>(stage + (i * 16 + (lane & 15)) * BN + wn * WN + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+            }
+            __syncthreads();
+            for (int idx = tid; idx < WM * BN; idx += NTHREADS) {
+                const int rl = idx / BN, cl = idx % BN;
+                const int m = m0 + h * WM + rl, n = n0 + cl;
+                if (m < p.M && n < p.N) {
+                    const int64_t orow = p.c_rowmap ? (int64_t)p.c_rowmap[m] : (int64_t)m;
+                    epilogue_elem<T>(p, stage[idx], m, orow, n);
                 }
             }
         }

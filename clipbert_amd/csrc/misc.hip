@@ -1,0 +1,131 @@
+// Small fp32 / elementwise kernels around the heads: softmax cross-entropy (+ gradient), column sums
+// (bias gradients), dtype casts, activation backward.
+#include "common.h"
+
+namespace {
+
+// one wave per row; logits fp32 (rows, C)
+__global__ void __launch_bounds__(256) cross_entropy_kernel(const float* logits, const int64_t* labels, float* loss, float* dlogits,
+                                                            const float* dloss, int64_t rows, int C, int64_t ignore_index) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* x = logits + row * C;
+    const int64_t y = labels[row];
+    const bool ignored = (y == ignore_index);
+    float m = -3.0e38f;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, x[c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += __expf(x[c] - m);
+    s = wave_sum(s);
+    const float lse = m + __logf(s);
+    if (lane == 0 && loss) loss[row] = ignored ? 0.f : (lse - x[y]);
+    if (dlogits) {
+        const float g = ignored ? 0.f : (dloss ? dloss[row] : 1.0f);
+        float* d = dlogits + row * C;
+        for (int c = lane; c < C; c += 64) {
+            float p = __expf(x[c] - lse);
+            d[c] = g * (p - ((int64_t)c == y ? 1.0f : 0.0f));
+        }
+    }
+}
+
+// out[n] += sum over a slab of rows; thread = column, blockIdx.y = row slab
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_kernel(const T* g, int64_t ldg, float* out, int64_t M, int N, int64_t rows_per) {
+    int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    int64_t m0 = (int64_t)blockIdx.y * rows_per;
+    int64_t m1 = m0 + rows_per < M ? m0 + rows_per : M;
+    float s = 0.f;
+    for (int64_t m = m0; m < m1; ++m) s += to_f32(g[m * ldg + n]);
+    atomicAdd(out + n, s);
+}
+
+template <typename S, typename D>
+__global__ void __launch_bounds__(256) cast_kernel(const S* src, D* dst, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        store4(dst + i, load4(src + i));
+    } else {
+        for (; i < n; ++i) dst[i] = from_f32<D>(to_f32(src[i]));
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) act_bwd_kernel(int act, const T* dy, const T* ref, T* dx, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 3 < n) {
+        f32x4 g = load4(dy + i), r = load4(ref + i), o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float d;
+            if (act == CB_ACT_GELU) d = gelu_erf_grad(r[e]);          // ref = pre-activation
+            else if (act == CB_ACT_RELU) d = r[e] > 0.f ? 1.f : 0.f;  // ref = output
+            else if (act == CB_ACT_TANH) d = 1.0f - r[e] * r[e];      // ref = output
+            else d = 1.0f;
+            o[e] = g[e] * d;
+        }
+        store4(dx + i, o);
+    } else {
+        for (; i < n; ++i) {
+            float r = to_f32(ref[i]), d;
+            if (act == CB_ACT_GELU) d = gelu_erf_grad(r);
+            else if (act == CB_ACT_RELU) d = r > 0.f ? 1.f : 0.f;
+            else if (act == CB_ACT_TANH) d = 1.0f - r * r;
+            else d = 1.0f;
+            dx[i] = from_f32<T>(to_f32(dy[i]) * d);
+        }
+    }
+}
+
+inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+extern "C" int cb_cross_entropy(const float* logits, const int64_t* labels, float* loss, float* dlogits, const float* dloss,
+                                int64_t rows, int32_t C, int64_t ignore_index, void* stream) {
+    CB_REQUIRE(logits && labels && C > 0, "cb_cross_entropy: bad arguments");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(cross_entropy_kernel, dim3(nblk(rows, 4)), dim3(256), 0, cb_stream(stream), logits, labels, loss, dlogits,
+                       dloss, rows, C, ignore_index);
+    return cb_launch_status("cb_cross_entropy");
+}
+
+extern "C" int cb_colsum(int32_t dtype, const void* g, int64_t ldg, float* out, int64_t M, int32_t N, void* stream) {
+    CB_REQUIRE(g && out && N > 0, "cb_colsum: bad arguments");
+    if (M == 0) return 0;
+    int64_t slabs = (M + 127) / 128;
+    if (slabs > 256) slabs = 256;
+    int64_t rows_per = (M + slabs - 1) / slabs;
+    dim3 gr(nblk(N, 256), (unsigned)slabs), b(256);
+    if (dtype == CB_BF16) hipLaunchKernelGGL((colsum_kernel<bf16>), gr, b, 0, cb_stream(stream), (const bf16*)g, ldg, out, M, N, rows_per);
+    else if (dtype == CB_F32) hipLaunchKernelGGL((colsum_kernel<float>), gr, b, 0, cb_stream(stream), (const float*)g, ldg, out, M, N, rows_per);
+    else return cb_fail("cb_colsum: bad dtype");
+    return cb_launch_status("cb_colsum");
+}
+
+extern "C" int cb_cast(int32_t src_dtype, const void* src, int32_t dst_dtype, void* dst, int64_t n, void* stream) {
+    CB_REQUIRE(src && dst, "cb_cast: null pointer");
+    if (n == 0) return 0;
+    dim3 g(nblk(n, 1024)), b(256);
+    hipStream_t st = cb_stream(stream);
+    if (src_dtype == CB_F32 && dst_dtype == CB_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), g, b, 0, st, (const float*)src, (bf16*)dst, n);
+    else if (src_dtype == CB_BF16 && dst_dtype == CB_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), g, b, 0, st, (const bf16*)src, (float*)dst, n);
+    else if (src_dtype == CB_F32 && dst_dtype == CB_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, st, (const float*)src, (float*)dst, n);
+    else if (src_dtype == CB_BF16 && dst_dtype == CB_BF16) hipLaunchKernelGGL((cast_kernel<bf16, bf16>), g, b, 0, st, (const bf16*)src, (bf16*)dst, n);
+    else return cb_fail("cb_cast: bad dtype");
+    return cb_launch_status("cb_cast");
+}
+
+extern "C" int cb_act_bwd(int32_t dtype, int32_t act, const void* dy, const void* ref, void* dx, int64_t n, void* stream) {
+    CB_REQUIRE(dy && ref && dx, "cb_act_bwd: null pointer");
+    if (n == 0) return 0;
+    dim3 g(nblk(n, 1024)), b(256);
+    if (dtype == CB_BF16) hipLaunchKernelGGL((act_bwd_kernel<bf16>), g, b, 0, cb_stream(stream), act, (const bf16*)dy, (const bf16*)ref, (bf16*)dx, n);
+    else if (dtype == CB_F32) hipLaunchKernelGGL((act_bwd_kernel<float>), g, b, 0, cb_stream(stream), act, (const float*)dy, (const float*)ref, (float*)dx, n);
+    else return cb_fail("cb_act_bwd: bad dtype");
+    return cb_launch_status("cb_act_bwd");
+}

@@ -1,0 +1,378 @@
+// LayerNorm (fp32 statistics) forward/backward and the two embedding front-ends of the cross-modal
+// BERT.  One 64-lane wave owns one row of D elements (D % 4 == 0, D <= 2048): the row lives in
+// registers (4 elements per lane per chunk of 256), statistics are two-pass in fp32 as apex
+// FusedLayerNorm does, and every global access is an 8/16-byte vector.  These kernels are HBM-bound.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXD = 2048;  // NCH chunks of 256 elements, NCH in {3, 4, 8}
+
+// loads row elements (lane + 64*c)*4 .. +3
+template <int MAXCH, typename T>
+__device__ __forceinline__ void load_row(const T* p, int D, int lane, f32x4 (&v)[MAXCH]) {
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        int e = (lane + 64 * c) * 4;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        v[c] = (e < D) ? load4(p + e) : z;
+    }
+}
+
+template <int MAXCH>
+__device__ __forceinline__ void row_stats(const f32x4 (&v)[MAXCH], int D, int lane, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+    mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        int e = (lane + 64 * c) * 4;
+        if (e < D) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { float d = v[c][i] - mean; q += d * d; }
+        }
+    }
+    rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+}
+
+template <int MAXCH, typename T>
+__device__ __forceinline__ void norm_store(const f32x4 (&v)[MAXCH], const float* gamma, const float* beta, T* y, int D,
+                                           int lane, float mean, float rstd) {
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        int e = (lane + 64 * c) * 4;
+        if (e < D) {
+            f32x4 g = load4(gamma + e), b = load4(beta + e), o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (v[c][i] - mean) * rstd * g[i] + b[i];
+            store4(y + e, o);
+        }
+    }
+}
+
+template <typename T, int MAXCH>
+__global__ void __launch_bounds__(256) layernorm_fwd_kernel(const T* x, const float* gamma, const float* beta, T* y,
+                                                            float* mean_out, float* rstd_out, int64_t rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    f32x4 v[MAXCH];
+    load_row(x + row * D, D, lane, v);
+    float mean, rstd;
+    row_stats(v, D, lane, eps, mean, rstd);
+    norm_store(v, gamma, beta, y + row * D, D, lane, mean, rstd);
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+}
+
+// Each wave walks rows with stride gridDim*4; dgamma/dbeta partials stay in registers, are combined
+// across the block's 4 waves through LDS and flushed with one atomic per element per block.
+template <typename T, int MAXCH>
+__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
+                                                            const float* rstd, T* dx, float* dgamma, float* dbeta,
+                                                            int64_t rows, int D, T* dx2, float drop_p, uint64_t seed) {
+    __shared__ float red[2][4][256];   // [gamma|beta][wave][one 256-element chunk]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 ag[MAXCH], ab[MAXCH];
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; ag[c] = z; ab[c] = z; }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        f32x4 g[MAXCH], xv[MAXCH];
+        load_row(dy + row * D, D, lane, g);
+        load_row(x + row * D, D, lane, xv);
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            int e = (lane + 64 * c) * 4;
+            if (e < D) {
+                f32x4 gm = load4(gamma + e);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float xh = (xv[c][i] - mu) * rs;
+                    float dg = g[c][i] * gm[i];
+                    ag[c][i] += g[c][i] * xh;
+                    ab[c][i] += g[c][i];
+                    s1 += dg; s2 += dg * xh;
+                    xv[c][i] = xh; g[c][i] = dg;
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            int e = (lane + 64 * c) * 4;
+            if (e < D) {
+                f32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = rs * (g[c][i] - c1 - xv[c][i] * c2);
+                store4(dx + row * D + e, o);
+                if (dx2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] *= dropout_mult(seed, (uint64_t)row * D + e + i, drop_p);
+                    store4(dx2 + row * D + e, o);
+                }
+            }
+        }
+    }
+    // block reduction of the parameter gradients, chunk by chunk (LDS: 2 x 4 waves x 256 floats)
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        if (c * 256 >= D) break;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            red[0][wave][lane * 4 + i] = ag[c][i];
+            red[1][wave][lane * 4 + i] = ab[c][i];
+        }
+        __syncthreads();
+        int e = threadIdx.x;                        // 256 threads <-> 256 elements of this chunk
+        int col = c * 256 + e;
+        if (col < D) {
+            float sg = red[0][0][e] + red[0][1][e] + red[0][2][e] + red[0][3][e];
+            float sb = red[1][0][e] + red[1][1][e] + red[1][2][e] + red[1][3][e];
+            atomicAdd(dgamma + col, sg);
+            atomicAdd(dbeta + col, sb);
+        }
+    }
+}
+
+// ---- embeddings -----------------------------------------------------------------------------------
+template <typename T, int MAXCH>
+__global__ void __launch_bounds__(256) text_embed_fwd_kernel(const int64_t* ids, const T* word, const T* pos, const T* type0,
+                                                             const float* gamma, const float* beta, T* out, T* pre,
+                                                             float* mean_out, float* rstd_out, int B, int Lt, int Ltot, int D,
+                                                             float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= (int64_t)B * Lt) return;
+    const int b = (int)(tok / Lt), t = (int)(tok % Lt);
+    const int64_t orow = (int64_t)b * Ltot + t;
+    const int64_t id = ids[tok];
+    f32x4 v[MAXCH], a[MAXCH];
+    load_row(word + id * D, D, lane, v);
+    load_row(pos + (int64_t)t * D, D, lane, a);
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) v[c] = v[c] + a[c];
+    load_row(type0, D, lane, a);
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) v[c] = v[c] + a[c];
+    if (pre) {
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) { int e = (lane + 64 * c) * 4; if (e < D) store4(pre + orow * D + e, v[c]); }
+    }
+    float mean, rstd;
+    row_stats(v, D, lane, eps, mean, rstd);
+    norm_store(v, gamma, beta, out + orow * D, D, lane, mean, rstd);
+    if (lane == 0) {
+        if (mean_out) mean_out[orow] = mean;
+        if (rstd_out) rstd_out[orow] = rstd;
+    }
+}
+
+template <typename T, int MAXCH>
+__global__ void __launch_bounds__(256) visual_embed_fwd_kernel(const T* grid, const int32_t* src_row, const int32_t* sel,
+                                                               const T* row_emb, const T* col_emb, const T* type0,
+                                                               const float* gamma, const float* beta, T* out, T* pre,
+                                                               float* mean_out, float* rstd_out, int B, int Tf, int Hg, int Wg,
+                                                               int Lv, int Lt, int Ltot, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= (int64_t)B * Lv) return;
+    const int b = (int)(tok / Lv), pidx = (int)(tok % Lv);
+    const int q = sel ? sel[pidx] : pidx;
+    const int h = q / Wg, w = q % Wg;
+    const int64_t src = src_row ? src_row[b] : b;
+    const int64_t orow = (int64_t)b * Ltot + Lt + pidx;
+    f32x4 v[MAXCH], a[MAXCH];
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; v[c] = z; }
+    for (int t = 0; t < Tf; ++t) {
+        load_row(grid + (((src * Tf + t) * Hg + h) * Wg + w) * D, D, lane, a);
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) v[c] = v[c] + a[c];
+    }
+    const float inv = 1.0f / (float)Tf;
+    load_row(row_emb + (int64_t)h * D, D, lane, a);
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) v[c] = v[c] * inv + a[c];
+    load_row(col_emb + (int64_t)w * D, D, lane, a);
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) v[c] = v[c] + a[c];
+    load_row(type0, D, lane, a);
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) v[c] = v[c] + a[c];
+    if (pre) {
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) { int e = (lane + 64 * c) * 4; if (e < D) store4(pre + orow * D + e, v[c]); }
+    }
+    float mean, rstd;
+    row_stats(v, D, lane, eps, mean, rstd);
+    norm_store(v, gamma, beta, out + orow * D, D, lane, mean, rstd);
+    if (lane == 0) {
+        if (mean_out) mean_out[orow] = mean;
+        if (rstd_out) rstd_out[orow] = rstd;
+    }
+}
+
+// one thread per (token, 4 channels): scatter-add into the table gradients
+template <typename T>
+__global__ void __launch_bounds__(256) text_embed_bwd_kernel(const T* dpre, const int64_t* ids, float* dword, float* dpos,
+                                                             float* dtype0, int B, int Lt, int Ltot, int D, int64_t pad_id) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int D4 = D >> 2;
+    if (idx >= (int64_t)B * Lt * D4) return;
+    int e = (int)(idx % D4) * 4;
+    int64_t tok = idx / D4;
+    int b = (int)(tok / Lt), t = (int)(tok % Lt);
+    f32x4 g = load4(dpre + ((int64_t)b * Ltot + t) * D + e);
+    int64_t id = ids[tok];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (id != pad_id) atomicAdd(dword + id * D + e + i, g[i]);
+        atomicAdd(dpos + (int64_t)t * D + e + i, g[i]);
+        atomicAdd(dtype0 + e + i, g[i]);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) visual_embed_bwd_kernel(const T* dpre, const int32_t* src_row, const int32_t* sel,
+                                                               float* dgrid, float* drow, float* dcol, float* dtype0, int B,
+                                                               int Tf, int Hg, int Wg, int Lv, int Lt, int Ltot, int D) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int D4 = D >> 2;
+    if (idx >= (int64_t)B * Lv * D4) return;
+    int e = (int)(idx % D4) * 4;
+    int64_t tok = idx / D4;
+    int b = (int)(tok / Lv), pidx = (int)(tok % Lv);
+    int q = sel ? sel[pidx] : pidx;
+    int h = q / Wg, w = q % Wg;
+    int64_t src = src_row ? src_row[b] : b;
+    f32x4 g = load4(dpre + ((int64_t)b * Ltot + Lt + pidx) * D + e);
+    const float inv = 1.0f / (float)Tf;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        for (int t = 0; t < Tf; ++t) atomicAdd(dgrid + (((src * Tf + t) * Hg + h) * Wg + w) * D + e + i, g[i] * inv);
+        atomicAdd(drow + (int64_t)h * D + e + i, g[i]);
+        atomicAdd(dcol + (int64_t)w * D + e + i, g[i]);
+        atomicAdd(dtype0 + e + i, g[i]);
+    }
+}
+
+inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+#define CB_D_OK(D) ((D) > 0 && (D) % 4 == 0 && (D) <= MAXD)
+
+// dispatch FUNC<T, NCH>(args...) on dtype and on the number of 256-element chunks a row needs
+#define CB_DISPATCH(FUNC, ...)                                                        \
+    do {                                                                              \
+        const int nch_ = D <= 768 ? 3 : (D <= 1024 ? 4 : 8);                          \
+        if (dtype == CB_BF16) {                                                       \
+            if (nch_ == 3) FUNC<bf16, 3>(__VA_ARGS__);                                \
+            else if (nch_ == 4) FUNC<bf16, 4>(__VA_ARGS__);                           \
+            else FUNC<bf16, 8>(__VA_ARGS__);                                          \
+        } else if (dtype == CB_F32) {                                                 \
+            if (nch_ == 3) FUNC<float, 3>(__VA_ARGS__);                               \
+            else if (nch_ == 4) FUNC<float, 4>(__VA_ARGS__);                          \
+            else FUNC<float, 8>(__VA_ARGS__);                                         \
+        } else return cb_fail("bad dtype %d", dtype);                                 \
+    } while (0)
+
+template <typename T, int NCH>
+void run_ln_fwd(hipStream_t st, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                int64_t rows, int D, float eps) {
+    hipLaunchKernelGGL((layernorm_fwd_kernel<T, NCH>), dim3(nblk(rows, 4)), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y,
+                       mean, rstd, rows, D, eps);
+}
+template <typename T, int NCH>
+void run_ln_bwd(hipStream_t st, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+                float* dgamma, float* dbeta, int64_t rows, int D, void* dx2, float p, uint64_t seed) {
+    unsigned blocks = nblk(rows, 4);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd,
+                       (T*)dx, dgamma, dbeta, rows, D, (T*)dx2, p, seed);
+}
+template <typename T, int NCH>
+void run_text_fwd(hipStream_t st, const int64_t* ids, const void* word, const void* pos, const void* type0, const float* gamma,
+                  const float* beta, void* out, void* pre, float* mean, float* rstd, int B, int Lt, int Ltot, int D, float eps) {
+    hipLaunchKernelGGL((text_embed_fwd_kernel<T, NCH>), dim3(nblk((int64_t)B * Lt, 4)), dim3(256), 0, st, ids, (const T*)word,
+                       (const T*)pos, (const T*)type0, gamma, beta, (T*)out, (T*)pre, mean, rstd, B, Lt, Ltot, D, eps);
+}
+template <typename T, int NCH>
+void run_vis_fwd(hipStream_t st, const void* grid, const int32_t* src_row, const int32_t* sel, const void* row_emb,
+                 const void* col_emb, const void* type0, const float* gamma, const float* beta, void* out, void* pre, float* mean,
+                 float* rstd, int B, int Tf, int Hg, int Wg, int Lv, int Lt, int Ltot, int D, float eps) {
+    hipLaunchKernelGGL((visual_embed_fwd_kernel<T, NCH>), dim3(nblk((int64_t)B * Lv, 4)), dim3(256), 0, st, (const T*)grid, src_row,
+                       sel, (const T*)row_emb, (const T*)col_emb, (const T*)type0, gamma, beta, (T*)out, (T*)pre, mean, rstd, B, Tf,
+                       Hg, Wg, Lv, Lt, Ltot, D, eps);
+}
+
+}  // namespace
+
+extern "C" int cb_layernorm_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                float* rstd, int64_t rows, int32_t D, float eps, void* stream) {
+    CB_REQUIRE(x && y && gamma && beta && CB_D_OK(D), "cb_layernorm_fwd: bad arguments (D %% 4 == 0, D <= 2048)");
+    if (rows == 0) return 0;
+    CB_DISPATCH(run_ln_fwd, cb_stream(stream), x, gamma, beta, y, mean, rstd, rows, D, eps);
+    return cb_launch_status("cb_layernorm_fwd");
+}
+
+extern "C" int cb_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                                const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int32_t D, void* dx2,
+                                float dropout_p, uint64_t dropout_seed, void* stream) {
+    CB_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && CB_D_OK(D), "cb_layernorm_bwd: bad arguments");
+    if (rows == 0) return 0;
+    CB_DISPATCH(run_ln_bwd, cb_stream(stream), dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, dx2, dropout_p, dropout_seed);
+    return cb_launch_status("cb_layernorm_bwd");
+}
+
+extern "C" int cb_text_embed_fwd(int32_t dtype, const int64_t* ids, const void* word, const void* pos, const void* type0,
+                                 const float* gamma, const float* beta, void* out, void* pre, float* mean, float* rstd,
+                                 int32_t B, int32_t Lt, int32_t L_total, int32_t D, float eps, void* stream) {
+    CB_REQUIRE(ids && word && pos && type0 && gamma && beta && out && CB_D_OK(D) && Lt <= L_total, "cb_text_embed_fwd: bad arguments");
+    if ((int64_t)B * Lt == 0) return 0;
+    CB_DISPATCH(run_text_fwd, cb_stream(stream), ids, word, pos, type0, gamma, beta, out, pre, mean, rstd, B, Lt, L_total, D, eps);
+    return cb_launch_status("cb_text_embed_fwd");
+}
+
+extern "C" int cb_visual_embed_fwd(int32_t dtype, const void* grid, const int32_t* src_row, const int32_t* sel,
+                                   const void* row_emb, const void* col_emb, const void* type0, const float* gamma,
+                                   const float* beta, void* out, void* pre, float* mean, float* rstd, int32_t B, int32_t T,
+                                   int32_t Hg, int32_t Wg, int32_t Lv, int32_t Lt, int32_t L_total, int32_t D, float eps,
+                                   void* stream) {
+    CB_REQUIRE(grid && row_emb && col_emb && type0 && gamma && beta && out && CB_D_OK(D) && T > 0 && Lt + Lv <= L_total,
+               "cb_visual_embed_fwd: bad arguments");
+    CB_REQUIRE(sel || Lv == Hg * Wg, "cb_visual_embed_fwd: Lv must equal Hg*Wg without a selection");
+    if ((int64_t)B * Lv == 0) return 0;
+    CB_DISPATCH(run_vis_fwd, cb_stream(stream), grid, src_row, sel, row_emb, col_emb, type0, gamma, beta, out, pre, mean, rstd, B, T,
+                Hg, Wg, Lv, Lt, L_total, D, eps);
+    return cb_launch_status("cb_visual_embed_fwd");
+}
+
+extern "C" int cb_text_embed_bwd(int32_t dtype, const void* dpre, const int64_t* ids, float* dword, float* dpos, float* dtype0,
+                                 int32_t B, int32_t Lt, int32_t L_total, int32_t D, int64_t pad_id, void* stream) {
+    CB_REQUIRE(dpre && ids && dword && dpos && dtype0 && D % 4 == 0, "cb_text_embed_bwd: bad arguments");
+    int64_t total = (int64_t)B * Lt * (D / 4);
+    if (total == 0) return 0;
+    dim3 g(nblk(total, 256)), b(256);
+    if (dtype == CB_BF16) hipLaunchKernelGGL((text_embed_bwd_kernel<bf16>), g, b, 0, cb_stream(stream), (const bf16*)dpre, ids, dword, dpos, dtype0, B, Lt, L_total, D, pad_id);
+    else if (dtype == CB_F32) hipLaunchKernelGGL((text_embed_bwd_kernel<float>), g, b, 0, cb_stream(stream), (const float*)dpre, ids, dword, dpos, dtype0, B, Lt, L_total, D, pad_id);
+    else return cb_fail("cb_text_embed_bwd: bad dtype");
+    return cb_launch_status("cb_text_embed_bwd");
+}
+
+extern "C" int cb_visual_embed_bwd(int32_t dtype, const void* dpre, const int32_t* src_row, const int32_t* sel, float* dgrid,
+                                   float* drow, float* dcol, float* dtype0, int32_t B, int32_t T, int32_t Hg, int32_t Wg,
+                                   int32_t Lv, int32_t Lt, int32_t L_total, int32_t D, void* stream) {
+    CB_REQUIRE(dpre && dgrid && drow && dcol && dtype0 && D % 4 == 0 && T > 0, "cb_visual_embed_bwd: bad arguments");
+    int64_t total = (int64_t)B * Lv * (D / 4);
+    if (total == 0) return 0;
+    dim3 g(nblk(total, 256)), b(256);
+    if (dtype == CB_BF16) hipLaunchKernelGGL((visual_embed_bwd_kernel<bf16>), g, b, 0, cb_stream(stream), (const bf16*)dpre, src_row, sel, dgrid, drow, dcol, dtype0, B, T, Hg, Wg, Lv, Lt, L_total, D);
+    else if (dtype == CB_F32) hipLaunchKernelGGL((visual_embed_bwd_kernel<float>), g, b, 0, cb_stream(stream), (const float*)dpre, src_row, sel, dgrid, drow, dcol, dtype0, B, T, Hg, Wg, Lv, Lt, L_total, D);
+    else return cb_fail("cb_visual_embed_bwd: bad dtype");
+    return cb_launch_status("cb_visual_embed_bwd");
+}

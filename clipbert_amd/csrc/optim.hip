@@ -1,0 +1,93 @@
+// Fused AdamW over flat fp32 ranges with on-device global-norm clipping (no host sync), optionally
+// emitting the bf16 compute copy of the updated weights in the same pass.  HBM-bound:
+// 4 reads + 3 writes of fp32 (+ 1 bf16 write) per parameter.
+#include "common.h"
+
+#include <math.h>
+
+namespace {
+
+__global__ void __launch_bounds__(256) sq_sum_kernel(const float* g, int64_t n, float* out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            f32x4 v = load4(g + i);
+            s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        } else {
+            for (int64_t j = i; j < n; ++j) s += g[j] * g[j];
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+struct PMV { float p, m, v; };
+__device__ __forceinline__ PMV adamw_one(float p, float g, float m, float v, float gs, float b1, float b2, float eps,
+                                         float step_size, float decay) {
+    g *= gs;
+    m = m * b1 + (1.0f - b1) * g;
+    v = v * b2 + (1.0f - b2) * g * g;
+    float denom = sqrtf(v) + eps;
+    p = p - step_size * (m / denom);
+    p = p - decay * p;          // decoupled weight decay AFTER the Adam update (adamw.py:77-101)
+    PMV r = {p, m, v};
+    return r;
+}
+
+__global__ void __launch_bounds__(256) adamw_kernel(float* p, const float* g, float* m, float* v, bf16* w16, int64_t n, float b1,
+                                                    float b2, float eps, float step_size, float decay, const float* sq_sum,
+                                                    float max_norm, float grad_scale) {
+    float gs = grad_scale;
+    if (sq_sum && max_norm > 0.f) {
+        float total = sqrtf(*sq_sum) * grad_scale;
+        float coef = max_norm / (total + 1e-6f);
+        gs *= coef < 1.0f ? coef : 1.0f;
+    }
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 3 < n) {
+        f32x4 pp = load4(p + i), gg = load4(g + i), mm = load4(m + i), vv = load4(v + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            PMV r = adamw_one(pp[e], gg[e], mm[e], vv[e], gs, b1, b2, eps, step_size, decay);
+            pp[e] = r.p; mm[e] = r.m; vv[e] = r.v;
+        }
+        store4(p + i, pp); store4(m + i, mm); store4(v + i, vv);
+        if (w16) store4(w16 + i, pp);
+    } else {
+        for (; i < n; ++i) {
+            PMV r = adamw_one(p[i], g[i], m[i], v[i], gs, b1, b2, eps, step_size, decay);
+            p[i] = r.p; m[i] = r.m; v[i] = r.v;
+            if (w16) w16[i] = (bf16)r.p;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cb_sq_sum(const float* g, int64_t n, float* out_accum, void* stream) {
+    CB_REQUIRE(g && out_accum, "cb_sq_sum: null pointer");
+    if (n == 0) return 0;
+    int64_t blocks = (n + 1023) / 1024;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sq_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, cb_stream(stream), g, n, out_accum);
+    return cb_launch_status("cb_sq_sum");
+}
+
+extern "C" int cb_adamw(float* p, const float* g, float* m, float* v, void* w16, int64_t n, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, int32_t step, const float* grad_sq_sum, float max_norm, float grad_scale,
+                        void* stream) {
+    CB_REQUIRE(p && g && m && v && step >= 1, "cb_adamw: bad arguments");
+    if (n == 0) return 0;
+    double bc1 = 1.0 - pow((double)beta1, (double)step);
+    double bc2 = 1.0 - pow((double)beta2, (double)step);
+    float step_size = (float)((double)lr * sqrt(bc2) / bc1);
+    float decay = weight_decay > 0.f ? lr * weight_decay : 0.f;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, cb_stream(stream), p, g, m, v, (bf16*)w16, n,
+                       beta1, beta2, eps, step_size, decay, grad_sq_sum, max_norm, grad_scale == 0.f ? 1.0f : grad_scale);
+    return cb_launch_status("cb_adamw");
+}

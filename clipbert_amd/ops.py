@@ -89,3 +89,177 @@ def build_pixel_table(n: int, oh: int, ow: int, stride: int, pad: int, sN: int, 
     _chk(_lib.get().cb_build_pixel_table(_ptr(tab), n, oh, ow, stride, pad, sN, sH, sW, _stream(tab)),
          "cb_build_pixel_table")
     return tab
+
+
+def _f3(vals):
+    return (C.c_float * 3)(*[float(v) for v in vals])
+
+
+def stem_pack(src: torch.Tensor, dtype: torch.dtype, pad: int = 3, mean=None, std=None) -> torch.Tensor:
+    """(N,3,H,W) fp32 (already normalised) or uint8 (+mean/std) -> (N, H+2*pad, W+2*pad, 4) zero-padded BGR0."""
+    n, c, h, w = src.shape
+    assert c == 3 and src.is_contiguous()
+    hp, wp = h + 2 * pad, w + 2 * pad
+    dst = torch.empty(n, hp, wp, 4, dtype=dtype, device=src.device)
+    u8 = src.dtype == torch.uint8
+    assert u8 or src.dtype == torch.float32
+    m3 = _f3(mean) if u8 else None
+    s3 = _f3(std) if u8 else None
+    _chk(_lib.get().cb_stem_pack(dtype_code(dtype), _ptr(src), int(u8), m3, s3, _ptr(dst), n, h, w, hp, wp, pad,
+                                 _stream(src)), "cb_stem_pack")
+    return dst
+
+
+def image_norm(frames_u8: torch.Tensor, mean, std) -> torch.Tensor:
+    """ImageNorm (a1): uint8 (..., 3, H, W) -> fp32."""
+    assert frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous() and frames_u8.shape[-3] == 3
+    out = torch.empty(frames_u8.shape, dtype=torch.float32, device=frames_u8.device)
+    hw = frames_u8.shape[-1] * frames_u8.shape[-2]
+    n = frames_u8.numel() // (3 * hw)
+    _chk(_lib.get().cb_image_norm(_ptr(frames_u8), _ptr(out), _f3(mean), _f3(std), n, hw, _stream(out)),
+         "cb_image_norm")
+    return out
+
+
+def maxpool_fwd(x: torch.Tensor, k: int, stride: int, pad: int, relu: bool = False) -> torch.Tensor:
+    """x (N,H,W,C) NHWC."""
+    n, h, w, c = x.shape
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    y = torch.empty(n, oh, ow, c, dtype=x.dtype, device=x.device)
+    _chk(_lib.get().cb_maxpool_fwd(dtype_code(x.dtype), _ptr(x), _ptr(y), n, h, w, c, oh, ow, k, stride, pad,
+                                   int(relu), _stream(x)), "cb_maxpool_fwd")
+    return y
+
+
+def maxpool2_bwd(x, y, dy, relu: bool = False) -> torch.Tensor:
+    n, h, w, c = x.shape
+    oh, ow = y.shape[1], y.shape[2]
+    dx = torch.empty_like(x)
+    _chk(_lib.get().cb_maxpool2_bwd(dtype_code(x.dtype), _ptr(x), _ptr(y), _ptr(dy), _ptr(dx), n, h, w, c, oh, ow,
+                                    int(relu), _stream(x)), "cb_maxpool2_bwd")
+    return dx
+
+
+def relu_scale_bwd(dy, y, scale=None, want_dz=False, scale2=None):
+    """returns (g = dy*(y>0)*scale | None, dz = dy*(y>0) | None, g2 = dz*scale2 | None)."""
+    c = y.shape[-1]
+    rows = y.numel() // c
+    g = torch.empty_like(y) if scale is not None else None
+    dz = torch.empty_like(y) if want_dz else None
+    g2 = torch.empty_like(y) if scale2 is not None else None
+    _chk(_lib.get().cb_relu_scale_bwd(dtype_code(y.dtype), _ptr(dy), _ptr(y), _ptr(scale), _ptr(g), _ptr(dz),
+                                      _ptr(scale2), _ptr(g2), rows, c, _stream(y)), "cb_relu_scale_bwd")
+    return g, dz, g2
+
+
+def layernorm_fwd(x, gamma, beta, eps, save_stats=False, out=None):
+    d = x.shape[-1]
+    rows = x.numel() // d
+    y = out if out is not None else torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    _chk(_lib.get().cb_layernorm_fwd(dtype_code(x.dtype), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean),
+                                     _ptr(rstd), rows, d, eps, _stream(x)), "cb_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dropout_p=0.0, dropout_seed=0):
+    """returns (dx, dx_dropped|None); dgamma/dbeta (fp32) are accumulated in place."""
+    d = x.shape[-1]
+    rows = x.numel() // d
+    dx = torch.empty_like(x)
+    dx2 = torch.empty_like(x) if dropout_p > 0 else None
+    _chk(_lib.get().cb_layernorm_bwd(dtype_code(x.dtype), _ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd),
+                                     _ptr(dx), _ptr(dgamma), _ptr(dbeta), rows, d, _ptr(dx2), dropout_p,
+                                     dropout_seed, _stream(x)), "cb_layernorm_bwd")
+    return dx, dx2
+
+
+def text_embed_fwd(ids, word, pos, type0, gamma, beta, out, pre, mean, rstd, lt, l_total, eps):
+    b = ids.shape[0]
+    d = word.shape[-1]
+    _chk(_lib.get().cb_text_embed_fwd(dtype_code(word.dtype), _ptr(ids), _ptr(word), _ptr(pos), _ptr(type0),
+                                      _ptr(gamma), _ptr(beta), _ptr(out), _ptr(pre), _ptr(mean), _ptr(rstd), b, lt,
+                                      l_total, d, eps, _stream(out)), "cb_text_embed_fwd")
+
+
+def visual_embed_fwd(grid, src_row, sel, row_emb, col_emb, type0, gamma, beta, out, pre, mean, rstd, b, lv, lt,
+                     l_total, eps):
+    _, t, hg, wg, d = grid.shape
+    _chk(_lib.get().cb_visual_embed_fwd(dtype_code(grid.dtype), _ptr(grid), _ptr(src_row), _ptr(sel), _ptr(row_emb),
+                                        _ptr(col_emb), _ptr(type0), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(pre),
+                                        _ptr(mean), _ptr(rstd), b, t, hg, wg, lv, lt, l_total, d, eps, _stream(out)),
+         "cb_visual_embed_fwd")
+
+
+def text_embed_bwd(dpre, ids, dword, dpos, dtype0, lt, l_total, pad_id):
+    b = ids.shape[0]
+    d = dword.shape[-1]
+    _chk(_lib.get().cb_text_embed_bwd(dtype_code(dpre.dtype), _ptr(dpre), _ptr(ids), _ptr(dword), _ptr(dpos),
+                                      _ptr(dtype0), b, lt, l_total, d, pad_id, _stream(dpre)), "cb_text_embed_bwd")
+
+
+def visual_embed_bwd(dpre, src_row, sel, dgrid, drow, dcol, dtype0, b, lv, lt, l_total):
+    _, t, hg, wg, d = dgrid.shape
+    _chk(_lib.get().cb_visual_embed_bwd(dtype_code(dpre.dtype), _ptr(dpre), _ptr(src_row), _ptr(sel), _ptr(dgrid),
+                                        _ptr(drow), _ptr(dcol), _ptr(dtype0), b, t, hg, wg, lv, lt, l_total, d,
+                                        _stream(dpre)), "cb_visual_embed_bwd")
+
+
+def attention_fwd(qkv, key_mask, b, l, h, save_lse=False, dropout_p=0.0, dropout_seed=0):
+    ctx = torch.empty(b * l, h * 64, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(b * h * l, dtype=torch.float32, device=qkv.device) if save_lse else None
+    _chk(_lib.get().cb_attention_fwd(dtype_code(qkv.dtype), _ptr(qkv), _ptr(key_mask), _ptr(ctx), _ptr(lse), b, l, h,
+                                     dropout_p, dropout_seed, _stream(qkv)), "cb_attention_fwd")
+    return ctx, lse
+
+
+def attention_bwd(qkv, key_mask, ctx, dctx, lse, b, l, h, dropout_p=0.0, dropout_seed=0):
+    dqkv = torch.empty_like(qkv)
+    ws = torch.empty(b * h * l, dtype=torch.float32, device=qkv.device)
+    _chk(_lib.get().cb_attention_bwd(dtype_code(qkv.dtype), _ptr(qkv), _ptr(key_mask), _ptr(ctx), _ptr(dctx),
+                                     _ptr(lse), _ptr(ws), _ptr(dqkv), b, l, h, dropout_p, dropout_seed, _stream(qkv)),
+         "cb_attention_bwd")
+    return dqkv
+
+
+def cross_entropy(logits, labels, want_loss=True, dloss=None, want_grad=False, ignore_index=-100):
+    rows, c = logits.shape
+    assert logits.dtype == torch.float32 and logits.is_contiguous()
+    loss = torch.empty(rows, dtype=torch.float32, device=logits.device) if want_loss else None
+    dlogits = torch.empty_like(logits) if want_grad else None
+    _chk(_lib.get().cb_cross_entropy(_ptr(logits), _ptr(labels), _ptr(loss), _ptr(dlogits), _ptr(dloss), rows, c,
+                                     ignore_index, _stream(logits)), "cb_cross_entropy")
+    return loss, dlogits
+
+
+def colsum(g, out, m=None, n=None, ldg=None):
+    """out[n] += sum_m g[m, n] (fp32 atomics)."""
+    m = g.shape[0] if m is None else m
+    n = g.shape[1] if n is None else n
+    _chk(_lib.get().cb_colsum(dtype_code(g.dtype), _ptr(g), ldg if ldg is not None else g.stride(0), _ptr(out), m, n,
+                              _stream(g)), "cb_colsum")
+
+
+def cast(src, dst):
+    assert src.numel() == dst.numel()
+    _chk(_lib.get().cb_cast(dtype_code(src.dtype), _ptr(src), dtype_code(dst.dtype), _ptr(dst), src.numel(),
+                            _stream(src)), "cb_cast")
+    return dst
+
+
+def act_bwd(act, dy, ref):
+    dx = torch.empty_like(dy)
+    _chk(_lib.get().cb_act_bwd(dtype_code(dy.dtype), act, _ptr(dy), _ptr(ref), _ptr(dx), dy.numel(), _stream(dy)),
+         "cb_act_bwd")
+    return dx
+
+
+def sq_sum(g, out):
+    _chk(_lib.get().cb_sq_sum(_ptr(g), g.numel(), _ptr(out), _stream(g)), "cb_sq_sum")
+
+
+def adamw(p, g, m, v, w16, lr, beta1, beta2, eps, weight_decay, step, grad_sq_sum=None, max_norm=-1.0,
+          grad_scale=1.0):
+    _chk(_lib.get().cb_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(w16), p.numel(), lr, beta1, beta2, eps,
+                             weight_decay, step, _ptr(grad_sq_sum), max_norm, grad_scale, _stream(p)), "cb_adamw")

@@ -96,12 +96,14 @@ int cb_build_pixel_table(cb_pixel* tab, int32_t N, int32_t OH, int32_t OW, int32
 /* Stem input pack: (N,3,H,W) fp32 RGB mean-subtracted (or uint8 RGB with mean/std) -> zero-padded
  * NHWC4 image (N, H+2*pad(+), W+2*pad(+), 4) in BGR order, dtype T.  Fuses ImageNorm
  * (src/datasets/data_utils.py:266-276), .float() (dataloader.py:104) and the RGB->BGR gather
- * (src/modeling/grid_feat.py:92-94).  src_u8 = 1: src is uint8 and (v - mean[c]) / std[c] is applied. */
+ * (src/modeling/grid_feat.py:92-94).  src_u8 = 1: src is uint8 and (v - mean[c]) / std[c] is applied.
+ * mean3 / std3 are HOST arrays of 3 floats (RGB order) -- the only host pointers in this ABI. */
 int cb_stem_pack(int32_t dtype, const void* src, int32_t src_u8, const float* mean3, const float* std3,
                  void* dst, int32_t N, int32_t H, int32_t W, int32_t Hp, int32_t Wp, int32_t pad,
                  void* stream);
 
-/* ImageNorm alone (a1): uint8 (n) -> fp32 (x - mean[c]) / std[c], NCHW with plane size hw. */
+/* ImageNorm alone (a1): uint8 (n) -> fp32 (x - mean[c]) / std[c], NCHW with plane size hw.
+ * mean3 / std3: HOST arrays of 3 floats. */
 int cb_image_norm(const uint8_t* src, float* dst, const float* mean3, const float* std3,
                   int64_t n_images, int64_t hw, void* stream);
 
@@ -147,7 +149,8 @@ int cb_visual_embed_fwd(int32_t dtype, const void* grid, const int32_t* src_row,
 /* Backward of both embeddings given d(pre) rows in a (B, L_total, D) buffer: scatter-adds (fp32
  * atomics) into the embedding-table gradients and into dgrid (fp32, zero-initialised by caller). */
 int cb_text_embed_bwd(int32_t dtype, const void* dpre, const int64_t* ids, float* dword, float* dpos,
-                      float* dtype0, int32_t B, int32_t Lt, int32_t L_total, int32_t D, void* stream);
+                      float* dtype0, int32_t B, int32_t Lt, int32_t L_total, int32_t D, int64_t pad_id,
+                      void* stream);   /* rows with ids == pad_id get no word gradient (padding_idx) */
 int cb_visual_embed_bwd(int32_t dtype, const void* dpre, const int32_t* src_row, const int32_t* sel,
                         float* dgrid, float* drow, float* dcol, float* dtype0, int32_t B, int32_t T,
                         int32_t Hg, int32_t Wg, int32_t Lv, int32_t Lt, int32_t L_total, int32_t D,
@@ -158,9 +161,10 @@ int cb_visual_embed_bwd(int32_t dtype, const void* dpre, const int32_t* src_row,
  * merged into ctx (B*L, H*64).  lse (B,H,L) fp32 is saved for the backward when non-null. */
 int cb_attention_fwd(int32_t dtype, const void* qkv, const float* key_mask, void* ctx, float* lse,
                      int32_t B, int32_t L, int32_t H, float dropout_p, uint64_t dropout_seed, void* stream);
+/* dsum_ws: fp32 workspace of B*H*L elements (rowsum(dctx*ctx), produced and consumed inside). */
 int cb_attention_bwd(int32_t dtype, const void* qkv, const float* key_mask, const void* ctx, const void* dctx,
-                     const float* lse, void* dqkv, int32_t B, int32_t L, int32_t H, float dropout_p,
-                     uint64_t dropout_seed, void* stream);
+                     const float* lse, float* dsum_ws, void* dqkv, int32_t B, int32_t L, int32_t H,
+                     float dropout_p, uint64_t dropout_seed, void* stream);
 
 /* Row-wise softmax cross-entropy with ignore_index (CrossEntropyLoss(reduction="none"),
  * src/modeling/modeling.py:287-298,562-566): loss[r] and (optional) dlogits = (softmax - onehot) *
@@ -173,8 +177,8 @@ int cb_colsum(int32_t dtype, const void* g, int64_t ldg, float* out, int64_t M, 
 
 /* Elementwise helpers on contiguous buffers. */
 int cb_cast(int32_t src_dtype, const void* src, int32_t dst_dtype, void* dst, int64_t n, void* stream);
-int cb_gelu_bwd(int32_t dtype, const void* dy, const void* pre, void* dx, int64_t n, void* stream);
-int cb_act_bwd(int32_t dtype, int32_t act, const void* dy, const void* y, void* dx, int64_t n, void* stream);
+/* dx = dy * act'(.) ; `ref` is the PRE-activation for CB_ACT_GELU and the OUTPUT for RELU / TANH. */
+int cb_act_bwd(int32_t dtype, int32_t act, const void* dy, const void* ref, void* dx, int64_t n, void* stream);
 
 /* Fused AdamW over a flat fp32 parameter range (src/optimization/adamw.py:40-103) with global-norm
  * clipping (run_video_retrieval.py:477-482): p, g, m, v are fp32 arrays of n elements; `w16`

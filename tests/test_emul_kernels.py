@@ -1,0 +1,196 @@
+"""Every non-GEMM kernel of libclipbert_hip executed on the host lane-level emulator against plain
+PyTorch fp32 references (and the oracle's AdamW restatement)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from clipbert_amd import ops
+from oracle import clipbert_oracle as O
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dt, f32=1e-5, bf=2e-2):
+    return dict(rtol=bf, atol=bf) if dt == torch.bfloat16 else dict(rtol=f32 * 10, atol=f32)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("D", [768, 64, 1280])
+def test_layernorm_fwd_bwd(emul, dt, D):
+    rows = 37
+    x = rnd(rows, D, seed=1).to(dt)
+    g, b = 1 + rnd(D, seed=2, scale=0.1), rnd(D, seed=3, scale=0.1)
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-12, save_stats=True)
+    xr = x.float().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (D,), gr, br, 1e-12)
+    torch.testing.assert_close(y.float(), ref, **tol(dt))
+    dy = rnd(rows, D, seed=4).to(dt)
+    ref.backward(dy.float())
+    dgam, dbet = torch.zeros(D), torch.zeros(D)
+    dx, _ = ops.layernorm_bwd(dy, x, g, mean, rstd, dgam, dbet)
+    torch.testing.assert_close(dx.float(), xr.grad, **tol(dt, 1e-4))
+    torch.testing.assert_close(dgam, gr.grad, **tol(dt, 1e-4, 5e-2))
+    torch.testing.assert_close(dbet, br.grad, **tol(dt, 1e-4, 5e-2))
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_embeddings_fwd_bwd(emul, dt):
+    B, Lt, Hg, Wg, T, D, V = 4, 6, 2, 3, 2, 128, 50
+    Lv = Hg * Wg
+    L = Lt + Lv
+    ids = torch.randint(0, V, (B, Lt), generator=torch.Generator().manual_seed(1))
+    ids[0, -1] = 0
+    tabs = {k: rnd(n, D, seed=i).to(dt) for i, (k, n) in enumerate(dict(word=V, pos=16, typ=2, row=5, col=5, vtyp=1).items())}
+    g1, b1, g2, b2 = 1 + rnd(D, seed=7, scale=0.1), rnd(D, seed=8, scale=0.1), 1 + rnd(D, seed=9, scale=0.1), rnd(D, seed=10, scale=0.1)
+    grid = rnd(2, T, Hg, Wg, D, seed=11).to(dt)
+    src_row = torch.tensor([0, 0, 1, 1], dtype=torch.int32)
+    out = torch.zeros(B * L, D, dtype=dt)
+    pre = torch.zeros(B * L, D, dtype=dt)
+    mean, rstd = torch.zeros(B * L), torch.zeros(B * L)
+    ops.text_embed_fwd(ids, tabs["word"], tabs["pos"], tabs["typ"], g1, b1, out, pre, mean, rstd, Lt, L, 1e-12)
+    ops.visual_embed_fwd(grid, src_row, None, tabs["row"], tabs["col"], tabs["vtyp"], g2, b2, out, pre, mean, rstd, B, Lv, Lt, L, 1e-12)
+    # reference with autograd
+    f = {k: v.float().requires_grad_(True) for k, v in tabs.items()}
+    gridr = grid.float().requires_grad_(True)
+    te = f["word"][ids] + f["pos"][:Lt].unsqueeze(0) + f["typ"][0]
+    gv = gridr[src_row.long()].mean(1) + f["row"][:Hg].view(1, Hg, 1, D) + f["col"][:Wg].view(1, 1, Wg, D)
+    ve = gv.reshape(B, Lv, D) + f["vtyp"][0]
+    pre_ref = torch.cat([te, ve], 1)
+    ref = torch.cat([F.layer_norm(te, (D,), g1, b1, 1e-12), F.layer_norm(ve, (D,), g2, b2, 1e-12)], 1)
+    torch.testing.assert_close(pre.float().view(B, L, D), pre_ref, **tol(dt))
+    torch.testing.assert_close(out.float().view(B, L, D), ref, **tol(dt))
+    # backward from d(pre)
+    dpre = rnd(B * L, D, seed=12).to(dt)
+    pre_ref.backward(dpre.float().view(B, L, D))
+    dword, dpos, dtyp = torch.zeros(V, D), torch.zeros(16, D), torch.zeros(2, D)
+    ops.text_embed_bwd(dpre, ids, dword, dpos, dtyp[0], Lt, L, pad_id=0)
+    ref_dword = f["word"].grad.clone()
+    ref_dword[0] = 0          # padding_idx rows receive no gradient
+    torch.testing.assert_close(dword, ref_dword, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dpos, f["pos"].grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dtyp, f["typ"].grad, rtol=1e-4, atol=1e-4)
+    dgrid, drow, dcol, dvt = torch.zeros(2, T, Hg, Wg, D), torch.zeros(5, D), torch.zeros(5, D), torch.zeros(1, D)
+    ops.visual_embed_bwd(dpre, src_row, None, dgrid, drow, dcol, dvt, B, Lv, Lt, L)
+    torch.testing.assert_close(dgrid, gridr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(drow, f["row"].grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dcol, f["col"].grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dvt, f["vtyp"].grad, rtol=1e-4, atol=1e-4)
+
+
+def test_visual_embed_pixel_subsample(emul):
+    B, Lt, Hg, Wg, T, D = 2, 3, 3, 3, 1, 64
+    sel = torch.tensor([1, 4, 5, 8], dtype=torch.int32)
+    Lv, L = 4, 7
+    grid = rnd(B, T, Hg, Wg, D, seed=1)
+    row, col, typ = rnd(4, D, seed=2), rnd(4, D, seed=3), rnd(1, D, seed=4)
+    g, b = torch.ones(D), torch.zeros(D)
+    out = torch.zeros(B * L, D)
+    ops.visual_embed_fwd(grid, None, sel, row, col, typ, g, b, out, None, None, None, B, Lv, Lt, L, 1e-12)
+    sd = {"p.row_position_embeddings.weight": row, "p.col_position_embeddings.weight": col,
+          "p.token_type_embeddings.weight": typ, "p.LayerNorm.weight": g, "p.LayerNorm.bias": b}
+    ref = O.visual_embeddings(sd, "p", grid, 1e-12, sel.long())
+    torch.testing.assert_close(out.view(B, L, D)[:, Lt:], ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("L", [9, 41, 70])
+def test_attention_fwd_bwd(emul, dt, L):
+    B, H = 2, 2
+    qkv = rnd(B * L, 3 * H * 64, seed=1).to(dt)
+    mask = torch.ones(B, L)
+    mask[0, L - 3:] = 0
+    mask[1, 2] = 0
+    ctx, lse = ops.attention_fwd(qkv, mask, B, L, H, save_lse=True)
+    x = qkv.float().requires_grad_(True)
+    q, k, v = [t.view(B, L, H, 64).permute(0, 2, 1, 3) for t in x.view(B, L, 3, H * 64).unbind(2)]
+    s = q @ k.transpose(-1, -2) / 8.0 + ((1 - mask) * -10000.0)[:, None, None, :]
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * L, H * 64)
+    torch.testing.assert_close(ctx.float(), ref, **tol(dt, 1e-5))
+    dctx = rnd(B * L, H * 64, seed=2).to(dt)
+    ref.backward(dctx.float())
+    dqkv = ops.attention_bwd(qkv, mask, ctx, dctx, lse, B, L, H)
+    torch.testing.assert_close(dqkv.float(), x.grad, **tol(dt, 1e-4, 3e-2))
+
+
+def test_cross_entropy_and_colsum_and_cast_and_act(emul):
+    logits = rnd(9, 37, seed=1)
+    labels = torch.randint(0, 37, (9,), generator=torch.Generator().manual_seed(2))
+    labels[3] = -100
+    dloss = rnd(9, seed=3)
+    loss, dl = ops.cross_entropy(logits, labels, dloss=dloss, want_grad=True)
+    lr = logits.clone().requires_grad_(True)
+    ref = F.cross_entropy(lr, labels, reduction="none", ignore_index=-100)
+    torch.testing.assert_close(loss, ref, rtol=1e-5, atol=1e-5)
+    ref.backward(dloss)
+    torch.testing.assert_close(dl, lr.grad, rtol=1e-5, atol=1e-6)
+    for dt in DT:
+        g = rnd(300, 70, seed=4).to(dt)
+        out = torch.ones(70)
+        ops.colsum(g, out)
+        torch.testing.assert_close(out, 1 + g.float().sum(0), rtol=1e-4, atol=1e-3)
+        for act, fn in [(ops.ACT_GELU, F.gelu), (ops.ACT_TANH, torch.tanh), (ops.ACT_RELU, F.relu)]:
+            pre = rnd(1001, seed=5).requires_grad_(True)
+            y = fn(pre)
+            dy = rnd(1001, seed=6)
+            y.backward(dy)
+            ref_in = pre.detach() if act == ops.ACT_GELU else y.detach()
+            dx = ops.act_bwd(act, dy.to(dt), ref_in.to(dt))
+            torch.testing.assert_close(dx.float(), pre.grad, **tol(dt, 1e-5, 3e-2))
+    src = rnd(1003, seed=7)
+    torch.testing.assert_close(ops.cast(src, torch.empty(1003, dtype=torch.bfloat16)), src.bfloat16())
+
+
+def test_adamw_matches_reference_restatement_with_clipping(emul):
+    n = 1003
+    p, g, m, v = rnd(n, seed=1), rnd(n, seed=2, scale=3.0), rnd(n, seed=3, scale=0.1), rnd(n, seed=4).abs() * 0.01
+    sq = torch.zeros(1)
+    ops.sq_sum(g, sq)
+    torch.testing.assert_close(sq[0], (g * g).sum(), rtol=1e-5, atol=1e-3)
+    gc, total = O.clip_grad_norm([g], 5.0)
+    pr, mr, vr = O.adamw_step(p, gc[0], m, v, step=3, lr=5e-5, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=1e-3)
+    w16 = torch.empty(n, dtype=torch.bfloat16)
+    p2, m2, v2 = p.clone(), m.clone(), v.clone()
+    ops.adamw(p2, g, m2, v2, w16, 5e-5, 0.9, 0.98, 1e-6, 1e-3, 3, grad_sq_sum=sq, max_norm=5.0)
+    torch.testing.assert_close(p2, pr, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(m2, mr, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(v2, vr, rtol=1e-5, atol=1e-8)
+    torch.testing.assert_close(w16, pr.bfloat16())
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_pool_stem_and_relu_bwd(emul, dt):
+    x = rnd(2, 8, 9, 7, seed=1).to(dt)                  # NCHW reference
+    xh = x.permute(0, 2, 3, 1).contiguous()
+    y = ops.maxpool_fwd(xh, 3, 2, 1)
+    torch.testing.assert_close(y.float().permute(0, 3, 1, 2), F.max_pool2d(x.float(), 3, 2, 1))
+    y2 = ops.maxpool_fwd(xh, 2, 2, 0, relu=True)
+    xr = x.float().requires_grad_(True)
+    ref2 = F.relu(F.max_pool2d(xr, 2, 2))
+    torch.testing.assert_close(y2.float().permute(0, 3, 1, 2), ref2)
+    dy = rnd(*ref2.shape, seed=2).to(dt)
+    ref2.backward(dy.float())
+    dx = ops.maxpool2_bwd(xh, y2, dy.permute(0, 2, 3, 1).contiguous(), relu=True)
+    torch.testing.assert_close(dx.float().permute(0, 3, 1, 2), xr.grad)
+    # stem pack: fp32 normalised input and fused uint8 path
+    img = torch.randint(0, 256, (2, 3, 6, 5), generator=torch.Generator().manual_seed(3), dtype=torch.uint8)
+    mean, std = (123.675, 116.28, 103.53), (1.0, 2.0, 0.5)
+    norm = ops.image_norm(img, mean, std)
+    ref_norm = (img.float() - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    torch.testing.assert_close(norm, ref_norm, rtol=1e-6, atol=1e-5)
+    ref_pack = torch.zeros(2, 12, 11, 4)
+    ref_pack[:, 3:9, 3:8, :3] = ref_norm[:, [2, 1, 0]].permute(0, 2, 3, 1)
+    for packed in (ops.stem_pack(norm, dt, 3), ops.stem_pack(img, dt, 3, mean, std)):
+        torch.testing.assert_close(packed.float(), ref_pack.to(dt).float(), **tol(dt, 1e-5, 1.0))
+    # relu + frozen-BN backward
+    yy, dyy = rnd(10, 16, seed=4).to(dt), rnd(10, 16, seed=5).to(dt)
+    sc, sc2 = rnd(16, seed=6), rnd(16, seed=7)
+    g, dz, g2 = ops.relu_scale_bwd(dyy, yy, sc, True, sc2)
+    refdz = dyy.float() * (yy.float() > 0)
+    torch.testing.assert_close(dz.float(), refdz.to(dt).float())
+    torch.testing.assert_close(g.float(), (refdz * sc).to(dt).float(), **tol(dt))
+    torch.testing.assert_close(g2.float(), (refdz * sc2).to(dt).float(), **tol(dt))

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libclipbert_hip.so")
 CB_F32, CB_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 ROWK, ROWK_GATHER, KROW, KROW_TAPS, KROW_GATHER = 0, 1, 2, 3, 4
+(HP_LR, HP_BETA1, HP_BETA2, HP_EPS, HP_WD, HP_BC1, HP_BC2, HP_MAX_NORM, HP_GRAD_SCALE, HP_COUNT) = range(10)
 
 vp, i32, i64, f32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
 
@@ -25,7 +26,8 @@ class GemmDesc(C.Structure):
         ("C", vp), ("ldc", i64), ("c_rowmap", vp), ("c_f32", i32), ("accumulate", i32),
         ("split_k", i32), ("act", i32), ("scale", vp), ("shift", vp), ("residual", vp), ("ldr", i64),
         ("relu_after", i32), ("reserved1", i32), ("mask", vp), ("ldm", i64), ("C2", vp), ("ldc2", i64),
-        ("alpha", f32), ("dropout_p", f32), ("dropout_seed", u64), ("tile", i32), ("reserved2", i32),
+        ("alpha", f32), ("dropout_p", f32), ("dropout_seed", u64), ("dropout_seed_ptr", vp), ("tile", i32),
+        ("reserved2", i32),
     ]
 
 
@@ -37,20 +39,21 @@ _SIGNATURES = {
     "cb_maxpool_fwd": [i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "cb_maxpool2_bwd": [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "cb_relu_scale_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],
-    "cb_layernorm_fwd": [i32, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
-    "cb_layernorm_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, f32, u64, vp],
+    "cb_layernorm_fwd": [i32, vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, i32, i32, vp],
+    "cb_layernorm_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, f32, u64, vp, i32, i32, i32, vp],
     "cb_text_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "cb_visual_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
                             i32, i32, i32, f32, vp],
     "cb_text_embed_bwd": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, vp],
     "cb_visual_embed_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
-    "cb_attention_fwd": [i32, vp, vp, vp, vp, i32, i32, i32, f32, u64, vp],
-    "cb_attention_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, u64, vp],
-    "cb_cross_entropy": [vp, vp, vp, vp, vp, i64, i32, i64, vp],
+    "cb_attention_fwd": [i32, vp, vp, vp, vp, i32, i32, i32, f32, u64, vp, vp],
+    "cb_attention_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, u64, vp, vp],
+    "cb_cross_entropy": [vp, i64, vp, vp, vp, vp, i64, i32, i64, vp],
     "cb_colsum": [i32, vp, i64, vp, i64, i32, vp],
     "cb_cast": [i32, vp, i32, vp, i64, vp],
     "cb_act_bwd": [i32, i32, vp, vp, vp, i64, vp],
-    "cb_adamw": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, f32, f32, vp],
+    "cb_adamw": [vp, vp, vp, vp, vp, i64, vp, vp, vp],
+    "cb_dropout": [i32, vp, vp, i64, f32, u64, vp, vp],
     "cb_sq_sum": [vp, i64, vp, vp],
 }
 

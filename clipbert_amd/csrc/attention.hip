@@ -41,7 +41,8 @@ __device__ __forceinline__ void stage_rows(const T* base, int64_t stride, int ro
 
 template <typename T>
 __global__ void __launch_bounds__(64) attention_fwd_kernel(const T* qkv, const float* key_mask, T* ctx, float* lse, int B, int L,
-                                                           int H, float drop_p, uint64_t seed) {
+                                                           int H, float drop_p, uint64_t seed, const uint64_t* seed_ptr) {
+    if (drop_p > 0.f && seed_ptr) seed += *seed_ptr;
     __shared__ __attribute__((aligned(16))) float Ks[KB][DH];
     __shared__ __attribute__((aligned(16))) float Vs[KB][DH];
     __shared__ float Ms[KB];
@@ -108,7 +109,8 @@ __global__ void __launch_bounds__(64) attention_fwd_kernel(const T* qkv, const f
 template <typename T>
 __global__ void __launch_bounds__(64) attention_bwd_q_kernel(const T* qkv, const float* key_mask, const T* ctx, const T* dctx,
                                                              const float* lse, float* dsum, T* dqkv, int B, int L, int H,
-                                                             float drop_p, uint64_t seed) {
+                                                             float drop_p, uint64_t seed, const uint64_t* seed_ptr) {
+    if (drop_p > 0.f && seed_ptr) seed += *seed_ptr;
     __shared__ __attribute__((aligned(16))) float Ks[KB][DH];
     __shared__ __attribute__((aligned(16))) float Vs[KB][DH];
     __shared__ float Ms[KB];
@@ -170,7 +172,8 @@ __global__ void __launch_bounds__(64) attention_bwd_q_kernel(const T* qkv, const
 template <typename T>
 __global__ void __launch_bounds__(64) attention_bwd_kv_kernel(const T* qkv, const float* key_mask, const T* dctx, const float* lse,
                                                               const float* dsum, T* dqkv, int B, int L, int H, float drop_p,
-                                                              uint64_t seed) {
+                                                              uint64_t seed, const uint64_t* seed_ptr) {
+    if (drop_p > 0.f && seed_ptr) seed += *seed_ptr;
     __shared__ __attribute__((aligned(16))) float Qs[KB][DH];
     __shared__ __attribute__((aligned(16))) float Gs[KB][DH];
     __shared__ float Ls[KB], Ds[KB];
@@ -235,27 +238,27 @@ __global__ void __launch_bounds__(64) attention_bwd_kv_kernel(const T* qkv, cons
 }  // namespace
 
 extern "C" int cb_attention_fwd(int32_t dtype, const void* qkv, const float* key_mask, void* ctx, float* lse, int32_t B, int32_t L,
-                                int32_t H, float dropout_p, uint64_t dropout_seed, void* stream) {
+                                int32_t H, float dropout_p, uint64_t dropout_seed, const uint64_t* dropout_seed_ptr, void* stream) {
     CB_REQUIRE(qkv && key_mask && ctx && B > 0 && L > 0 && H > 0, "cb_attention_fwd: bad arguments");
     dim3 g(B * H, (L + 63) / 64), b(64);
-    if (dtype == CB_BF16) hipLaunchKernelGGL((attention_fwd_kernel<bf16>), g, b, 0, cb_stream(stream), (const bf16*)qkv, key_mask, (bf16*)ctx, lse, B, L, H, dropout_p, dropout_seed);
-    else if (dtype == CB_F32) hipLaunchKernelGGL((attention_fwd_kernel<float>), g, b, 0, cb_stream(stream), (const float*)qkv, key_mask, (float*)ctx, lse, B, L, H, dropout_p, dropout_seed);
+    if (dtype == CB_BF16) hipLaunchKernelGGL((attention_fwd_kernel<bf16>), g, b, 0, cb_stream(stream), (const bf16*)qkv, key_mask, (bf16*)ctx, lse, B, L, H, dropout_p, dropout_seed, dropout_seed_ptr);
+    else if (dtype == CB_F32) hipLaunchKernelGGL((attention_fwd_kernel<float>), g, b, 0, cb_stream(stream), (const float*)qkv, key_mask, (float*)ctx, lse, B, L, H, dropout_p, dropout_seed, dropout_seed_ptr);
     else return cb_fail("cb_attention_fwd: bad dtype");
     return cb_launch_status("cb_attention_fwd");
 }
 
 extern "C" int cb_attention_bwd(int32_t dtype, const void* qkv, const float* key_mask, const void* ctx, const void* dctx,
                                 const float* lse, float* dsum_ws, void* dqkv, int32_t B, int32_t L, int32_t H, float dropout_p,
-                                uint64_t dropout_seed, void* stream) {
+                                uint64_t dropout_seed, const uint64_t* dropout_seed_ptr, void* stream) {
     CB_REQUIRE(qkv && key_mask && ctx && dctx && lse && dsum_ws && dqkv && B > 0 && L > 0 && H > 0, "cb_attention_bwd: bad arguments");
     dim3 g(B * H, (L + 63) / 64), b(64);
     hipStream_t st = cb_stream(stream);
     if (dtype == CB_BF16) {
-        hipLaunchKernelGGL((attention_bwd_q_kernel<bf16>), g, b, 0, st, (const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, dsum_ws, (bf16*)dqkv, B, L, H, dropout_p, dropout_seed);
-        hipLaunchKernelGGL((attention_bwd_kv_kernel<bf16>), g, b, 0, st, (const bf16*)qkv, key_mask, (const bf16*)dctx, lse, dsum_ws, (bf16*)dqkv, B, L, H, dropout_p, dropout_seed);
+        hipLaunchKernelGGL((attention_bwd_q_kernel<bf16>), g, b, 0, st, (const bf16*)qkv, key_mask, (const bf16*)ctx, (const bf16*)dctx, lse, dsum_ws, (bf16*)dqkv, B, L, H, dropout_p, dropout_seed, dropout_seed_ptr);
+        hipLaunchKernelGGL((attention_bwd_kv_kernel<bf16>), g, b, 0, st, (const bf16*)qkv, key_mask, (const bf16*)dctx, lse, dsum_ws, (bf16*)dqkv, B, L, H, dropout_p, dropout_seed, dropout_seed_ptr);
     } else if (dtype == CB_F32) {
-        hipLaunchKernelGGL((attention_bwd_q_kernel<float>), g, b, 0, st, (const float*)qkv, key_mask, (const float*)ctx, (const float*)dctx, lse, dsum_ws, (float*)dqkv, B, L, H, dropout_p, dropout_seed);
-        hipLaunchKernelGGL((attention_bwd_kv_kernel<float>), g, b, 0, st, (const float*)qkv, key_mask, (const float*)dctx, lse, dsum_ws, (float*)dqkv, B, L, H, dropout_p, dropout_seed);
+        hipLaunchKernelGGL((attention_bwd_q_kernel<float>), g, b, 0, st, (const float*)qkv, key_mask, (const float*)ctx, (const float*)dctx, lse, dsum_ws, (float*)dqkv, B, L, H, dropout_p, dropout_seed, dropout_seed_ptr);
+        hipLaunchKernelGGL((attention_bwd_kv_kernel<float>), g, b, 0, st, (const float*)qkv, key_mask, (const float*)dctx, lse, dsum_ws, (float*)dqkv, B, L, H, dropout_p, dropout_seed, dropout_seed_ptr);
     } else return cb_fail("cb_attention_bwd: bad dtype");
     return cb_launch_status("cb_attention_bwd");
 }

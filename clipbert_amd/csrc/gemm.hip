@@ -43,6 +43,7 @@ struct GP {
     int c_f32, accumulate, split_k, act, relu_after;
     float alpha, dropout_p;
     uint64_t seed;
+    const uint64_t* seed_ptr;
     int a_vec, b_vec, c_vec;
     int ktiles;
 };
@@ -354,6 +355,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
     }
 
     // ---- epilogue: lane owns n = nb..nb+3 of row m ------------------------------------------------
+    if (p.dropout_p > 0.f && p.seed_ptr) p.seed += *p.seed_ptr;
     const bool fast = p.c_vec && (n0 + BN <= p.N);      // block-uniform
     if (fast) {
 #pragma unroll
@@ -443,7 +445,7 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     p.c_f32 = d->c_f32; p.accumulate = d->accumulate; p.split_k = d->split_k > 0 ? d->split_k : 1;
     p.act = d->act; p.relu_after = d->relu_after;
     p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
-    p.dropout_p = d->dropout_p; p.seed = d->dropout_seed;
+    p.dropout_p = d->dropout_p; p.seed = d->dropout_seed; p.seed_ptr = d->dropout_seed_ptr;
     p.ktiles = (d->K + BK - 1) / BK;
 
     const bool a_krow = d->a_mode == CB_KROW;

@@ -5,12 +5,13 @@
 namespace {
 
 // one wave per row; logits fp32 (rows, C)
-__global__ void __launch_bounds__(256) cross_entropy_kernel(const float* logits, const int64_t* labels, float* loss, float* dlogits,
-                                                            const float* dloss, int64_t rows, int C, int64_t ignore_index) {
+__global__ void __launch_bounds__(256) cross_entropy_kernel(const float* logits, int64_t ld, const int64_t* labels, float* loss,
+                                                            float* dlogits, const float* dloss, int64_t rows, int C,
+                                                            int64_t ignore_index) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* x = logits + row * C;
+    const float* x = logits + row * ld;
     const int64_t y = labels[row];
     const bool ignored = (y == ignore_index);
     float m = -3.0e38f;
@@ -23,7 +24,7 @@ __global__ void __launch_bounds__(256) cross_entropy_kernel(const float* logits,
     if (lane == 0 && loss) loss[row] = ignored ? 0.f : (lse - x[y]);
     if (dlogits) {
         const float g = ignored ? 0.f : (dloss ? dloss[row] : 1.0f);
-        float* d = dlogits + row * C;
+        float* d = dlogits + row * ld;
         for (int c = lane; c < C; c += 64) {
             float p = __expf(x[c] - lse);
             d[c] = g * (p - ((int64_t)c == y ? 1.0f : 0.0f));
@@ -81,16 +82,42 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(int act, const T* dy, cons
     }
 }
 
+template <typename T>
+__global__ void __launch_bounds__(256) dropout_kernel(const T* x, T* y, int64_t n, float p, uint64_t seed, const uint64_t* seed_ptr) {
+    if (seed_ptr) seed += *seed_ptr;
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 3 < n) {
+        f32x4 v = load4(x + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= dropout_mult(seed, (uint64_t)(i + e), p);
+        store4(y + i, v);
+    } else {
+        for (; i < n; ++i) y[i] = from_f32<T>(to_f32(x[i]) * dropout_mult(seed, (uint64_t)i, p));
+    }
+}
+
 inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace
 
-extern "C" int cb_cross_entropy(const float* logits, const int64_t* labels, float* loss, float* dlogits, const float* dloss,
-                                int64_t rows, int32_t C, int64_t ignore_index, void* stream) {
-    CB_REQUIRE(logits && labels && C > 0, "cb_cross_entropy: bad arguments");
+extern "C" int cb_dropout(int32_t dtype, const void* x, void* y, int64_t n, float p, uint64_t seed, const uint64_t* seed_ptr,
+                          void* stream) {
+    CB_REQUIRE(x && y && p >= 0.f && p < 1.f, "cb_dropout: bad arguments");
+    if (n == 0) return 0;
+    dim3 g(nblk(n, 1024)), b(256);
+    if (dtype == CB_BF16) hipLaunchKernelGGL((dropout_kernel<bf16>), g, b, 0, cb_stream(stream), (const bf16*)x, (bf16*)y, n, p, seed, seed_ptr);
+    else if (dtype == CB_F32) hipLaunchKernelGGL((dropout_kernel<float>), g, b, 0, cb_stream(stream), (const float*)x, (float*)y, n, p, seed, seed_ptr);
+    else return cb_fail("cb_dropout: bad dtype");
+    return cb_launch_status("cb_dropout");
+}
+
+extern "C" int cb_cross_entropy(const float* logits, int64_t ld, const int64_t* labels, float* loss, float* dlogits,
+                                const float* dloss, int64_t rows, int32_t C, int64_t ignore_index, void* stream) {
+    CB_REQUIRE(logits && labels && C > 0 && ld >= C, "cb_cross_entropy: bad arguments");
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(cross_entropy_kernel, dim3(nblk(rows, 4)), dim3(256), 0, cb_stream(stream), logits, labels, loss, dlogits,
-                       dloss, rows, C, ignore_index);
+    hipLaunchKernelGGL(cross_entropy_kernel, dim3(nblk(rows, 4)), dim3(256), 0, cb_stream(stream), logits, ld, labels, loss,
+                       dlogits, dloss, rows, C, ignore_index);
     return cb_launch_status("cb_cross_entropy");
 }
 

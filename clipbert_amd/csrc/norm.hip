@@ -54,10 +54,12 @@ __device__ __forceinline__ void norm_store(const f32x4 (&v)[MAXCH], const float*
 
 template <typename T, int MAXCH>
 __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const T* x, const float* gamma, const float* beta, T* y,
-                                                            float* mean_out, float* rstd_out, int64_t rows, int D, float eps) {
+                                                            float* mean_out, float* rstd_out, int64_t rows, int D, float eps,
+                                                            int seg_len, int seg_stride, int seg_off) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    if (seg_len > 0) row = (row / seg_len) * seg_stride + seg_off + row % seg_len;
     f32x4 v[MAXCH];
     load_row(x + row * D, D, lane, v);
     float mean, rstd;
@@ -74,13 +76,16 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const T* x, const fl
 template <typename T, int MAXCH>
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
                                                             const float* rstd, T* dx, float* dgamma, float* dbeta,
-                                                            int64_t rows, int D, T* dx2, float drop_p, uint64_t seed) {
-    __shared__ float red[2][4][256];   // [gamma|beta][wave][one 256-element chunk]
+                                                            int64_t rows, int D, T* dx2, float drop_p, uint64_t seed,
+                                                            const uint64_t* seed_ptr, int seg_len, int seg_stride, int seg_off) {
+    __shared__ float red[2][4][256];
+    if (dx2 && seed_ptr) seed += *seed_ptr;   // [gamma|beta][wave][one 256-element chunk]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 ag[MAXCH], ab[MAXCH];
 #pragma unroll
     for (int c = 0; c < MAXCH; ++c) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; ag[c] = z; ab[c] = z; }
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    for (int64_t lrow = (int64_t)blockIdx.x * 4 + wave; lrow < rows; lrow += (int64_t)gridDim.x * 4) {
+        const int64_t row = seg_len > 0 ? (lrow / seg_len) * seg_stride + seg_off + lrow % seg_len : lrow;
         f32x4 g[MAXCH], xv[MAXCH];
         load_row(dy + row * D, D, lane, g);
         load_row(x + row * D, D, lane, xv);
@@ -283,17 +288,18 @@ inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per
 
 template <typename T, int NCH>
 void run_ln_fwd(hipStream_t st, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                int64_t rows, int D, float eps) {
+                int64_t rows, int D, float eps, int seg_len, int seg_stride, int seg_off) {
     hipLaunchKernelGGL((layernorm_fwd_kernel<T, NCH>), dim3(nblk(rows, 4)), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y,
-                       mean, rstd, rows, D, eps);
+                       mean, rstd, rows, D, eps, seg_len, seg_stride, seg_off);
 }
 template <typename T, int NCH>
 void run_ln_bwd(hipStream_t st, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
-                float* dgamma, float* dbeta, int64_t rows, int D, void* dx2, float p, uint64_t seed) {
+                float* dgamma, float* dbeta, int64_t rows, int D, void* dx2, float p, uint64_t seed, const uint64_t* seed_ptr,
+                int seg_len, int seg_stride, int seg_off) {
     unsigned blocks = nblk(rows, 4);
     if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd,
-                       (T*)dx, dgamma, dbeta, rows, D, (T*)dx2, p, seed);
+                       (T*)dx, dgamma, dbeta, rows, D, (T*)dx2, p, seed, seed_ptr, seg_len, seg_stride, seg_off);
 }
 template <typename T, int NCH>
 void run_text_fwd(hipStream_t st, const int64_t* ids, const void* word, const void* pos, const void* type0, const float* gamma,
@@ -313,19 +319,22 @@ void run_vis_fwd(hipStream_t st, const void* grid, const int32_t* src_row, const
 }  // namespace
 
 extern "C" int cb_layernorm_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean,
-                                float* rstd, int64_t rows, int32_t D, float eps, void* stream) {
+                                float* rstd, int64_t rows, int32_t D, float eps, int32_t seg_len, int32_t seg_stride,
+                                int32_t seg_off, void* stream) {
     CB_REQUIRE(x && y && gamma && beta && CB_D_OK(D), "cb_layernorm_fwd: bad arguments (D %% 4 == 0, D <= 2048)");
     if (rows == 0) return 0;
-    CB_DISPATCH(run_ln_fwd, cb_stream(stream), x, gamma, beta, y, mean, rstd, rows, D, eps);
+    CB_DISPATCH(run_ln_fwd, cb_stream(stream), x, gamma, beta, y, mean, rstd, rows, D, eps, seg_len, seg_stride, seg_off);
     return cb_launch_status("cb_layernorm_fwd");
 }
 
 extern "C" int cb_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* gamma, const float* mean,
                                 const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int32_t D, void* dx2,
-                                float dropout_p, uint64_t dropout_seed, void* stream) {
+                                float dropout_p, uint64_t dropout_seed, const uint64_t* dropout_seed_ptr, int32_t seg_len,
+                                int32_t seg_stride, int32_t seg_off, void* stream) {
     CB_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && CB_D_OK(D), "cb_layernorm_bwd: bad arguments");
     if (rows == 0) return 0;
-    CB_DISPATCH(run_ln_bwd, cb_stream(stream), dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, dx2, dropout_p, dropout_seed);
+    CB_DISPATCH(run_ln_bwd, cb_stream(stream), dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, dx2, dropout_p, dropout_seed,
+                dropout_seed_ptr, seg_len, seg_stride, seg_off);
     return cb_launch_status("cb_layernorm_bwd");
 }
 

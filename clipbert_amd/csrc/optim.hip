@@ -38,12 +38,15 @@ __device__ __forceinline__ PMV adamw_one(float p, float g, float m, float v, flo
     return r;
 }
 
-__global__ void __launch_bounds__(256) adamw_kernel(float* p, const float* g, float* m, float* v, bf16* w16, int64_t n, float b1,
-                                                    float b2, float eps, float step_size, float decay, const float* sq_sum,
-                                                    float max_norm, float grad_scale) {
-    float gs = grad_scale;
+__global__ void __launch_bounds__(256) adamw_kernel(float* p, const float* g, float* m, float* v, bf16* w16, int64_t n,
+                                                    const float* hp, const float* sq_sum) {
+    const float lr = hp[CB_HP_LR], b1 = hp[CB_HP_BETA1], b2 = hp[CB_HP_BETA2], eps = hp[CB_HP_EPS];
+    const float wd = hp[CB_HP_WD], max_norm = hp[CB_HP_MAX_NORM];
+    const float step_size = lr * sqrtf(hp[CB_HP_BC2]) / hp[CB_HP_BC1];
+    const float decay = wd > 0.f ? lr * wd : 0.f;
+    float gs = hp[CB_HP_GRAD_SCALE];
     if (sq_sum && max_norm > 0.f) {
-        float total = sqrtf(*sq_sum) * grad_scale;
+        float total = sqrtf(*sq_sum) * gs;
         float coef = max_norm / (total + 1e-6f);
         gs *= coef < 1.0f ? coef : 1.0f;
     }
@@ -78,16 +81,11 @@ extern "C" int cb_sq_sum(const float* g, int64_t n, float* out_accum, void* stre
     return cb_launch_status("cb_sq_sum");
 }
 
-extern "C" int cb_adamw(float* p, const float* g, float* m, float* v, void* w16, int64_t n, float lr, float beta1, float beta2,
-                        float eps, float weight_decay, int32_t step, const float* grad_sq_sum, float max_norm, float grad_scale,
-                        void* stream) {
-    CB_REQUIRE(p && g && m && v && step >= 1, "cb_adamw: bad arguments");
+extern "C" int cb_adamw(float* p, const float* g, float* m, float* v, void* w16, int64_t n, const float* hyper,
+                        const float* grad_sq_sum, void* stream) {
+    CB_REQUIRE(p && g && m && v && hyper, "cb_adamw: bad arguments");
     if (n == 0) return 0;
-    double bc1 = 1.0 - pow((double)beta1, (double)step);
-    double bc2 = 1.0 - pow((double)beta2, (double)step);
-    float step_size = (float)((double)lr * sqrt(bc2) / bc1);
-    float decay = weight_decay > 0.f ? lr * weight_decay : 0.f;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, cb_stream(stream), p, g, m, v, (bf16*)w16, n,
-                       beta1, beta2, eps, step_size, decay, grad_sq_sum, max_norm, grad_scale == 0.f ? 1.0f : grad_scale);
+                       hyper, grad_sq_sum);
     return cb_launch_status("cb_adamw");
 }

@@ -46,7 +46,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch
          b_mode=ROWK, lda=None, ldb=None, ldc=None, a_tab=None, b_tab=None, R=1, S=1, Cin=0, H=0, W=0,
          sH=0, sW=0, flip_taps=False, c_rowmap=None, accumulate=False, split_k=1, act=ACT_NONE,
          scale=None, shift=None, residual=None, ldr=None, relu_after=False, mask=None, ldm=None,
-         out2=None, ldc2=None, alpha=1.0, dropout_p=0.0, dropout_seed=0, tile=0):
+         out2=None, ldc2=None, alpha=1.0, dropout_p=0.0, dropout_seed=0, seed_ptr=None, tile=0):
     """C[M,N] (op)= epilogue(sum_k A(m,k) B(n,k)); see include/clipbert_hip.h cb_gemm_desc."""
     d = GemmDesc()
     d.dtype = dtype_code(a.dtype)
@@ -77,6 +77,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch
     d.alpha = alpha
     d.dropout_p = dropout_p
     d.dropout_seed = dropout_seed
+    d.dropout_seed_ptr = _ptr(seed_ptr)
     d.tile = tile
     _chk(_lib.get().cb_gemm(C.byref(d), _stream(a)), "cb_gemm")
     return out
@@ -159,19 +160,22 @@ def layernorm_fwd(x, gamma, beta, eps, save_stats=False, out=None):
     mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
     _chk(_lib.get().cb_layernorm_fwd(dtype_code(x.dtype), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean),
-                                     _ptr(rstd), rows, d, eps, _stream(x)), "cb_layernorm_fwd")
+                                     _ptr(rstd), rows, d, eps, 0, 0, 0, _stream(x)), "cb_layernorm_fwd")
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dropout_p=0.0, dropout_seed=0):
-    """returns (dx, dx_dropped|None); dgamma/dbeta (fp32) are accumulated in place."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dropout_p=0.0, dropout_seed=0, seed_ptr=None,
+                  dx=None, rows=None, seg=(0, 0, 0)):
+    """returns (dx, dx_dropped|None); dgamma/dbeta (fp32) are accumulated in place.
+    seg = (seg_len, seg_stride, seg_off) addresses a strided subset of rows (see the header)."""
     d = x.shape[-1]
-    rows = x.numel() // d
-    dx = torch.empty_like(x)
+    rows = x.numel() // d if rows is None else rows
+    dx = torch.empty_like(x) if dx is None else dx
     dx2 = torch.empty_like(x) if dropout_p > 0 else None
     _chk(_lib.get().cb_layernorm_bwd(dtype_code(x.dtype), _ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd),
                                      _ptr(dx), _ptr(dgamma), _ptr(dbeta), rows, d, _ptr(dx2), dropout_p,
-                                     dropout_seed, _stream(x)), "cb_layernorm_bwd")
+                                     dropout_seed, _ptr(seed_ptr), seg[0], seg[1], seg[2], _stream(x)),
+         "cb_layernorm_bwd")
     return dx, dx2
 
 
@@ -206,29 +210,34 @@ def visual_embed_bwd(dpre, src_row, sel, dgrid, drow, dcol, dtype0, b, lv, lt, l
                                         _stream(dpre)), "cb_visual_embed_bwd")
 
 
-def attention_fwd(qkv, key_mask, b, l, h, save_lse=False, dropout_p=0.0, dropout_seed=0):
+def attention_fwd(qkv, key_mask, b, l, h, save_lse=False, dropout_p=0.0, dropout_seed=0, seed_ptr=None):
     ctx = torch.empty(b * l, h * 64, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(b * h * l, dtype=torch.float32, device=qkv.device) if save_lse else None
     _chk(_lib.get().cb_attention_fwd(dtype_code(qkv.dtype), _ptr(qkv), _ptr(key_mask), _ptr(ctx), _ptr(lse), b, l, h,
-                                     dropout_p, dropout_seed, _stream(qkv)), "cb_attention_fwd")
+                                     dropout_p, dropout_seed, _ptr(seed_ptr), _stream(qkv)), "cb_attention_fwd")
     return ctx, lse
 
 
-def attention_bwd(qkv, key_mask, ctx, dctx, lse, b, l, h, dropout_p=0.0, dropout_seed=0):
+def attention_bwd(qkv, key_mask, ctx, dctx, lse, b, l, h, dropout_p=0.0, dropout_seed=0, seed_ptr=None):
     dqkv = torch.empty_like(qkv)
     ws = torch.empty(b * h * l, dtype=torch.float32, device=qkv.device)
     _chk(_lib.get().cb_attention_bwd(dtype_code(qkv.dtype), _ptr(qkv), _ptr(key_mask), _ptr(ctx), _ptr(dctx),
-                                     _ptr(lse), _ptr(ws), _ptr(dqkv), b, l, h, dropout_p, dropout_seed, _stream(qkv)),
+                                     _ptr(lse), _ptr(ws), _ptr(dqkv), b, l, h, dropout_p, dropout_seed, _ptr(seed_ptr),
+                                     _stream(qkv)),
          "cb_attention_bwd")
     return dqkv
 
 
 def cross_entropy(logits, labels, want_loss=True, dloss=None, want_grad=False, ignore_index=-100):
+    """logits fp32 (rows, C), row stride may exceed C (padded vocab logits)."""
     rows, c = logits.shape
-    assert logits.dtype == torch.float32 and logits.is_contiguous()
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    ld = logits.stride(0)
     loss = torch.empty(rows, dtype=torch.float32, device=logits.device) if want_loss else None
-    dlogits = torch.empty_like(logits) if want_grad else None
-    _chk(_lib.get().cb_cross_entropy(_ptr(logits), _ptr(labels), _ptr(loss), _ptr(dlogits), _ptr(dloss), rows, c,
+    dlogits = None
+    if want_grad:
+        dlogits = torch.empty_strided(logits.shape, logits.stride(), dtype=torch.float32, device=logits.device)
+    _chk(_lib.get().cb_cross_entropy(_ptr(logits), ld, _ptr(labels), _ptr(loss), _ptr(dlogits), _ptr(dloss), rows, c,
                                      ignore_index, _stream(logits)), "cb_cross_entropy")
     return loss, dlogits
 
@@ -259,7 +268,19 @@ def sq_sum(g, out):
     _chk(_lib.get().cb_sq_sum(_ptr(g), g.numel(), _ptr(out), _stream(g)), "cb_sq_sum")
 
 
-def adamw(p, g, m, v, w16, lr, beta1, beta2, eps, weight_decay, step, grad_sq_sum=None, max_norm=-1.0,
-          grad_scale=1.0):
-    _chk(_lib.get().cb_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(w16), p.numel(), lr, beta1, beta2, eps,
-                             weight_decay, step, _ptr(grad_sq_sum), max_norm, grad_scale, _stream(p)), "cb_adamw")
+def adamw_hyper(lr, beta1, beta2, eps, weight_decay, step, max_norm=-1.0, grad_scale=1.0):
+    """Host-side packing of the CB_HP_* array (see include/clipbert_hip.h)."""
+    return [lr, beta1, beta2, eps, weight_decay, 1.0 - beta1 ** step, 1.0 - beta2 ** step, max_norm, grad_scale, 0.0]
+
+
+def adamw(p, g, m, v, w16, hyper_dev, grad_sq_sum=None):
+    """hyper_dev: DEVICE fp32 tensor of >= HP_COUNT entries (adamw_hyper)."""
+    _chk(_lib.get().cb_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(w16), p.numel(), _ptr(hyper_dev),
+                             _ptr(grad_sq_sum), _stream(p)), "cb_adamw")
+
+
+def dropout(x, p, seed=0, seed_ptr=None, out=None):
+    y = torch.empty_like(x) if out is None else out
+    _chk(_lib.get().cb_dropout(dtype_code(x.dtype), _ptr(x), _ptr(y), x.numel(), p, seed, _ptr(seed_ptr), _stream(x)),
+         "cb_dropout")
+    return y

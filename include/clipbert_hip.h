@@ -76,7 +76,8 @@ typedef struct {
     void* C2; int64_t ldc2;   /* optional second output: value BEFORE act (GELU backward needs it)   */
     float alpha;              /* multiplies the accumulator first (1.0 if 0)                         */
     float dropout_p;          /* > 0: inverted dropout on the value before the residual add          */
-    uint64_t dropout_seed;
+    uint64_t dropout_seed;    /* mask = f(dropout_seed + *dropout_seed_ptr, m*N + n)                  */
+    const uint64_t* dropout_seed_ptr;  /* optional DEVICE word added to the seed (varies per hipGraph replay) */
     int32_t tile;             /* 0 auto, 1 = 128x128, 2 = 64x64                                      */
     int32_t reserved2;
 } cb_gemm_desc;
@@ -124,13 +125,17 @@ int cb_relu_scale_bwd(int32_t dtype, const void* dy, const void* y, const float*
 
 /* LayerNorm over the last dim (apex FusedLayerNorm, src/modeling/transformers.py:32,148).
  * y = (x - mean) * rstd * gamma + beta, fp32 statistics; mean/rstd (rows) are saved when non-null. */
+/* Row segments: logical row r lives at physical row (r / seg_len) * seg_stride + seg_off + r % seg_len
+ * (seg_len <= 0: rows are contiguous).  Lets one call address e.g. only the text rows of (B, L, D). */
 int cb_layernorm_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, void* y,
-                     float* mean, float* rstd, int64_t rows, int32_t D, float eps, void* stream);
+                     float* mean, float* rstd, int64_t rows, int32_t D, float eps, int32_t seg_len,
+                     int32_t seg_stride, int32_t seg_off, void* stream);
 /* dx = LN backward; dgamma/dbeta (fp32, D) are ACCUMULATED with atomics.  dx2 (optional) receives
  * dx with inverted-dropout mask (seed, p) applied -- the gradient of the dropped GEMM output. */
 int cb_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* gamma, const float* mean,
                      const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int32_t D,
-                     void* dx2, float dropout_p, uint64_t dropout_seed, void* stream);
+                     void* dx2, float dropout_p, uint64_t dropout_seed, const uint64_t* dropout_seed_ptr,
+                     int32_t seg_len, int32_t seg_stride, int32_t seg_off, void* stream);
 
 /* Text embedding (BertEmbeddings.forward, src/modeling/transformers.py:172-199): out row
  * (b*L_total + t) = LN(word[ids[b,t]] + pos[t] + type[0]); pre-LN sum saved in `pre` when non-null. */
@@ -160,16 +165,17 @@ int cb_visual_embed_bwd(int32_t dtype, const void* dpre, const int32_t* src_row,
  * QKV buffer (B*L, 3*H*64): scores = QK^T / 8 + (1 - mask) * -10000, fp32 softmax, ctx = P V, heads
  * merged into ctx (B*L, H*64).  lse (B,H,L) fp32 is saved for the backward when non-null. */
 int cb_attention_fwd(int32_t dtype, const void* qkv, const float* key_mask, void* ctx, float* lse,
-                     int32_t B, int32_t L, int32_t H, float dropout_p, uint64_t dropout_seed, void* stream);
+                     int32_t B, int32_t L, int32_t H, float dropout_p, uint64_t dropout_seed,
+                     const uint64_t* dropout_seed_ptr, void* stream);
 /* dsum_ws: fp32 workspace of B*H*L elements (rowsum(dctx*ctx), produced and consumed inside). */
 int cb_attention_bwd(int32_t dtype, const void* qkv, const float* key_mask, const void* ctx, const void* dctx,
                      const float* lse, float* dsum_ws, void* dqkv, int32_t B, int32_t L, int32_t H,
-                     float dropout_p, uint64_t dropout_seed, void* stream);
+                     float dropout_p, uint64_t dropout_seed, const uint64_t* dropout_seed_ptr, void* stream);
 
 /* Row-wise softmax cross-entropy with ignore_index (CrossEntropyLoss(reduction="none"),
  * src/modeling/modeling.py:287-298,562-566): loss[r] and (optional) dlogits = (softmax - onehot) *
  * dloss[r].  logits fp32 (rows, C). */
-int cb_cross_entropy(const float* logits, const int64_t* labels, float* loss, float* dlogits,
+int cb_cross_entropy(const float* logits, int64_t ld, const int64_t* labels, float* loss, float* dlogits,
                      const float* dloss, int64_t rows, int32_t C, int64_t ignore_index, void* stream);
 
 /* Column sums: out[n] (+)= sum_m g[m,n]  (bias gradients).  fp32 atomics into out. */
@@ -183,11 +189,18 @@ int cb_act_bwd(int32_t dtype, int32_t act, const void* dy, const void* ref, void
 /* Fused AdamW over a flat fp32 parameter range (src/optimization/adamw.py:40-103) with global-norm
  * clipping (run_video_retrieval.py:477-482): p, g, m, v are fp32 arrays of n elements; `w16`
  * (optional) receives the bf16 compute copy.  grad_sq_sum: device scalar holding sum(g^2) over ALL
- * parameters (cb_sq_sum); clip coefficient = min(1, max_norm / (sqrt(sum) + 1e-6)); max_norm <= 0
- * disables clipping.  grad_scale multiplies g first (1/world_size when gradients were summed). */
-int cb_adamw(float* p, const float* g, float* m, float* v, void* w16, int64_t n, float lr, float beta1,
-             float beta2, float eps, float weight_decay, int32_t step, const float* grad_sq_sum,
-             float max_norm, float grad_scale, void* stream);
+ * parameters (cb_sq_sum); clip coefficient = min(1, max_norm / (grad_scale*sqrt(sum) + 1e-6));
+ * max_norm <= 0 disables clipping.  grad_scale multiplies g first (1/world_size when gradients were
+ * summed across ranks). */
+int cb_adamw(float* p, const float* g, float* m, float* v, void* w16, int64_t n, const float* hyper,
+             const float* grad_sq_sum, void* stream);
+/* hyper: DEVICE array of CB_HP_COUNT floats (so a captured hipGraph sees new values each replay):
+ * [lr, beta1, beta2, eps, weight_decay, 1-beta1^t, 1-beta2^t, max_norm, grad_scale] */
+enum { CB_HP_LR = 0, CB_HP_BETA1, CB_HP_BETA2, CB_HP_EPS, CB_HP_WD, CB_HP_BC1, CB_HP_BC2, CB_HP_MAX_NORM,
+       CB_HP_GRAD_SCALE, CB_HP_COUNT };
+/* y = x * inverted-dropout mask(seed + *seed_ptr, index)  (forward and backward of nn.Dropout). */
+int cb_dropout(int32_t dtype, const void* x, void* y, int64_t n, float p, uint64_t seed,
+               const uint64_t* seed_ptr, void* stream);
 int cb_sq_sum(const float* g, int64_t n, float* out_accum, void* stream);
 
 const char* cb_last_error(void);

@@ -155,7 +155,8 @@ def test_adamw_matches_reference_restatement_with_clipping(emul):
     pr, mr, vr = O.adamw_step(p, gc[0], m, v, step=3, lr=5e-5, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=1e-3)
     w16 = torch.empty(n, dtype=torch.bfloat16)
     p2, m2, v2 = p.clone(), m.clone(), v.clone()
-    ops.adamw(p2, g, m2, v2, w16, 5e-5, 0.9, 0.98, 1e-6, 1e-3, 3, grad_sq_sum=sq, max_norm=5.0)
+    hp = torch.tensor(ops.adamw_hyper(5e-5, 0.9, 0.98, 1e-6, 1e-3, 3, max_norm=5.0))
+    ops.adamw(p2, g, m2, v2, w16, hp, grad_sq_sum=sq)
     torch.testing.assert_close(p2, pr, rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(m2, mr, rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(v2, vr, rtol=1e-5, atol=1e-8)
@@ -194,3 +195,33 @@ def test_pool_stem_and_relu_bwd(emul, dt):
     torch.testing.assert_close(dz.float(), refdz.to(dt).float())
     torch.testing.assert_close(g.float(), (refdz * sc).to(dt).float(), **tol(dt))
     torch.testing.assert_close(g2.float(), (refdz * sc2).to(dt).float(), **tol(dt))
+
+
+def test_dropout_kernel_and_seed_pointer(emul):
+    x = torch.ones(5001)
+    a = ops.dropout(x, 0.1, seed=3)
+    b = ops.dropout(x, 0.1, seed=1, seed_ptr=torch.tensor([2], dtype=torch.int64))
+    assert torch.equal(a, b)                       # seed + *seed_ptr
+    assert abs((a > 0).float().mean().item() - 0.9) < 0.02
+    torch.testing.assert_close(a[a > 0], torch.full_like(a[a > 0], 1 / 0.9))
+    c = ops.dropout(x, 0.1, seed=4)
+    assert not torch.equal(a, c)
+
+
+def test_layernorm_bwd_row_segments(emul):
+    B, L, Lt, D = 3, 7, 4, 64
+    x, dy = rnd(B * L, D, seed=1), rnd(B * L, D, seed=2)
+    g = 1 + rnd(D, seed=3, scale=0.1)
+    mean, var = x.mean(-1), x.var(-1, unbiased=False)
+    rstd = (var + 1e-12).rsqrt()
+    dx = torch.zeros_like(x)
+    dg, db = torch.zeros(D), torch.zeros(D)
+    ops.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dx=dx, rows=B * Lt, seg=(Lt, L, 0))
+    xr = x.clone().requires_grad_(True)
+    gr = g.clone().requires_grad_(True)
+    y = F.layer_norm(xr, (D,), gr, torch.zeros(D), 1e-12)
+    sel = torch.zeros(B, L, 1)
+    sel[:, :Lt] = 1
+    y.backward(dy * sel.view(B * L, 1))
+    torch.testing.assert_close(dx, xr.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dg, gr.grad, rtol=1e-4, atol=1e-4)

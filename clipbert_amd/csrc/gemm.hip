@@ -462,7 +462,8 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     if (d->a_mode == CB_ROWK_GATHER) {
         CB_REQUIRE(d->a_tab, "cb_gemm: a_tab missing");
         CB_REQUIRE(d->K == taps * p.Ct, "cb_gemm: K (%d) != R*S*Cin (%d)", d->K, taps * p.Ct);
-        CB_REQUIRE(d->sH % eps == 0 && d->sW % eps == 0 && aligned16(d->A), "cb_gemm: gather strides/base must be 16-byte multiples");
+        CB_REQUIRE((p.R == 1 || d->sH % eps == 0) && (p.S == 1 || d->sW % eps == 0) && aligned16(d->A),
+                   "cb_gemm: gather strides/base must be 16-byte multiples");
         p.a_vec = 1;
     } else if (d->a_mode == CB_ROWK) {
         p.a_vec = (d->lda % eps == 0) && (d->K % eps == 0) && aligned16(d->A);
@@ -479,7 +480,8 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     } else {
         CB_REQUIRE(d->b_tab, "cb_gemm: b_tab missing");
         CB_REQUIRE(d->N == taps * p.Ct, "cb_gemm: N (%d) != R*S*Cin (%d)", d->N, taps * p.Ct);
-        CB_REQUIRE(d->sH % eps == 0 && d->sW % eps == 0 && aligned16(d->B), "cb_gemm: gather strides/base must be 16-byte multiples");
+        CB_REQUIRE((p.R == 1 || d->sH % eps == 0) && (p.S == 1 || d->sW % eps == 0) && aligned16(d->B),
+                   "cb_gemm: gather strides/base must be 16-byte multiples");
         p.b_vec = 1;
     }
     if (p.split_k > 1) {

@@ -1,0 +1,1058 @@
+"""ClipBERT module API on top of libclipbert_hip (MI355X / gfx950).
+
+The classes keep the reference's names, constructor / forward signatures, returned dicts and
+state-dict keys:
+
+    ClipBert(config, input_format="BGR", detectron2_model_cfg=..., transformer_cls=...)   e2e_model.py:14-50
+    GridFeatBackbone                                                                      grid_feat.py:37-105
+    ClipBertForPreTraining / ...VideoTextRetrieval / ...MultipleChoice / ...SequenceClassification
+                                                                                          modeling.py:241-580
+
+but they hold no PyTorch compute: parameters are views into flat HBM buffers (params.ParamBank) and
+every forward / backward step is a call into the C ABI (clipbert_amd.ops).  The backward pass is written
+out explicitly (two coarse autograd nodes: CNN trunk, cross-modal encoder) so that residual-gradient
+sums, ReLU/FrozenBN masks and bias/LayerNorm reductions are fused into kernel epilogues instead of
+being left to autograd's eager tensor ops.  Parameter gradients are accumulated by the kernels
+directly into the flat fp32 gradient buffer (``p.grad`` is a view of it).
+"""
+import math
+from types import SimpleNamespace
+from typing import List, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from .ops import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_TANH, KROW, KROW_GATHER, KROW_TAPS, ROWK, ROWK_GATHER)
+from .params import ParamBank
+
+FROZEN_BN_EPS = 1e-5
+RESNET50_STAGES = (("res2", 3, 64, 256, 1), ("res3", 4, 128, 512, 2), ("res4", 6, 256, 1024, 2),
+                   ("res5", 3, 512, 2048, 2))
+
+
+def _cfg_get(config, key, default=None):
+    if isinstance(config, dict):
+        return config.get(key, default)
+    return getattr(config, key, default)
+
+
+def as_config(config):
+    """Accepts a dict (src/configs/base_model.json contents + task keys) or any attribute bag."""
+    if isinstance(config, dict):
+        return SimpleNamespace(**config)
+    return config
+
+
+# =================================================================================================
+# parameter holders (names chosen so that state_dict() keys equal the reference's)
+# =================================================================================================
+class Linear(nn.Module):
+    def __init__(self, in_features, out_features, std=0.02):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.randn(out_features, in_features) * std)
+        self.bias = nn.Parameter(torch.zeros(out_features))
+
+
+class Embedding(nn.Module):
+    def __init__(self, n, dim, std=0.02, padding_idx=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(n, dim) * std)
+        self.padding_idx = padding_idx
+        if padding_idx is not None:
+            with torch.no_grad():
+                self.weight[padding_idx].zero_()
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, dim, eps):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+        self.eps = eps
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """detectron2.layers.FrozenBatchNorm2d: four buffers, y = x*scale + shift with fixed statistics."""
+    def __init__(self, c):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(c))
+        self.register_buffer("bias", torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+
+
+class Conv2d(nn.Module):
+    """Conv weight in the reference's OIHW logical shape (channels_last memory image = KRSC) plus an
+    optional FrozenBN child called ``norm`` as detectron2 names it."""
+    def __init__(self, cin, cout, k, stride=1, pad=0, norm=True):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
+        w = torch.randn(cout, cin, k, k) * math.sqrt(2.0 / (cout * k * k))
+        self.weight = nn.Parameter(w.contiguous(memory_format=torch.channels_last))
+        self.norm = FrozenBatchNorm2d(cout) if norm else None
+        self._ss = None
+
+    def scale_shift(self):
+        """fp32 per-channel (scale, shift) of the frozen affine; cached (buffers are constants)."""
+        if self.norm is None:
+            return None, None
+        if self._ss is None or self._ss[0].device != self.norm.weight.device:
+            n = self.norm
+            scale = (n.weight.float() * (n.running_var.float() + FROZEN_BN_EPS).rsqrt()).contiguous()
+            shift = (n.bias.float() - n.running_mean.float() * scale).contiguous()
+            self._ss = (scale, shift)
+        return self._ss
+
+    def _load_from_state_dict(self, *a, **kw):
+        self._ss = None
+        return super()._load_from_state_dict(*a, **kw)
+
+
+class BottleneckBlock(nn.Module):
+    def __init__(self, cin, mid, cout, stride):
+        super().__init__()
+        self.shortcut = Conv2d(cin, cout, 1, stride) if cin != cout else None
+        self.conv1 = Conv2d(cin, mid, 1, stride)          # stride in the 1x1 (STRIDE_IN_1X1=True)
+        self.conv2 = Conv2d(mid, mid, 3, 1, 1)
+        self.conv3 = Conv2d(mid, cout, 1)
+
+
+class _Stem(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = Conv2d(3, 64, 7, 2, 3)
+
+
+class _ResNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.stem = _Stem()
+        cin = 64
+        for name, n_blocks, mid, cout, stride in RESNET50_STAGES:
+            blocks = []
+            for b in range(n_blocks):
+                blocks.append(BottleneckBlock(cin, mid, cout, stride if b == 0 else 1))
+                cin = cout
+            setattr(self, name, nn.ModuleList(blocks))
+
+
+class _Detectron2Model(nn.Module):
+    """Only ``backbone`` of the GeneralizedRCNN is ever executed by ClipBERT (grid_feat.py:95-97);
+    the RPN / ROI heads of the reference checkpoint are ignored at load time."""
+    def __init__(self):
+        super().__init__()
+        self.backbone = _ResNet()
+
+
+class _GridConv(nn.Module):
+    """grid_encoder[0]: conv3x3(2048 -> hidden, no bias)  (grid_feat.py:16-21,43-45)."""
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, 3, 1, 1
+        w = torch.randn(cout, cin, 3, 3) * math.sqrt(2.0 / (cin * 9))
+        self.weight = nn.Parameter(w.contiguous(memory_format=torch.channels_last))
+        self.norm = None
+
+    def scale_shift(self):
+        return None, None
+
+
+# =================================================================================================
+# execution context shared by all modules of one ClipBert instance
+# =================================================================================================
+class Runtime:
+    def __init__(self):
+        self.bank: Optional[ParamBank] = None
+        self.dtype = torch.bfloat16
+        self.tables = {}
+        self.rowmaps = {}
+        self.seed_dev: Optional[torch.Tensor] = None     # device int64 added to every dropout seed
+        self.anchor: Optional[torch.Tensor] = None       # requires_grad leaf that keeps the coarse nodes alive
+        self.stem_w = None
+
+    def table(self, n, oh, ow, stride, pad, sN, sH, sW, device):
+        key = (n, oh, ow, stride, pad, sN, sH, sW, str(device))
+        t = self.tables.get(key)
+        if t is None:
+            t = ops.build_pixel_table(n, oh, ow, stride, pad, sN, sH, sW, device)
+            self.tables[key] = t
+        return t
+
+    def strided_rowmap(self, n, h, w, oh, ow, stride, device):
+        key = (n, h, w, oh, ow, stride, str(device))
+        t = self.rowmaps.get(key)
+        if t is None:
+            t = (torch.arange(n).view(n, 1, 1) * (h * w) + (torch.arange(oh) * stride).view(1, oh, 1) * w
+                 + (torch.arange(ow) * stride).view(1, 1, ow)).reshape(-1).to(torch.int32).to(device)
+            self.rowmaps[key] = t
+        return t
+
+
+def _pick_split(mo, no, kred):
+    """split-K factor for weight-gradient GEMMs (tiny outputs, long pixel reductions)."""
+    blocks = ((mo + 63) // 64) * ((no + 63) // 64)
+    ktiles = (kred + 31) // 32
+    if blocks >= 384 or ktiles < 16:
+        return 1
+    return max(1, min((512 + blocks - 1) // blocks, ktiles // 8))
+
+
+# =================================================================================================
+# CNN trunk: explicit forward / backward
+# =================================================================================================
+def _conv_fwd(rt: Runtime, x, conv, act=ACT_NONE, residual=None, relu_after=False):
+    n, h, w, cin = x.shape
+    k, s, p = conv.k, conv.stride, conv.pad
+    oh, ow = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    cout = conv.cout
+    m = n * oh * ow
+    y = torch.empty(n, oh, ow, cout, dtype=x.dtype, device=x.device)
+    wk = rt.bank.compute(conv.weight).view(cout, k * k * cin)
+    scale, shift = conv.scale_shift()
+    res2d = residual.view(m, cout) if residual is not None else None
+    if k == 1 and s == 1:
+        ops.gemm(x.view(m, cin), wk, m, cout, cin, out=y.view(m, cout), scale=scale, shift=shift, act=act,
+                 residual=res2d, relu_after=relu_after)
+    else:
+        tab = rt.table(n, oh, ow, s, p, h * w * cin, w * cin, cin, x.device)
+        ops.gemm(x, wk, m, cout, k * k * cin, out=y.view(m, cout), a_mode=ROWK_GATHER, a_tab=tab, lda=0,
+                 ldb=k * k * cin, R=k, S=k, Cin=cin, H=h, W=w, sH=w * cin, sW=cin, scale=scale, shift=shift, act=act,
+                 residual=res2d, relu_after=relu_after)
+    return y
+
+
+def _conv_dgrad(rt: Runtime, g, conv, in_shape, scale=None, mask=None, residual=None, out=None, accumulate=False):
+    """d(input) of a convolution given g = d(conv output) (already multiplied by the FrozenBN scale).
+    Epilogue options: per-channel ``scale`` and ReLU ``mask`` of the PRODUCER of the input, ``residual``."""
+    n, h, w, cin = in_shape
+    _, oh, ow, cout = g.shape
+    k, s, p = conv.k, conv.stride, conv.pad
+    wk = rt.bank.compute(conv.weight).view(cout, k * k * cin)
+    mi = n * h * w
+    if out is None:
+        out = (torch.zeros if s > 1 else torch.empty)(n, h, w, cin, dtype=g.dtype, device=g.device)
+    o2 = out.view(mi, cin)
+    r2 = residual.view(mi, cin) if residual is not None else None
+    k2 = mask.view(mi, cin) if mask is not None else None
+    if k == 1:
+        rowmap = rt.strided_rowmap(n, h, w, oh, ow, s, g.device) if s > 1 else None
+        ops.gemm(g.view(n * oh * ow, cout), wk, n * oh * ow, cin, cout, out=o2, b_mode=KROW_TAPS, ldb=cin, R=1, S=1,
+                 Cin=cout, c_rowmap=rowmap, scale=scale, mask=k2, residual=r2, accumulate=accumulate)
+    else:
+        assert s == 1
+        tab = rt.table(n, h, w, 1, k - 1 - p, oh * ow * cout, ow * cout, cout, g.device)
+        ops.gemm(g, wk, mi, cin, k * k * cout, out=o2, a_mode=ROWK_GATHER, a_tab=tab, lda=0, b_mode=KROW_TAPS,
+                 ldb=k * k * cin, R=k, S=k, Cin=cout, H=oh, W=ow, sH=ow * cout, sW=cout, flip_taps=True, scale=scale,
+                 mask=k2, residual=r2, accumulate=accumulate)
+    return out
+
+
+def _conv_wgrad(rt: Runtime, g, x, conv):
+    """dW[co][(r,s,c)] += sum_pixels g[m,co] * x[pix(m,r,s), c], straight into the flat fp32 grad buffer."""
+    gw = rt.bank.grad_image(conv.weight)
+    if gw is None:
+        return
+    n, h, w, cin = x.shape
+    _, oh, ow, cout = g.shape
+    k, s, p = conv.k, conv.stride, conv.pad
+    m = n * oh * ow
+    kk = k * k * cin
+    split = _pick_split(cout, kk, m)
+    if k == 1 and s == 1:
+        ops.gemm(g.view(m, cout), x.view(m, cin), cout, cin, m, out=gw.view(cout, kk), a_mode=KROW, lda=cout,
+                 b_mode=KROW, ldb=cin, accumulate=True, split_k=split)
+    else:
+        tab = rt.table(n, oh, ow, s, p, h * w * cin, w * cin, cin, x.device)
+        ops.gemm(g.view(m, cout), x, cout, kk, m, out=gw.view(cout, kk), a_mode=KROW, lda=cout, b_mode=KROW_GATHER,
+                 b_tab=tab, ldb=0, R=k, S=k, Cin=cin, H=h, W=w, sH=w * cin, sW=cin, accumulate=True, split_k=split)
+
+
+def _stem_weight(rt: Runtime, conv: Conv2d):
+    """[64][7 rows][8 taps x 4 ch] image of the 7x7x3 stem filter (tap 7 and channel 3 are zero)."""
+    if rt.stem_w is None:
+        w = conv.weight.detach().float()                         # (64, 3, 7, 7)
+        wp = torch.zeros(64, 7, 8, 4, dtype=torch.float32, device=w.device)
+        wp[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+        rt.stem_w = wp.view(64, 224).to(rt.dtype).contiguous()
+    return rt.stem_w
+
+
+def _block_trainable(rt: Runtime, blk: BottleneckBlock) -> bool:
+    return any(rt.bank.is_trainable(c.weight) for c in (blk.conv1, blk.conv2, blk.conv3) + ((blk.shortcut,) if blk.shortcut is not None else ()))
+
+
+def cnn_forward(bb: "GridFeatBackbone", x5: torch.Tensor, save: bool):
+    """(B,T,3,H,W) fp32 RGB mean-subtracted (or uint8 RGB) -> grid (B,T,H',W',hidden) + saved activations."""
+    rt = bb.rt
+    b, t, c, h, w = x5.shape
+    n = b * t
+    x4 = x5.reshape(n, c, h, w)
+    if not x4.is_contiguous():
+        x4 = x4.contiguous()
+    if x4.dtype == torch.uint8:
+        packed = ops.stem_pack(x4, rt.dtype, 3, bb.pixel_mean, bb.pixel_std, extra_w=2)
+    else:
+        packed = ops.stem_pack(x4.float(), rt.dtype, 3, extra_w=2)
+    hp, wp = packed.shape[1], packed.shape[2]
+    net = bb.feature.backbone
+    stem = net.stem.conv1
+    oh, ow = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+    m = n * oh * ow
+    tab = rt.table(n, oh, ow, 2, 0, hp * wp * 4, wp * 4, 4, x5.device)
+    y = torch.empty(n, oh, ow, 64, dtype=rt.dtype, device=x5.device)
+    scale, shift = stem.scale_shift()
+    ops.gemm(packed, _stem_weight(rt, stem), m, 64, 224, out=y.view(m, 64), a_mode=ROWK_GATHER, a_tab=tab, lda=0, ldb=224,
+             R=7, S=1, Cin=32, H=hp, W=wp, sH=wp * 4, sW=4, scale=scale, shift=shift, act=ACT_RELU)
+    x = ops.maxpool_fwd(y, 3, 2, 1)
+    saved = []
+    for name, _nb, _mid, _cout, _s in RESNET50_STAGES:
+        for blk in getattr(net, name):
+            sc = _conv_fwd(rt, x, blk.shortcut) if blk.shortcut is not None else x
+            y1 = _conv_fwd(rt, x, blk.conv1, act=ACT_RELU)
+            y2 = _conv_fwd(rt, y1, blk.conv2, act=ACT_RELU)
+            out = _conv_fwd(rt, y2, blk.conv3, residual=sc, relu_after=True)
+            if save and _block_trainable(rt, blk):
+                saved.append((blk, x, y1, y2, out))
+            x = out
+    gconv = bb.grid_encoder[0]
+    gy = _conv_fwd(rt, x, gconv)
+    grid = ops.maxpool_fwd(gy, 2, 2, 0, relu=True)
+    hg, wg = grid.shape[1], grid.shape[2]
+    return grid.view(b, t, hg, wg, gconv.cout), (saved, x, gy, grid) if save else None
+
+
+def cnn_backward(bb: "GridFeatBackbone", saved_pack, dgrid: torch.Tensor):
+    rt = bb.rt
+    saved, res5, gy, grid = saved_pack
+    gconv = bb.grid_encoder[0]
+    dg = ops.maxpool2_bwd(gy, grid, dgrid.reshape(grid.shape).contiguous(), relu=True)
+    _conv_wgrad(rt, dg, res5, gconv)
+    if not saved:
+        return
+    dout = _conv_dgrad(rt, dg, gconv, res5.shape)
+    for idx in range(len(saved) - 1, -1, -1):
+        blk, x, y1, y2, out = saved[idx]
+        need_dx = idx > 0
+        s3, _ = blk.conv3.scale_shift()
+        s2, _ = blk.conv2.scale_shift()
+        s1, _ = blk.conv1.scale_shift()
+        if blk.shortcut is not None:
+            ssc, _ = blk.shortcut.scale_shift()
+            g3, _dz, gsc = ops.relu_scale_bwd(dout, out, s3, False, ssc)
+            dz = None
+        else:
+            g3, dz, gsc = ops.relu_scale_bwd(dout, out, s3, True, None)
+        _conv_wgrad(rt, g3, y2, blk.conv3)
+        g2 = _conv_dgrad(rt, g3, blk.conv3, y2.shape, scale=s2, mask=y2)       # -> d(conv2 out) * mask * scale2
+        _conv_wgrad(rt, g2, y1, blk.conv2)
+        g1 = _conv_dgrad(rt, g2, blk.conv2, y1.shape, scale=s1, mask=y1)
+        _conv_wgrad(rt, g1, x, blk.conv1)
+        if blk.shortcut is not None:
+            _conv_wgrad(rt, gsc, x, blk.shortcut)
+        if need_dx:
+            if blk.shortcut is None:
+                dout = _conv_dgrad(rt, g1, blk.conv1, x.shape, residual=dz)
+            else:
+                dout = _conv_dgrad(rt, g1, blk.conv1, x.shape)
+                _conv_dgrad(rt, gsc, blk.shortcut, x.shape, out=dout, accumulate=True)
+
+
+class _CnnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, x5, bb):
+        save = ctx.needs_input_grad[0] and bb.has_trainable()    # anchor: True iff autograd is recording
+        grid, pack = cnn_forward(bb, x5, save)
+        ctx.bb, ctx.pack = bb, pack
+        return grid
+
+    @staticmethod
+    def backward(ctx, dgrid):
+        if ctx.pack is not None:
+            cnn_backward(ctx.bb, ctx.pack, dgrid.contiguous())
+            ctx.pack = None
+        return None, None, None
+
+
+class GridFeatBackbone(nn.Module):
+    """ResNet-50 grid-feature backbone + grid encoder (src/modeling/grid_feat.py:37-105)."""
+    def __init__(self, detectron2_model_cfg=None, config=None, input_format="BGR", freeze_at=2):
+        super().__init__()
+        assert input_format == "BGR", "detectron 2 image input format should be BGR"
+        config = as_config(config)
+        self.detectron2_model_cfg = detectron2_model_cfg
+        self.feature = _Detectron2Model()
+        self.grid_encoder = nn.ModuleList([_GridConv(config.backbone_channel_in_size, config.hidden_size)])
+        self.input_format = input_format
+        self.config = config
+        self.pixel_mean = (123.675, 116.28, 103.53)
+        self.pixel_std = (1.0, 1.0, 1.0)
+        self.rt: Optional[Runtime] = None
+        # detectron2 FREEZE_AT=2: stem and res2 never receive gradients
+        net = self.feature.backbone
+        frozen = [net.stem] + ([net.res2] if freeze_at >= 2 else [])
+        for mod in frozen:
+            for p in mod.parameters():
+                p.requires_grad = False
+
+    @property
+    def config_file(self):
+        return f"clipbert_amd R-50 grid backbone (detectron2 cfg: {self.detectron2_model_cfg})"
+
+    def has_trainable(self):
+        return any(p.requires_grad for p in self.parameters())
+
+    def forward(self, x):
+        """x: (B, n_frm, 3, H, W) RGB float (mean-subtracted) or uint8 -> (B, n_frm, H', W', hidden)."""
+        return _CnnFn.apply(self.rt.anchor, x, self)
+
+
+# =================================================================================================
+# cross-modal BERT
+# =================================================================================================
+class BertEmbeddings(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.word_embeddings = Embedding(config.vocab_size, config.hidden_size, config.initializer_range,
+                                         padding_idx=_cfg_get(config, "pad_token_id", 0))
+        self.position_embeddings = Embedding(config.max_position_embeddings, config.hidden_size, config.initializer_range)
+        self.token_type_embeddings = Embedding(config.type_vocab_size, config.hidden_size, config.initializer_range)
+        self.LayerNorm = LayerNorm(config.hidden_size, config.layer_norm_eps)
+
+
+class VisualInputEmbedding(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        r = config.initializer_range
+        self.position_embeddings = Embedding(config.max_position_embeddings, config.hidden_size, r)   # unused (as in the reference)
+        self.row_position_embeddings = Embedding(config.max_grid_row_position_embeddings, config.hidden_size, r)
+        self.col_position_embeddings = Embedding(config.max_grid_col_position_embeddings, config.hidden_size, r)
+        self.token_type_embeddings = Embedding(1, config.hidden_size, r)
+        self.LayerNorm = LayerNorm(config.hidden_size, config.layer_norm_eps)
+
+
+class _SelfAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        d = config.hidden_size
+        self.query, self.key, self.value = Linear(d, d), Linear(d, d), Linear(d, d)
+
+
+class _SelfOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = LayerNorm(config.hidden_size, config.layer_norm_eps)
+
+
+class _Attention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.self = _SelfAttention(config)
+        self.output = _SelfOutput(config)
+
+
+class _Intermediate(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = Linear(config.hidden_size, config.intermediate_size)
+
+
+class _Output(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = Linear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = LayerNorm(config.hidden_size, config.layer_norm_eps)
+
+
+class BertLayer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.attention = _Attention(config)
+        self.intermediate = _Intermediate(config)
+        self.output = _Output(config)
+
+
+class BertEncoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.layer = nn.ModuleList([BertLayer(config) for _ in range(config.num_hidden_layers)])
+
+
+class BertPooler(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = Linear(config.hidden_size, config.hidden_size)
+
+
+# dropout sites -> distinct seed streams
+_SITE_EMB, _SITE_ATTN, _SITE_SELF_OUT, _SITE_OUT, _SITE_POOL = 1, 2, 3, 4, 5
+
+
+def _seed(site, layer=0):
+    return (site * 1000003 + layer * 7919) * 2654435761 % (1 << 62)
+
+
+class ClipBertBaseModel(nn.Module):
+    """Embeddings + 12-layer encoder + pooler (src/modeling/modeling.py:156-238)."""
+    def __init__(self, config):
+        super().__init__()
+        config = as_config(config)
+        assert _cfg_get(config, "hidden_act", "gelu") == "gelu", "only the exact-erf GELU of base_model.json is implemented"
+        assert config.hidden_size // config.num_attention_heads == 64, "attention kernels are built for head size 64"
+        self.config = config
+        self.embeddings = BertEmbeddings(config)
+        self.visual_embeddings = VisualInputEmbedding(config)
+        self.encoder = BertEncoder(config)
+        self.pooler = BertPooler(config)
+        self.rt: Optional[Runtime] = None
+
+    def get_input_embeddings(self):
+        return self.embeddings.word_embeddings
+
+    def forward(self, text_input_ids, visual_inputs, attention_mask, src_row=None, pooled_dropout=False):
+        """visual_inputs: grid (Bv, n_frm, H', W', d); src_row maps each text row to its grid row
+        (the fused form of repeat_tensor_rows).  Returns (sequence_output (B, L, d), pooled (B, d))."""
+        seq, pooled = _EncoderFn.apply(self.rt.anchor, visual_inputs, self, text_input_ids, attention_mask, src_row,
+                                       pooled_dropout)
+        b = text_input_ids.shape[0]
+        return seq.view(b, -1, self.config.hidden_size), pooled
+
+
+def _drop_p(model, training, key="hidden_dropout_prob"):
+    return float(_cfg_get(model.config, key, 0.0)) if training else 0.0
+
+
+def encoder_forward(model: ClipBertBaseModel, grid, ids, mask, src_row, pooled_dropout, save):
+    rt, cfg = model.rt, model.config
+    bank, dt, dev = rt.bank, rt.dtype, ids.device
+    d, nh, eps = cfg.hidden_size, cfg.num_attention_heads, cfg.layer_norm_eps
+    training = model.training
+    p_h = _drop_p(model, training)
+    p_a = _drop_p(model, training, "attention_probs_dropout_prob")
+    bsz, lt = ids.shape
+    bv, t, hg, wg, _ = grid.shape
+    # optional random pixel sub-sampling: training phase of pre-training only (modeling.py:80-88)
+    sel = None
+    lv = hg * wg
+    nsamp = int(_cfg_get(cfg, "pixel_random_sampling_size", 0) or 0)
+    if nsamp > 0 and training and nsamp < lv:
+        idx = np.sort(np.random.choice(lv, size=nsamp, replace=False))     # numpy global RNG, as the reference
+        sel = torch.from_numpy(idx.astype(np.int32)).to(dev)
+        lv = nsamp
+    L = lt + lv
+    M = bsz * L
+    if src_row is None:
+        assert bv == bsz, "visual batch and text batch differ: pass src_row (n_examples_list)"
+    key_mask = torch.ones(bsz, L, dtype=torch.float32, device=dev)
+    key_mask[:, :lt] = mask.to(torch.float32)
+    x = torch.empty(M, d, dtype=dt, device=dev)
+    pre = torch.empty(M, d, dtype=dt, device=dev) if save else None
+    mean0 = torch.empty(M, dtype=torch.float32, device=dev) if save else None
+    rstd0 = torch.empty(M, dtype=torch.float32, device=dev) if save else None
+    emb, vemb = model.embeddings, model.visual_embeddings
+    ids_c = ids.contiguous()
+    ops.text_embed_fwd(ids_c, bank.compute(emb.word_embeddings.weight), bank.compute(emb.position_embeddings.weight),
+                       bank.compute(emb.token_type_embeddings.weight)[0], emb.LayerNorm.weight, emb.LayerNorm.bias, x, pre,
+                       mean0, rstd0, lt, L, eps)
+    grid_c = grid.contiguous()
+    ops.visual_embed_fwd(grid_c, src_row, sel, bank.compute(vemb.row_position_embeddings.weight),
+                         bank.compute(vemb.col_position_embeddings.weight), bank.compute(vemb.token_type_embeddings.weight)[0],
+                         vemb.LayerNorm.weight, vemb.LayerNorm.bias, x, pre, mean0, rstd0, bsz, lv, lt, L, eps)
+    if p_h > 0:
+        ops.dropout(x, p_h, _seed(_SITE_EMB), rt.seed_dev, out=x)
+    layers = []
+    for li, layer in enumerate(model.encoder.layer):
+        att, so, it, ou = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
+        wqkv = bank.compute_span(att.query.weight, att.value.weight, (3 * d, d))
+        bqkv = bank.master_span(att.query.bias, att.value.bias, (3 * d,))
+        qkv = torch.empty(M, 3 * d, dtype=dt, device=dev)
+        ops.gemm(x, wqkv, M, 3 * d, d, out=qkv, shift=bqkv)
+        ctx, lse = ops.attention_fwd(qkv, key_mask, bsz, L, nh, save_lse=save, dropout_p=p_a,
+                                     dropout_seed=_seed(_SITE_ATTN, li), seed_ptr=rt.seed_dev)
+        a_pre = torch.empty(M, d, dtype=dt, device=dev)
+        ops.gemm(ctx, bank.compute(so.dense.weight), M, d, d, out=a_pre, shift=so.dense.bias, residual=x, dropout_p=p_h,
+                 dropout_seed=_seed(_SITE_SELF_OUT, li), seed_ptr=rt.seed_dev)
+        a, mean1, rstd1 = ops.layernorm_fwd(a_pre, so.LayerNorm.weight, so.LayerNorm.bias, eps, save_stats=save)
+        ff = cfg.intermediate_size
+        hact = torch.empty(M, ff, dtype=dt, device=dev)
+        hpre = torch.empty(M, ff, dtype=dt, device=dev) if save else None
+        ops.gemm(a, bank.compute(it.dense.weight), M, ff, d, out=hact, shift=it.dense.bias, act=ACT_GELU, out2=hpre)
+        o_pre = torch.empty(M, d, dtype=dt, device=dev)
+        ops.gemm(hact, bank.compute(ou.dense.weight), M, d, ff, out=o_pre, shift=ou.dense.bias, residual=a, dropout_p=p_h,
+                 dropout_seed=_seed(_SITE_OUT, li), seed_ptr=rt.seed_dev)
+        out, mean2, rstd2 = ops.layernorm_fwd(o_pre, ou.LayerNorm.weight, ou.LayerNorm.bias, eps, save_stats=save)
+        if save:
+            layers.append((x, qkv, ctx, lse, a_pre, mean1, rstd1, a, hpre, hact, o_pre, mean2, rstd2))
+        x = out
+    pooled = torch.empty(bsz, d, dtype=dt, device=dev)
+    p_pool = p_h if pooled_dropout else 0.0
+    pooled_raw = torch.empty(bsz, d, dtype=dt, device=dev) if (save and p_pool > 0) else None
+    pw = model.pooler.dense
+    if pooled_raw is not None:
+        ops.gemm(x, bank.compute(pw.weight), bsz, d, d, out=pooled_raw, lda=L * d, shift=pw.bias, act=ACT_TANH)
+        ops.dropout(pooled_raw, p_pool, _seed(_SITE_POOL), rt.seed_dev, out=pooled)
+    else:
+        ops.gemm(x, bank.compute(pw.weight), bsz, d, d, out=pooled, lda=L * d, shift=pw.bias, act=ACT_TANH,
+                 dropout_p=p_pool, dropout_seed=_seed(_SITE_POOL), seed_ptr=rt.seed_dev)
+    pack = None
+    if save:
+        pack = SimpleNamespace(layers=layers, x_final=x, pooled=pooled, pooled_raw=pooled_raw, p_pool=p_pool, pre=pre,
+                               mean0=mean0, rstd0=rstd0, ids=ids_c, key_mask=key_mask, src_row=src_row, sel=sel, bsz=bsz,
+                               lt=lt, lv=lv, L=L, grid_shape=tuple(grid.shape), p_h=p_h, p_a=p_a)
+    return x, pooled, pack
+
+
+def _linear_wgrad(rt: Runtime, g, x, lin_weight, lin_bias, m, n, k, ldx=None, grad_w=None, grad_b=None):
+    """dW[n,k] += g[m,n]^T x[m,k];  db[n] += colsum(g)."""
+    gw = grad_w if grad_w is not None else rt.bank.grad_image(lin_weight)
+    if gw is not None:
+        ops.gemm(g, x, n, k, m, out=gw, a_mode=KROW, lda=g.stride(0), b_mode=KROW, ldb=ldx if ldx is not None else x.stride(0),
+                 accumulate=True, split_k=_pick_split(n, k, m))
+    gb = grad_b if grad_b is not None else (rt.bank.grad_image(lin_bias) if lin_bias is not None else None)
+    if gb is not None:
+        ops.colsum(g, gb, m, n)
+
+
+def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
+    rt, cfg = model.rt, model.config
+    bank, dt = rt.bank, rt.dtype
+    d, nh, ff = cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size
+    bsz, L, lt, lv = pk.bsz, pk.L, pk.lt, pk.lv
+    M = bsz * L
+    dev = pk.x_final.device
+    # ---- pooler ------------------------------------------------------------------------------------
+    if d_seq is None:
+        dx = torch.zeros(M, d, dtype=dt, device=dev)
+    else:
+        dx = d_seq.reshape(M, d)
+        if dx.dtype != dt or not dx.is_contiguous():
+            dx = ops.cast(dx.contiguous(), torch.empty(M, d, dtype=dt, device=dev))
+    if d_pooled is not None:
+        g = d_pooled.to(dt).contiguous()
+        if pk.pooled_raw is not None:
+            g = ops.dropout(g, pk.p_pool, _seed(_SITE_POOL), rt.seed_dev)
+            g = ops.act_bwd(ACT_TANH, g, pk.pooled_raw)
+        else:
+            g = ops.act_bwd(ACT_TANH, g, pk.pooled)
+        pw = model.pooler.dense
+        _linear_wgrad(rt, g, pk.x_final, pw.weight, pw.bias, bsz, d, d, ldx=L * d)
+        ops.gemm(g, bank.compute(pw.weight), bsz, d, d, out=dx, b_mode=KROW, ldc=L * d, accumulate=True)
+    # ---- encoder layers, last to first -----------------------------------------------------------------
+    for li in range(len(pk.layers) - 1, -1, -1):
+        layer = model.encoder.layer[li]
+        att, so, it, ou = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
+        x, qkv, ctx, lse, a_pre, mean1, rstd1, a, hpre, hact, o_pre, mean2, rstd2 = pk.layers[li]
+        d_o_pre, d_o_drop = ops.layernorm_bwd(dx, o_pre, ou.LayerNorm.weight, mean2, rstd2, bank.grad_image(ou.LayerNorm.weight),
+                                              bank.grad_image(ou.LayerNorm.bias), pk.p_h, _seed(_SITE_OUT, li), rt.seed_dev)
+        g = d_o_drop if d_o_drop is not None else d_o_pre
+        _linear_wgrad(rt, g, hact, ou.dense.weight, ou.dense.bias, M, d, ff)
+        dh = torch.empty(M, ff, dtype=dt, device=dev)
+        ops.gemm(g, bank.compute(ou.dense.weight), M, ff, d, out=dh, b_mode=KROW)
+        dhp = ops.act_bwd(ACT_GELU, dh, hpre)
+        _linear_wgrad(rt, dhp, a, it.dense.weight, it.dense.bias, M, ff, d)
+        da = torch.empty(M, d, dtype=dt, device=dev)
+        ops.gemm(dhp, bank.compute(it.dense.weight), M, d, ff, out=da, b_mode=KROW, residual=d_o_pre)
+        d_a_pre, d_a_drop = ops.layernorm_bwd(da, a_pre, so.LayerNorm.weight, mean1, rstd1, bank.grad_image(so.LayerNorm.weight),
+                                              bank.grad_image(so.LayerNorm.bias), pk.p_h, _seed(_SITE_SELF_OUT, li), rt.seed_dev)
+        g = d_a_drop if d_a_drop is not None else d_a_pre
+        _linear_wgrad(rt, g, ctx, so.dense.weight, so.dense.bias, M, d, d)
+        dctx = torch.empty(M, d, dtype=dt, device=dev)
+        ops.gemm(g, bank.compute(so.dense.weight), M, d, d, out=dctx, b_mode=KROW)
+        dqkv = ops.attention_bwd(qkv, pk.key_mask, ctx, dctx, lse, bsz, L, nh, pk.p_a, _seed(_SITE_ATTN, li), rt.seed_dev)
+        gw = bank.grad_span(att.query.weight, att.value.weight, (3 * d, d)) if bank.is_trainable(att.query.weight) else None
+        gb = bank.grad_span(att.query.bias, att.value.bias, (3 * d,)) if bank.is_trainable(att.query.bias) else None
+        if gw is not None:
+            _linear_wgrad(rt, dqkv, x, None, None, M, 3 * d, d, grad_w=gw, grad_b=gb)
+        wqkv = bank.compute_span(att.query.weight, att.value.weight, (3 * d, d))
+        dx = torch.empty(M, d, dtype=dt, device=dev)
+        ops.gemm(dqkv, wqkv, M, d, 3 * d, out=dx, b_mode=KROW, residual=d_a_pre)
+    # ---- embeddings -----------------------------------------------------------------------------------
+    if pk.p_h > 0:
+        dx = ops.dropout(dx, pk.p_h, _seed(_SITE_EMB), rt.seed_dev)
+    emb, vemb = model.embeddings, model.visual_embeddings
+    dpre = torch.empty(M, d, dtype=dt, device=dev)
+    ops.layernorm_bwd(dx, pk.pre, emb.LayerNorm.weight, pk.mean0, pk.rstd0, bank.grad_image(emb.LayerNorm.weight),
+                      bank.grad_image(emb.LayerNorm.bias), dx=dpre, rows=bsz * lt, seg=(lt, L, 0))
+    ops.layernorm_bwd(dx, pk.pre, vemb.LayerNorm.weight, pk.mean0, pk.rstd0, bank.grad_image(vemb.LayerNorm.weight),
+                      bank.grad_image(vemb.LayerNorm.bias), dx=dpre, rows=bsz * lv, seg=(lv, L, lt))
+    we = emb.word_embeddings
+    ops.text_embed_bwd(dpre, pk.ids, bank.grad_image(we.weight), bank.grad_image(emb.position_embeddings.weight),
+                       bank.grad_image(emb.token_type_embeddings.weight)[0], lt, L,
+                       we.padding_idx if we.padding_idx is not None else -1)
+    dgrid = torch.zeros(pk.grid_shape, dtype=torch.float32, device=dev)
+    ops.visual_embed_bwd(dpre, pk.src_row, pk.sel, dgrid, bank.grad_image(vemb.row_position_embeddings.weight),
+                         bank.grad_image(vemb.col_position_embeddings.weight), bank.grad_image(vemb.token_type_embeddings.weight)[0],
+                         bsz, lv, lt, L)
+    if dt == torch.float32:
+        return dgrid
+    return ops.cast(dgrid, torch.empty(pk.grid_shape, dtype=dt, device=dev))
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, grid, model, ids, mask, src_row, pooled_dropout):
+        save = ctx.needs_input_grad[0]
+        ctx.set_materialize_grads(False)
+        seq, pooled, pack = encoder_forward(model, grid, ids, mask, src_row, pooled_dropout, save)
+        ctx.model, ctx.pack = model, pack
+        return seq, pooled
+
+    @staticmethod
+    def backward(ctx, d_seq, d_pooled):
+        dgrid = encoder_backward(ctx.model, ctx.pack, d_seq, d_pooled)
+        ctx.pack = None
+        return None, dgrid, None, None, None, None, None
+
+
+# =================================================================================================
+# heads (small autograd nodes: one consumer each, so autograd never has to add tensors)
+# =================================================================================================
+class _LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b).  ``rows`` = (n_seg, seg_len, seg_stride_rows) selects x rows (b*stride + t)."""
+    @staticmethod
+    def forward(ctx, anchor, x, rt, weight, bias, act, out_f32, rows):
+        bank = rt.bank
+        n, k = weight.shape
+        dev = x.device
+        x2 = x.reshape(-1, k)
+        tab, rowmap = None, None
+        if rows is None:
+            m = x2.shape[0]
+        else:
+            nseg, seglen, segstride = rows
+            m = nseg * seglen
+            tab = rt.table(nseg, 1, seglen, 1, 0, segstride * k, 0, k, dev)
+        out_dt = torch.float32 if out_f32 else rt.dtype
+        ld = (n + 3) // 4 * 4
+        store = torch.empty(m, ld, dtype=out_dt, device=dev)
+        y = store[:, :n]
+        save = ctx.needs_input_grad[0]
+        pre = torch.empty(m, ld, dtype=rt.dtype, device=dev)[:, :n] if (save and act == ACT_GELU) else None
+        w = bank.compute(weight)
+        if tab is None:
+            ops.gemm(x2, w, m, n, k, out=y, shift=bias, act=act, out2=pre)
+        else:
+            ops.gemm(x2, w, m, n, k, out=y, a_mode=ROWK_GATHER, a_tab=tab, lda=0, R=1, S=1, Cin=k, H=1, W=rows[1], sH=0, sW=k,
+                     shift=bias, act=act, out2=pre)
+        ctx.rt, ctx.weight, ctx.bias, ctx.act, ctx.rows = rt, weight, bias, act, rows
+        ctx.x2, ctx.y, ctx.pre, ctx.m, ctx.x_shape = (x2 if save else None), (y if save else None), pre, m, x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rt, weight, bias, act = ctx.rt, ctx.weight, ctx.bias, ctx.act
+        bank, dt = rt.bank, rt.dtype
+        n, k = weight.shape
+        m = ctx.m
+        g = dy
+        if g.dtype != dt or g.stride(1) != 1:
+            g = ops.cast(g.contiguous(), torch.empty(m, n, dtype=dt, device=dy.device))
+        if act == ACT_GELU:
+            g = ops.act_bwd(ACT_GELU, g.contiguous(), ctx.pre.contiguous())
+        elif act != ACT_NONE:
+            g = ops.act_bwd(act, g.contiguous(), ctx.y.contiguous().to(dt))
+        x2 = ctx.x2
+        gw = bank.grad_image(weight)
+        gb = bank.grad_image(bias) if bias is not None else None
+        if ctx.rows is None:
+            if gw is not None:
+                ops.gemm(g, x2, n, k, m, out=gw, a_mode=KROW, lda=g.stride(0), b_mode=KROW, ldb=x2.stride(0), accumulate=True,
+                         split_k=_pick_split(n, k, m))
+            dx = torch.empty(x2.shape, dtype=dt, device=dy.device)
+            ops.gemm(g, bank.compute(weight), m, k, n, out=dx, lda=g.stride(0), b_mode=KROW)
+        else:
+            nseg, seglen, segstride = ctx.rows
+            tab = rt.table(nseg, 1, seglen, 1, 0, segstride * k, 0, k, dy.device)
+            if gw is not None:
+                ops.gemm(g, x2, n, k, m, out=gw, a_mode=KROW, lda=g.stride(0), b_mode=KROW_GATHER, b_tab=tab, ldb=0, R=1, S=1,
+                         Cin=k, H=1, W=seglen, sH=0, sW=k, accumulate=True, split_k=_pick_split(n, k, m))
+            rowmap = rt.strided_rowmap(nseg, 1, segstride, 1, seglen, 1, dy.device)
+            dx = torch.zeros(x2.shape, dtype=dt, device=dy.device)
+            ops.gemm(g, bank.compute(weight), m, k, n, out=dx, lda=g.stride(0), b_mode=KROW, c_rowmap=rowmap)
+        if gb is not None:
+            ops.colsum(g, gb, m, n, ldg=g.stride(0))
+        return None, dx.view(ctx.x_shape), None, None, None, None, None, None
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, x, rt, ln):
+        save = ctx.needs_input_grad[0]
+        xc = x.contiguous()
+        y, mean, rstd = ops.layernorm_fwd(xc, ln.weight, ln.bias, ln.eps, save_stats=save)
+        ctx.rt, ctx.ln, ctx.saved = rt, ln, (xc, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, mean, rstd = ctx.saved
+        bank = ctx.rt.bank
+        dx, _ = ops.layernorm_bwd(dy.contiguous(), xc, ctx.ln.weight, mean, rstd, bank.grad_image(ctx.ln.weight),
+                                  bank.grad_image(ctx.ln.bias))
+        return None, dx, None, None
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    """CrossEntropyLoss(reduction='none', ignore_index=-100) on fp32 logits (rows, C)."""
+    @staticmethod
+    def forward(ctx, logits, labels):
+        loss, _ = ops.cross_entropy(logits, labels)
+        ctx.save_for_backward(logits, labels)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, labels = ctx.saved_tensors
+        _, dlogits = ops.cross_entropy(logits, labels, want_loss=False, dloss=dloss.contiguous(), want_grad=True)
+        return dlogits, None
+
+
+def cross_entropy_none(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    lg = logits if logits.dtype == torch.float32 else logits.float()
+    return _CrossEntropyFn.apply(lg, labels.contiguous())
+
+
+class _ClipBertHead(nn.Module):
+    """Common part of the task models: owns ``bert`` and the runtime."""
+    def __init__(self, config):
+        super().__init__()
+        config = as_config(config)
+        self.config = config
+        self.bert = ClipBertBaseModel(config)
+        self.rt: Optional[Runtime] = None
+
+    def _mlp(self, pooled, seq):
+        rt = self.rt
+        h = _LinearFn.apply(rt.anchor, pooled, rt, seq[0].weight, seq[0].bias, ACT_RELU, False, None)
+        return _LinearFn.apply(rt.anchor, h, rt, seq[2].weight, seq[2].bias, ACT_NONE, True, None)
+
+
+def _make_mlp(d, n_out):
+    return nn.ModuleList([Linear(d, d * 2), nn.Identity(), Linear(d * 2, n_out)])
+
+
+class ClipBertForVideoTextRetrieval(_ClipBertHead):
+    """src/modeling/modeling.py:523-580."""
+    def __init__(self, config):
+        super().__init__(config)
+        self.classifier = _make_mlp(self.config.hidden_size, self.config.num_labels)
+        self.margin = _cfg_get(self.config, "margin", 0.0)
+
+    def forward(self, text_input_ids, visual_inputs, text_input_mask, labels=None, sample_size=-1, src_row=None):
+        _, pooled = self.bert(text_input_ids, visual_inputs, text_input_mask, src_row, pooled_dropout=True)
+        logits = self._mlp(pooled, self.classifier)
+        logits, loss = self.calc_loss(logits, labels, sample_size=sample_size)
+        return dict(logits=logits, loss=loss)
+
+    def calc_loss(self, logits, labels, sample_size=-1):
+        if labels is None:
+            return logits, 0
+        if self.config.loss_type == "ce":
+            loss = cross_entropy_none(logits.view(-1, self.config.num_labels), labels.view(-1))
+        elif self.config.loss_type == "rank":
+            # a handful of scalars (B' values): sigmoid margin ranking, modeling.py:567-575
+            assert sample_size > 0
+            scores = torch.sigmoid(logits).squeeze().contiguous().view(sample_size, -1)
+            loss = torch.clamp(self.margin + scores[:, 1:] - scores[:, :1], min=0)
+        else:
+            raise ValueError("Invalid option for config.loss_type")
+        return logits, loss
+
+
+class ClipBertForMultipleChoice(_ClipBertHead):
+    """src/modeling/modeling.py:387-451."""
+    def __init__(self, config):
+        super().__init__(config)
+        self.classifier = _make_mlp(self.config.hidden_size, 1)
+
+    def forward(self, text_input_ids, visual_inputs, text_input_mask, labels=None, src_row=None):
+        _, pooled = self.bert(text_input_ids, visual_inputs, text_input_mask, src_row, pooled_dropout=True)
+        logits = self._mlp(pooled, self.classifier)
+        logits, loss = self.calc_loss(logits, labels)
+        return dict(logits=logits, loss=loss)
+
+    def calc_loss(self, logits, labels):
+        if self.config.loss_type == "ce":
+            logits = logits.reshape(-1, self.config.num_labels)
+        if labels is None:
+            return logits, 0
+        if self.config.num_labels == 1:
+            loss = (logits.view(-1) - labels.view(-1)) ** 2
+        elif self.config.loss_type == "bce":
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, labels, reduction="none")
+        elif self.config.loss_type == "ce":
+            loss = cross_entropy_none(logits.contiguous(), labels.view(-1))
+        else:
+            raise ValueError("Invalid option for config.loss_type")
+        return logits, loss
+
+
+class ClipBertForSequenceClassification(_ClipBertHead):
+    """src/modeling/modeling.py:327-384."""
+    def __init__(self, config):
+        super().__init__(config)
+        self.classifier = _make_mlp(self.config.hidden_size, self.config.num_labels)
+
+    def forward(self, text_input_ids, visual_inputs, text_input_mask, labels=None, src_row=None):
+        _, pooled = self.bert(text_input_ids, visual_inputs, text_input_mask, src_row, pooled_dropout=True)
+        logits = self._mlp(pooled, self.classifier)
+        logits, loss = self.calc_loss(logits, labels)
+        return dict(logits=logits, loss=loss)
+
+    def calc_loss(self, logits, labels):
+        if labels is None:
+            return logits, 0
+        if self.config.num_labels == 1:
+            loss = (logits.view(-1) - labels.view(-1)) ** 2
+        elif self.config.loss_type == "bce":
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, labels, reduction="none")
+        elif self.config.loss_type == "ce":
+            loss = cross_entropy_none(logits.view(-1, self.config.num_labels), labels.view(-1))
+        else:
+            raise ValueError("Invalid option for config.loss_type")
+        return logits, loss
+
+
+class _PredictionHeadTransform(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = LayerNorm(config.hidden_size, config.layer_norm_eps)
+
+
+class _Decoder(nn.Module):
+    def __init__(self, weight, bias):
+        super().__init__()
+        self.weight = weight          # tied to bert.embeddings.word_embeddings.weight
+        self.bias = bias              # same Parameter as predictions.bias (transformers.py:507-510)
+
+
+class _LMPredictionHead(nn.Module):
+    def __init__(self, config, word_weight):
+        super().__init__()
+        self.transform = _PredictionHeadTransform(config)
+        self.bias = nn.Parameter(torch.zeros(config.vocab_size))
+        self.decoder = _Decoder(word_weight, self.bias)
+
+
+class _PreTrainingHeads(nn.Module):
+    def __init__(self, config, word_weight):
+        super().__init__()
+        self.predictions = _LMPredictionHead(config, word_weight)
+        self.seq_relationship = Linear(config.hidden_size, 2)
+
+
+class ClipBertForPreTraining(_ClipBertHead):
+    """src/modeling/modeling.py:241-307 with BertPreTrainingHeads (transformers.py:479-547)."""
+    def __init__(self, config):
+        super().__init__(config)
+        self.cls = _PreTrainingHeads(self.config, self.bert.embeddings.word_embeddings.weight)
+
+    def get_output_embeddings(self):
+        return self.cls.predictions.decoder
+
+    def forward(self, text_input_ids, visual_inputs, text_input_mask, mlm_labels=None, itm_labels=None, src_row=None):
+        rt = self.rt
+        seq, pooled = self.bert(text_input_ids, visual_inputs, text_input_mask, src_row)
+        b, L, d = seq.shape
+        lt = text_input_mask.shape[1]
+        pred = self.cls.predictions
+        # heads on the TEXT rows only (modeling.py:283-285): gathered inside the GEMM loader
+        h = _LinearFn.apply(rt.anchor, seq, rt, pred.transform.dense.weight, pred.transform.dense.bias, ACT_GELU, False,
+                            (b, lt, L))
+        h = _LayerNormFn.apply(rt.anchor, h, rt, pred.transform.LayerNorm)
+        scores = _LinearFn.apply(rt.anchor, h, rt, pred.decoder.weight, pred.bias, ACT_NONE, True, None)
+        rel = self.cls.seq_relationship
+        itm = _LinearFn.apply(rt.anchor, pooled, rt, rel.weight, rel.bias, ACT_NONE, True, None)
+        v = self.config.vocab_size
+        mlm_loss = cross_entropy_none(scores, mlm_labels.view(-1)) if mlm_labels is not None else 0
+        itm_loss = cross_entropy_none(itm.view(-1, 2), itm_labels.view(-1)) if itm_labels is not None else 0
+        return dict(mlm_scores=scores.view(b, lt, v), mlm_loss=mlm_loss, mlm_labels=mlm_labels, itm_scores=itm,
+                    itm_loss=itm_loss, itm_labels=itm_labels)
+
+
+# =================================================================================================
+# end-to-end wrapper
+# =================================================================================================
+class ClipBert(nn.Module):
+    """src/modeling/e2e_model.py:14-50."""
+    def __init__(self, config, input_format="BGR", detectron2_model_cfg=None, transformer_cls=ClipBertForPreTraining):
+        super().__init__()
+        config = as_config(config)
+        self.config = config
+        self.detectron2_model_cfg = detectron2_model_cfg
+        self.cnn = GridFeatBackbone(detectron2_model_cfg=detectron2_model_cfg, config=config, input_format=input_format)
+        self.transformer = transformer_cls(config)
+        self.retrieval = transformer_cls == ClipBertForVideoTextRetrieval
+        self.rt: Optional[Runtime] = None
+        self._src_cache = {}
+
+    # ---- MI355X runtime --------------------------------------------------------------------------------
+    def prepare(self, dtype=torch.bfloat16, device=None, transformer_lr_mul_prefix="", cnn_lr_mul_prefix="grid_encoder"):
+        """Move parameters into the flat HBM buffers and build compute copies.  Call after loading
+        weights / changing requires_grad (freeze_cnn_backbone) and before the first forward."""
+        device = torch.device(device) if device is not None else next(self.parameters()).device
+        for buf_owner in self.modules():
+            if isinstance(buf_owner, FrozenBatchNorm2d):
+                buf_owner.to(device)
+        rt = Runtime()
+        rt.dtype = dtype
+        rt.bank = ParamBank(self, device, dtype, transformer_lr_mul_prefix, cnn_lr_mul_prefix)
+        rt.seed_dev = torch.zeros(1, dtype=torch.int64, device=device)
+        rt.anchor = torch.zeros(1, dtype=torch.float32, device=device, requires_grad=True)
+        for m in self.modules():
+            if hasattr(m, "rt"):
+                m.rt = rt
+            if isinstance(m, (Conv2d,)):
+                m._ss = None
+        return self
+
+    def _ensure_prepared(self, device):
+        if self.rt is None:
+            self.prepare(device=device)
+
+    def forward(self, batch):
+        repeat_counts = batch["n_examples_list"]
+        del batch["n_examples_list"]
+        vis = batch["visual_inputs"]
+        self._ensure_prepared(vis.device)
+        visual_features = self.cnn(vis)
+        batch["visual_inputs"] = visual_features
+        # repeat_tensor_rows (data_utils.py:344-357) is fused into the visual-embedding gather
+        src_row = None
+        if sum(repeat_counts) != len(repeat_counts):
+            key = (tuple(repeat_counts), str(vis.device))
+            src_row = self._src_cache.get(key)
+            if src_row is None:
+                src_row = torch.tensor([i for i, r in enumerate(repeat_counts) for _ in range(r)], dtype=torch.int32,
+                                       device=vis.device)
+                self._src_cache[key] = src_row
+        if self.retrieval:
+            batch["sample_size"] = len(repeat_counts)
+        return self.transformer(src_row=src_row, **batch)
+
+    def load_separate_ckpt(self, cnn_weights_path=None, bert_weights_path=None):
+        if cnn_weights_path:
+            sd = torch.load(cnn_weights_path, map_location="cpu")
+            sd = sd.get("model", sd)
+            self.cnn.feature.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=False)
+        if bert_weights_path:
+            sd = torch.load(bert_weights_path, map_location="cpu")
+            load_state_dict_with_mismatch(self.transformer, sd)
+        self.rt = None
+
+    def freeze_cnn_backbone(self):
+        for _n, p in self.cnn.feature.named_parameters():
+            p.requires_grad = False
+        self.rt = None
+
+
+def load_state_dict_with_mismatch(model: nn.Module, loaded_state_dict):
+    """Key/shape tolerant load (src/utils/load_save.py:71-100): drops shape-mismatched and unknown keys
+    (e.g. the reference checkpoint's dead RPN/ROI-head weights), loads the rest non-strictly."""
+    own = model.state_dict()
+    ok = {k: v for k, v in loaded_state_dict.items() if k in own and tuple(own[k].shape) == tuple(v.shape)}
+    return model.load_state_dict(ok, strict=False)

@@ -96,11 +96,11 @@ def _f3(vals):
     return (C.c_float * 3)(*[float(v) for v in vals])
 
 
-def stem_pack(src: torch.Tensor, dtype: torch.dtype, pad: int = 3, mean=None, std=None) -> torch.Tensor:
-    """(N,3,H,W) fp32 (already normalised) or uint8 (+mean/std) -> (N, H+2*pad, W+2*pad, 4) zero-padded BGR0."""
+def stem_pack(src: torch.Tensor, dtype: torch.dtype, pad: int = 3, mean=None, std=None, extra_w: int = 0) -> torch.Tensor:
+    """(N,3,H,W) fp32 (already normalised) or uint8 (+mean/std) -> (N, H+2*pad, W+2*pad+extra_w, 4) zero-padded BGR0."""
     n, c, h, w = src.shape
     assert c == 3 and src.is_contiguous()
-    hp, wp = h + 2 * pad, w + 2 * pad
+    hp, wp = h + 2 * pad, w + 2 * pad + extra_w
     dst = torch.empty(n, hp, wp, 4, dtype=dtype, device=src.device)
     u8 = src.dtype == torch.uint8
     assert u8 or src.dtype == torch.float32

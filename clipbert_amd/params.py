@@ -1,0 +1,176 @@
+"""Flat parameter storage for the MI355X path.
+
+All trainable parameters live in ONE fp32 master buffer laid out group-by-group in the reference's
+8 optimizer groups (src/optimization/utils.py:96-161), with a parallel fp32 gradient buffer, two
+AdamW state buffers and -- in bf16 mode -- a bf16 compute copy that the fused AdamW kernel rewrites
+in the same pass.  ``nn.Parameter.data`` / ``.grad`` are views into these buffers, so
+
+* the optimizer is a handful of kernel launches over contiguous ranges (no per-tensor loop),
+* gradient all-reduce works on large contiguous slices (buckets) of one buffer,
+* conv weights keep the reference's logical OIHW shape (state-dict compatible) but a channels_last
+  memory image = KRSC, which is exactly what the implicit-GEMM kernels read,
+* query/key/value weights (and biases) are adjacent, so the fused QKV GEMM reads them as one
+  [3*hidden, hidden] matrix without any copy.
+
+Frozen parameters and FrozenBN buffers get a compute copy once (``sync_compute``).
+"""
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+
+NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight")     # src/optimization/utils.py:134
+N_GROUPS = 8
+
+
+def group_of(name: str, transformer_lr_mul_prefix: str = "", cnn_lr_mul_prefix: str = "grid_encoder") -> int:
+    """Index into the reference's param-group list: transformer {top decay, top no-decay, rest decay,
+    rest no-decay} then the same four for the cnn (run_video_retrieval.py:455-467 indexes them so)."""
+    if "transformer" in name:
+        base, pre = 0, transformer_lr_mul_prefix
+    elif "cnn" in name:
+        base, pre = 4, cnn_lr_mul_prefix
+    else:
+        raise ValueError(f"parameter {name!r} belongs to neither 'transformer' nor 'cnn'")
+    top = 0 if (pre != "" and pre in name) else 2
+    nd = 1 if any(t in name for t in NO_DECAY) else 0
+    return base + top + nd
+
+
+def _physical(t: torch.Tensor) -> torch.Tensor:
+    """1-D view of the memory image of a dense tensor (contiguous or channels_last)."""
+    if t.dim() == 4:
+        return t.permute(0, 2, 3, 1).reshape(-1)       # KRSC image of an OIHW tensor
+    return t.reshape(-1)
+
+
+class ParamBank:
+    ALIGN = 64          # elements; keeps every parameter 256-byte aligned in fp32 and 128-byte in bf16
+
+    def __init__(self, root: nn.Module, device, compute_dtype: torch.dtype, transformer_lr_mul_prefix: str = "",
+                 cnn_lr_mul_prefix: str = "grid_encoder", name_prefix: str = ""):
+        assert compute_dtype in (torch.bfloat16, torch.float32)
+        self.device = torch.device(device)
+        self.compute_dtype = compute_dtype
+        named = []
+        seen = {}
+        for name, p in root.named_parameters(remove_duplicate=False):
+            if id(p) in seen:               # tied weights (MLM decoder <-> word embeddings, decoder.bias)
+                continue
+            seen[id(p)] = name
+            named.append((name_prefix + name, p))
+        self.names: Dict[int, str] = {id(p): n for n, p in named}
+        trainable = [(n, p) for n, p in named if p.requires_grad]
+        frozen = [(n, p) for n, p in named if not p.requires_grad]
+        groups: List[List] = [[] for _ in range(N_GROUPS)]
+        for n, p in trainable:
+            groups[group_of(n, transformer_lr_mul_prefix, cnn_lr_mul_prefix)].append((n, p))
+        self.offset: Dict[int, int] = {}
+        self.group_range: List[tuple] = []
+        off = 0
+        for g in groups:
+            start = off
+            for _n, p in g:
+                self.offset[id(p)] = off
+                off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            self.group_range.append((start, off))
+        self.n_train = off
+        dev = self.device
+        self.master = torch.zeros(max(off, 1), dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(max(off, 1), dtype=torch.float32, device=dev)
+        self.exp_avg: Optional[torch.Tensor] = None
+        self.exp_avg_sq: Optional[torch.Tensor] = None
+        self.w16 = torch.zeros(max(off, 1), dtype=torch.bfloat16, device=dev) if compute_dtype == torch.bfloat16 else None
+        self._trainable = trainable
+        for _n, p in trainable:
+            self._rebind(p, self.master, self.offset[id(p)], grad=True)
+        # frozen parameters: own flat fp32 + compute copy
+        foff = 0
+        self.f_offset: Dict[int, int] = {}
+        for _n, p in frozen:
+            self.f_offset[id(p)] = foff
+            foff += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.f_master = torch.zeros(max(foff, 1), dtype=torch.float32, device=dev)
+        self.f_w16 = torch.zeros(max(foff, 1), dtype=torch.bfloat16, device=dev) if compute_dtype == torch.bfloat16 else None
+        for _n, p in frozen:
+            self._rebind(p, self.f_master, self.f_offset[id(p)], grad=False)
+        self.sync_compute()
+
+    def _view(self, flat: torch.Tensor, off: int, like: torch.Tensor) -> torch.Tensor:
+        n = like.numel()
+        if like.dim() == 4:
+            o, i, r, s = like.shape
+            return flat[off:off + n].view(o, r, s, i).permute(0, 3, 1, 2)     # logical OIHW, memory KRSC
+        return flat[off:off + n].view(like.shape)
+
+    def _rebind(self, p: nn.Parameter, flat: torch.Tensor, off: int, grad: bool):
+        v = self._view(flat, off, p)
+        v.copy_(p.data.to(self.device))
+        p.data = v
+        if grad:
+            p.grad = self._view(self.grad, off, p)
+
+    # ---- accessors used by the forward/backward code --------------------------------------------
+    def compute(self, p: nn.Parameter) -> torch.Tensor:
+        """Compute-dtype tensor with the parameter's MEMORY image: 4-D -> (O, R, S, I), else its shape."""
+        key = id(p)
+        if key in self.offset:
+            flat, off = (self.w16 if self.w16 is not None else self.master), self.offset[key]
+        else:
+            flat, off = (self.f_w16 if self.f_w16 is not None else self.f_master), self.f_offset[key]
+        n = p.numel()
+        if p.dim() == 4:
+            o, i, r, s = p.shape
+            return flat[off:off + n].view(o, r, s, i)
+        return flat[off:off + n].view(p.shape)
+
+    def compute_span(self, first: nn.Parameter, last: nn.Parameter, shape) -> torch.Tensor:
+        """One tensor over several ADJACENT parameters (fused QKV)."""
+        flat = self.w16 if self.w16 is not None else self.master
+        a, b = self.offset[id(first)], self.offset[id(last)] + last.numel()
+        t = flat[a:b]
+        assert t.numel() == int(torch.Size(shape).numel()), "parameters are not adjacent in the flat buffer"
+        return t.view(shape)
+
+    def master_span(self, first: nn.Parameter, last: nn.Parameter, shape) -> torch.Tensor:
+        """fp32 master view over adjacent parameters (fused QKV bias, read by the GEMM epilogue)."""
+        a, b = self.offset[id(first)], self.offset[id(last)] + last.numel()
+        t = self.master[a:b]
+        assert t.numel() == int(torch.Size(shape).numel()), "parameters are not adjacent in the flat buffer"
+        return t.view(shape)
+
+    def grad_image(self, p: nn.Parameter) -> torch.Tensor:
+        """fp32 gradient in the parameter's memory image (see ``compute``); None if frozen."""
+        key = id(p)
+        if key not in self.offset:
+            return None
+        off, n = self.offset[key], p.numel()
+        if p.dim() == 4:
+            o, i, r, s = p.shape
+            return self.grad[off:off + n].view(o, r, s, i)
+        return self.grad[off:off + n].view(p.shape)
+
+    def grad_span(self, first: nn.Parameter, last: nn.Parameter, shape) -> torch.Tensor:
+        a, b = self.offset[id(first)], self.offset[id(last)] + last.numel()
+        return self.grad[a:b].view(shape)
+
+    def is_trainable(self, p: nn.Parameter) -> bool:
+        return id(p) in self.offset
+
+    # ---- maintenance -----------------------------------------------------------------------------
+    def sync_compute(self):
+        """Refresh the bf16 compute copies from the fp32 masters (after loading / editing weights)."""
+        if self.w16 is not None and self.n_train > 0:
+            ops.cast(self.master, self.w16)
+        if self.f_w16 is not None:
+            ops.cast(self.f_master, self.f_w16)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def ensure_state(self):
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.master)
+            self.exp_avg_sq = torch.zeros_like(self.master)

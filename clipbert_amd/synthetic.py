@@ -138,12 +138,12 @@ def synthetic_frames(n_videos: int, n_frames: int, size: int, seed: int = 42) ->
 def synthetic_text(n_pairs: int, max_len: int, seed: int = 42, vocab: int = 30522):
     """ids (n, L) int64 and mask (n, L) int64."""
     g = _gen(seed, "text")
-    ids = torch.randint(1000, vocab, (n_pairs, max_len), generator=g, dtype=torch.long)
+    ids = torch.randint(min(1000, vocab // 2), vocab, (n_pairs, max_len), generator=g, dtype=torch.long)
     lo = min(8, max_len)
     sep = torch.randint(lo - 1, max_len, (n_pairs,), generator=g, dtype=torch.long)
     pos = torch.arange(max_len).unsqueeze(0)
-    ids[:, 0] = 101
-    ids[pos == sep.unsqueeze(1)] = 102
+    ids[:, 0] = min(101, vocab - 2)
+    ids[pos == sep.unsqueeze(1)] = min(102, vocab - 1)
     mask = (pos <= sep.unsqueeze(1)).long()
     return ids * mask, mask
 

@@ -172,6 +172,7 @@ class Runtime:
         self.seed_dev: Optional[torch.Tensor] = None     # device int64 added to every dropout seed
         self.anchor: Optional[torch.Tensor] = None       # requires_grad leaf that keeps the coarse nodes alive
         self.stem_w = None
+        self.after_encoder_backward = None               # hook: launch the transformer-bucket all-reduce
 
     def table(self, n, oh, ow, stride, pad, sN, sH, sW, device):
         key = (n, oh, ow, stride, pad, sN, sH, sW, str(device))
@@ -704,6 +705,9 @@ class _EncoderFn(torch.autograd.Function):
     def backward(ctx, d_seq, d_pooled):
         dgrid = encoder_backward(ctx.model, ctx.pack, d_seq, d_pooled)
         ctx.pack = None
+        hook = ctx.model.rt.after_encoder_backward
+        if hook is not None:
+            hook()
         return None, dgrid, None, None, None, None, None
 
 

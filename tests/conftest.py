@@ -40,3 +40,25 @@ def emul(emul_lib, monkeypatch):
     monkeypatch.setattr(_lib, "_LIB", emul_lib)
     monkeypatch.setattr(ops, "_ALLOW_HOST_POINTERS", True)
     return emul_lib
+
+
+class _HW:
+    def __init__(self, name, dev):
+        self.name, self.dev = name, dev
+
+    def __call__(self, t):
+        """move a tensor (or None) to the backend's device"""
+        return None if t is None else t.to(self.dev)
+
+
+@pytest.fixture(params=["emul", pytest.param("gpu", marks=pytest.mark.gpu)])
+def hw(request, monkeypatch):
+    """Backend under test: the host lane-level emulator build (CPU tensors) or the real library on cuda:0."""
+    import torch
+    if request.param == "emul":
+        lib = request.getfixturevalue("emul_lib")
+        from clipbert_amd import _lib, ops
+        monkeypatch.setattr(_lib, "_LIB", lib)
+        monkeypatch.setattr(ops, "_ALLOW_HOST_POINTERS", True)
+        return _HW("emul", torch.device("cpu"))
+    return _HW("gpu", torch.device("cuda", 0))

@@ -1,0 +1,52 @@
+"""The C-ABI library builds for gfx950, loads on a GPU-less host and exports every symbol that
+include/clipbert_hip.h declares; the product loader has no fallback."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from clipbert_amd import _lib, build
+    path = build.build()
+    lib = ctypes.CDLL(path)
+    header = open(os.path.join(ROOT, "include", "clipbert_hip.h")).read()
+    declared = set(re.findall(r"\b(cb_[a-z0-9_]+)\s*\(", header))
+    declared -= {"cb_gemm_desc"}
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.cb_version() >= 1
+
+
+def test_gemm_desc_layout_matches_header():
+    """ctypes mirror vs a struct compiled from the header itself."""
+    import subprocess
+    import tempfile
+    from clipbert_amd import _lib
+    src = '#include "clipbert_hip.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%zu %zu %zu %zu %zu", sizeof(cb_gemm_desc), ' \
+          'offsetof(cb_gemm_desc, C), offsetof(cb_gemm_desc, dropout_seed_ptr), offsetof(cb_gemm_desc, tile), sizeof(cb_pixel));return 0;}'
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        size, off_c, off_seed, off_tile, px = map(int, subprocess.check_output([exe]).split())
+    G = _lib.GemmDesc
+    assert (ctypes.sizeof(G), G.C.offset, G.dropout_seed_ptr.offset, G.tile.offset, px) == (size, off_c, off_seed, off_tile, 8)
+
+
+def test_product_loader_has_no_fallback(tmp_path):
+    from clipbert_amd import _lib
+    with pytest.raises(RuntimeError, match="no fallback"):
+        _lib.load(str(tmp_path / "missing.so"))
+
+
+def test_ops_refuse_cpu_tensors_on_the_product_path():
+    import torch
+    from clipbert_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.cast(torch.zeros(4), torch.zeros(4, dtype=torch.bfloat16))

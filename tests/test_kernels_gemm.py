@@ -1,5 +1,6 @@
-"""GEMM / implicit-GEMM convolution kernels (clipbert_amd/csrc/gemm.hip) executed on the host lane-level
-emulator and compared with plain PyTorch fp32 references of the same op (forward, dgrad, wgrad)."""
+"""GEMM / implicit-GEMM convolution kernels (clipbert_amd/csrc/gemm.hip) against plain PyTorch fp32
+references of the same op (forward, dgrad, wgrad).  Every case runs twice: on the host lane-level emulator
+build (CPU suite) and, marked `gpu`, through the real libclipbert_hip.so on an MI355X."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -20,13 +21,13 @@ def rnd(*shape, seed=0, scale=1.0):
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M,N,K,tile", [(100, 72, 96, 2), (130, 136, 64, 1), (5, 2, 8, 0), (33, 37, 40, 2)])
-def test_linear_forward_epilogues(emul, dt, M, N, K, tile):
+def test_linear_forward_epilogues(hw, dt, M, N, K, tile):
     if dt == torch.float32 and tile == 1:
         tile = 0
-    x, w, b = rnd(M, K, seed=1).to(dt), rnd(N, K, seed=2, scale=0.2).to(dt), rnd(N, seed=3)
-    res = rnd(M, N, seed=4).to(dt)
-    out = torch.empty(M, N, dtype=dt)
-    pre = torch.empty(M, N, dtype=dt)
+    x, w, b = hw(rnd(M, K, seed=1).to(dt)), hw(rnd(N, K, seed=2, scale=0.2).to(dt)), hw(rnd(N, seed=3))
+    res = hw(rnd(M, N, seed=4).to(dt))
+    out = torch.empty(M, N, dtype=dt, device=hw.dev)
+    pre = torch.empty(M, N, dtype=dt, device=hw.dev)
     ops.gemm(x, w, M, N, K, out=out, shift=b, act=ops.ACT_GELU, residual=res, out2=pre, tile=tile)
     ref_pre = x.float() @ w.float().t() + b
     ref = F.gelu(ref_pre) + res.float()
@@ -35,21 +36,21 @@ def test_linear_forward_epilogues(emul, dt, M, N, K, tile):
 
 
 @pytest.mark.parametrize("dt", DT)
-def test_linear_dgrad_wgrad(emul, dt):
+def test_linear_dgrad_wgrad(hw, dt):
     M, N, K = 70, 48, 64
-    x, w, g = rnd(M, K, seed=1).to(dt), rnd(N, K, seed=2, scale=0.2).to(dt), rnd(M, N, seed=3).to(dt)
-    dx = torch.empty(M, K, dtype=dt)
+    x, w, g = hw(rnd(M, K, seed=1).to(dt)), hw(rnd(N, K, seed=2, scale=0.2).to(dt)), hw(rnd(M, N, seed=3).to(dt))
+    dx = torch.empty(M, K, dtype=dt, device=hw.dev)
     ops.gemm(g, w, M, K, N, out=dx, b_mode=ops.KROW)                      # dX = g W
     torch.testing.assert_close(dx.float(), g.float() @ w.float(), **tol(dt))
-    dw = torch.zeros(N, K, dtype=torch.float32)
+    dw = torch.zeros(N, K, dtype=torch.float32, device=hw.dev)
     ops.gemm(g, x, N, K, M, out=dw, a_mode=ops.KROW, b_mode=ops.KROW, accumulate=True, split_k=3)   # dW = g^T x
     torch.testing.assert_close(dw, g.float().t() @ x.float(), **tol(dt))
     # tiny / unaligned head shapes (num_labels = 2): scalar guarded loaders
-    g2, w2 = rnd(M, 2, seed=5).to(dt), rnd(2, K, seed=6).to(dt)
-    dx2 = torch.empty(M, K, dtype=dt)
+    g2, w2 = hw(rnd(M, 2, seed=5).to(dt)), hw(rnd(2, K, seed=6).to(dt))
+    dx2 = torch.empty(M, K, dtype=dt, device=hw.dev)
     ops.gemm(g2, w2, M, K, 2, out=dx2, b_mode=ops.KROW)
     torch.testing.assert_close(dx2.float(), g2.float() @ w2.float(), **tol(dt))
-    dw2 = torch.empty(2, K, dtype=torch.float32)
+    dw2 = torch.empty(2, K, dtype=torch.float32, device=hw.dev)
     ops.gemm(g2, x, 2, K, M, out=dw2, a_mode=ops.KROW, b_mode=ops.KROW)
     torch.testing.assert_close(dw2, g2.float().t() @ x.float(), **tol(dt))
 
@@ -60,18 +61,18 @@ def _nhwc(x):
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("k,stride,pad,H,W,Cin,Cout", [(3, 1, 1, 7, 9, 32, 64), (1, 2, 0, 8, 6, 64, 40), (1, 1, 0, 5, 5, 32, 64)])
-def test_conv_forward_backward(emul, dt, k, stride, pad, H, W, Cin, Cout):
+def test_conv_forward_backward(hw, dt, k, stride, pad, H, W, Cin, Cout):
     n = 2
-    x = rnd(n, Cin, H, W, seed=1).to(dt)
-    w = rnd(Cout, Cin, k, k, seed=2, scale=0.1).to(dt)
-    scale, shift = rnd(Cout, seed=3).abs() + 0.5, rnd(Cout, seed=4)
+    x = hw(rnd(n, Cin, H, W, seed=1).to(dt))
+    w = hw(rnd(Cout, Cin, k, k, seed=2, scale=0.1).to(dt))
+    scale, shift = hw(rnd(Cout, seed=3).abs() + 0.5), hw(rnd(Cout, seed=4))
     OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     xh = _nhwc(x)                                        # (n, H, W, Cin)
     wk = w.permute(0, 2, 3, 1).contiguous()              # KRSC
     M = n * OH * OW
     tab = ops.build_pixel_table(n, OH, OW, stride, pad, H * W * Cin, W * Cin, Cin, x.device)
-    res = rnd(M, Cout, seed=5).to(dt)
-    y = torch.empty(M, Cout, dtype=dt)
+    res = hw(rnd(M, Cout, seed=5).to(dt))
+    y = torch.empty(M, Cout, dtype=dt, device=hw.dev)
     ops.gemm(xh, wk, M, Cout, k * k * Cin, out=y, a_mode=ops.ROWK_GATHER, a_tab=tab, lda=0, ldb=k * k * Cin,
              R=k, S=k, Cin=Cin, H=H, W=W, sH=W * Cin, sW=Cin, scale=scale, shift=shift, residual=res, relu_after=True)
     xr = x.float().requires_grad_(True)
@@ -81,11 +82,11 @@ def test_conv_forward_backward(emul, dt, k, stride, pad, H, W, Cin, Cout):
     torch.testing.assert_close(y.float().view(n, OH, OW, Cout), ref.permute(0, 2, 3, 1), **tol(dt))
 
     # backward of the bare convolution for an upstream gradient g (already scaled/masked)
-    g = rnd(n, Cout, OH, OW, seed=6).to(dt)
+    g = hw(rnd(n, Cout, OH, OW, seed=6).to(dt))
     conv.backward(g.float())
     gh = _nhwc(g).view(M, Cout)
     # dgrad: transposed conv = gather over g with flipped taps (stride 1), or scatter (1x1 strided)
-    dx = torch.zeros(n * H * W, Cin, dtype=dt)
+    dx = torch.zeros(n * H * W, Cin, dtype=dt, device=hw.dev)
     if stride == 1:
         tab_in = ops.build_pixel_table(n, H, W, 1, k - 1 - pad, OH * OW * Cout, OW * Cout, Cout, x.device)
         ops.gemm(gh, wk, n * H * W, Cin, k * k * Cout, out=dx, a_mode=ops.ROWK_GATHER, a_tab=tab_in, lda=0,
@@ -93,21 +94,21 @@ def test_conv_forward_backward(emul, dt, k, stride, pad, H, W, Cin, Cout):
                  flip_taps=True)
     else:
         rowmap = (torch.arange(n).view(n, 1, 1) * H * W + (torch.arange(OH) * stride).view(1, OH, 1) * W
-                  + (torch.arange(OW) * stride).view(1, 1, OW)).reshape(-1).int()
+                  + (torch.arange(OW) * stride).view(1, 1, OW)).reshape(-1).int().to(hw.dev)
         ops.gemm(gh, wk, M, Cin, Cout, out=dx, b_mode=ops.KROW_TAPS, ldb=Cin, R=1, S=1, Cin=Cout, c_rowmap=rowmap)
     torch.testing.assert_close(dx.float().view(n, H, W, Cin), xr.grad.permute(0, 2, 3, 1), **tol(dt))
     # wgrad: dW[co][(r,s,c)] = sum_m g[m,co] X[pix(m,r,s), c], split over the pixel reduction
-    dw = torch.zeros(Cout, k * k * Cin, dtype=torch.float32)
+    dw = torch.zeros(Cout, k * k * Cin, dtype=torch.float32, device=hw.dev)
     ops.gemm(gh, xh, Cout, k * k * Cin, M, out=dw, a_mode=ops.KROW, lda=Cout, b_mode=ops.KROW_GATHER, b_tab=tab,
              ldb=0, R=k, S=k, Cin=Cin, H=H, W=W, sH=W * Cin, sW=Cin, accumulate=True, split_k=2)
     torch.testing.assert_close(dw.view(Cout, k, k, Cin), wr.grad.permute(0, 2, 3, 1), **tol(dt))
 
 
-def test_dropout_epilogue_is_consistent_and_unbiased(emul):
+def test_dropout_epilogue_is_consistent_and_unbiased(hw):
     M, N, K = 64, 64, 32
-    x, w = torch.ones(M, K), torch.ones(N, K) / K
-    a = torch.empty(M, N)
-    b = torch.empty(M, N)
+    x, w = torch.ones(M, K, device=hw.dev), torch.ones(N, K, device=hw.dev) / K
+    a = torch.empty(M, N, device=hw.dev)
+    b = torch.empty(M, N, device=hw.dev)
     ops.gemm(x, w, M, N, K, out=a, dropout_p=0.25, dropout_seed=7)
     ops.gemm(x, w, M, N, K, out=b, dropout_p=0.25, dropout_seed=7)
     assert torch.equal(a, b)

@@ -1,5 +1,6 @@
-"""Every non-GEMM kernel of libclipbert_hip executed on the host lane-level emulator against plain
-PyTorch fp32 references (and the oracle's AdamW restatement)."""
+"""Every non-GEMM kernel of libclipbert_hip against plain PyTorch fp32 references (and the oracle's AdamW
+restatement).  Each case runs on the host lane-level emulator build (CPU suite) and, marked `gpu`, on the
+real library on an MI355X."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -14,13 +15,31 @@ def tol(dt, f32=1e-5, bf=2e-2):
     return dict(rtol=bf, atol=bf) if dt == torch.bfloat16 else dict(rtol=f32 * 10, atol=f32)
 
 
+DEV = [torch.device("cpu")]
+
+
+@pytest.fixture(autouse=True)
+def _device(hw):
+    DEV[0] = hw.dev
+    yield
+    DEV[0] = torch.device("cpu")
+
+
 def rnd(*shape, seed=0, scale=1.0):
-    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale).to(DEV[0])
+
+
+def zeros(*shape, dtype=torch.float32):
+    return torch.zeros(*shape, dtype=dtype, device=DEV[0])
+
+
+def ones(*shape, dtype=torch.float32):
+    return torch.ones(*shape, dtype=dtype, device=DEV[0])
 
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("D", [768, 64, 1280])
-def test_layernorm_fwd_bwd(emul, dt, D):
+def test_layernorm_fwd_bwd(hw, dt, D):
     rows = 37
     x = rnd(rows, D, seed=1).to(dt)
     g, b = 1 + rnd(D, seed=2, scale=0.1), rnd(D, seed=3, scale=0.1)
@@ -31,7 +50,7 @@ def test_layernorm_fwd_bwd(emul, dt, D):
     torch.testing.assert_close(y.float(), ref, **tol(dt))
     dy = rnd(rows, D, seed=4).to(dt)
     ref.backward(dy.float())
-    dgam, dbet = torch.zeros(D), torch.zeros(D)
+    dgam, dbet = zeros(D), zeros(D)
     dx, _ = ops.layernorm_bwd(dy, x, g, mean, rstd, dgam, dbet)
     torch.testing.assert_close(dx.float(), xr.grad, **tol(dt, 1e-4))
     torch.testing.assert_close(dgam, gr.grad, **tol(dt, 1e-4, 5e-2))
@@ -39,19 +58,19 @@ def test_layernorm_fwd_bwd(emul, dt, D):
 
 
 @pytest.mark.parametrize("dt", DT)
-def test_embeddings_fwd_bwd(emul, dt):
+def test_embeddings_fwd_bwd(hw, dt):
     B, Lt, Hg, Wg, T, D, V = 4, 6, 2, 3, 2, 128, 50
     Lv = Hg * Wg
     L = Lt + Lv
-    ids = torch.randint(0, V, (B, Lt), generator=torch.Generator().manual_seed(1))
+    ids = torch.randint(0, V, (B, Lt), generator=torch.Generator().manual_seed(1)).to(DEV[0])
     ids[0, -1] = 0
     tabs = {k: rnd(n, D, seed=i).to(dt) for i, (k, n) in enumerate(dict(word=V, pos=16, typ=2, row=5, col=5, vtyp=1).items())}
     g1, b1, g2, b2 = 1 + rnd(D, seed=7, scale=0.1), rnd(D, seed=8, scale=0.1), 1 + rnd(D, seed=9, scale=0.1), rnd(D, seed=10, scale=0.1)
     grid = rnd(2, T, Hg, Wg, D, seed=11).to(dt)
-    src_row = torch.tensor([0, 0, 1, 1], dtype=torch.int32)
-    out = torch.zeros(B * L, D, dtype=dt)
-    pre = torch.zeros(B * L, D, dtype=dt)
-    mean, rstd = torch.zeros(B * L), torch.zeros(B * L)
+    src_row = torch.tensor([0, 0, 1, 1], dtype=torch.int32, device=DEV[0])
+    out = zeros(B * L, D, dtype=dt)
+    pre = zeros(B * L, D, dtype=dt)
+    mean, rstd = zeros(B * L), zeros(B * L)
     ops.text_embed_fwd(ids, tabs["word"], tabs["pos"], tabs["typ"], g1, b1, out, pre, mean, rstd, Lt, L, 1e-12)
     ops.visual_embed_fwd(grid, src_row, None, tabs["row"], tabs["col"], tabs["vtyp"], g2, b2, out, pre, mean, rstd, B, Lv, Lt, L, 1e-12)
     # reference with autograd
@@ -67,14 +86,14 @@ def test_embeddings_fwd_bwd(emul, dt):
     # backward from d(pre)
     dpre = rnd(B * L, D, seed=12).to(dt)
     pre_ref.backward(dpre.float().view(B, L, D))
-    dword, dpos, dtyp = torch.zeros(V, D), torch.zeros(16, D), torch.zeros(2, D)
+    dword, dpos, dtyp = zeros(V, D), zeros(16, D), zeros(2, D)
     ops.text_embed_bwd(dpre, ids, dword, dpos, dtyp[0], Lt, L, pad_id=0)
     ref_dword = f["word"].grad.clone()
     ref_dword[0] = 0          # padding_idx rows receive no gradient
     torch.testing.assert_close(dword, ref_dword, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(dpos, f["pos"].grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(dtyp, f["typ"].grad, rtol=1e-4, atol=1e-4)
-    dgrid, drow, dcol, dvt = torch.zeros(2, T, Hg, Wg, D), torch.zeros(5, D), torch.zeros(5, D), torch.zeros(1, D)
+    dgrid, drow, dcol, dvt = zeros(2, T, Hg, Wg, D), zeros(5, D), zeros(5, D), zeros(1, D)
     ops.visual_embed_bwd(dpre, src_row, None, dgrid, drow, dcol, dvt, B, Lv, Lt, L)
     torch.testing.assert_close(dgrid, gridr.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(drow, f["row"].grad, rtol=1e-4, atol=1e-4)
@@ -82,27 +101,27 @@ def test_embeddings_fwd_bwd(emul, dt):
     torch.testing.assert_close(dvt, f["vtyp"].grad, rtol=1e-4, atol=1e-4)
 
 
-def test_visual_embed_pixel_subsample(emul):
+def test_visual_embed_pixel_subsample(hw):
     B, Lt, Hg, Wg, T, D = 2, 3, 3, 3, 1, 64
-    sel = torch.tensor([1, 4, 5, 8], dtype=torch.int32)
+    sel = torch.tensor([1, 4, 5, 8], dtype=torch.int32, device=DEV[0])
     Lv, L = 4, 7
     grid = rnd(B, T, Hg, Wg, D, seed=1)
     row, col, typ = rnd(4, D, seed=2), rnd(4, D, seed=3), rnd(1, D, seed=4)
-    g, b = torch.ones(D), torch.zeros(D)
-    out = torch.zeros(B * L, D)
+    g, b = ones(D), zeros(D)
+    out = zeros(B * L, D)
     ops.visual_embed_fwd(grid, None, sel, row, col, typ, g, b, out, None, None, None, B, Lv, Lt, L, 1e-12)
-    sd = {"p.row_position_embeddings.weight": row, "p.col_position_embeddings.weight": col,
-          "p.token_type_embeddings.weight": typ, "p.LayerNorm.weight": g, "p.LayerNorm.bias": b}
-    ref = O.visual_embeddings(sd, "p", grid, 1e-12, sel.long())
-    torch.testing.assert_close(out.view(B, L, D)[:, Lt:], ref, rtol=1e-5, atol=1e-5)
+    sd = {"p.row_position_embeddings.weight": row.cpu(), "p.col_position_embeddings.weight": col.cpu(),
+          "p.token_type_embeddings.weight": typ.cpu(), "p.LayerNorm.weight": g.cpu(), "p.LayerNorm.bias": b.cpu()}
+    ref = O.visual_embeddings(sd, "p", grid.cpu(), 1e-12, sel.long().cpu())
+    torch.testing.assert_close(out.view(B, L, D)[:, Lt:].cpu(), ref, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("L", [9, 41, 70])
-def test_attention_fwd_bwd(emul, dt, L):
+def test_attention_fwd_bwd(hw, dt, L):
     B, H = 2, 2
     qkv = rnd(B * L, 3 * H * 64, seed=1).to(dt)
-    mask = torch.ones(B, L)
+    mask = ones(B, L)
     mask[0, L - 3:] = 0
     mask[1, 2] = 0
     ctx, lse = ops.attention_fwd(qkv, mask, B, L, H, save_lse=True)
@@ -117,9 +136,9 @@ def test_attention_fwd_bwd(emul, dt, L):
     torch.testing.assert_close(dqkv.float(), x.grad, **tol(dt, 1e-4, 3e-2))
 
 
-def test_cross_entropy_and_colsum_and_cast_and_act(emul):
+def test_cross_entropy_and_colsum_and_cast_and_act(hw):
     logits = rnd(9, 37, seed=1)
-    labels = torch.randint(0, 37, (9,), generator=torch.Generator().manual_seed(2))
+    labels = torch.randint(0, 37, (9,), generator=torch.Generator().manual_seed(2)).to(DEV[0])
     labels[3] = -100
     dloss = rnd(9, seed=3)
     loss, dl = ops.cross_entropy(logits, labels, dloss=dloss, want_grad=True)
@@ -130,7 +149,7 @@ def test_cross_entropy_and_colsum_and_cast_and_act(emul):
     torch.testing.assert_close(dl, lr.grad, rtol=1e-5, atol=1e-6)
     for dt in DT:
         g = rnd(300, 70, seed=4).to(dt)
-        out = torch.ones(70)
+        out = ones(70)
         ops.colsum(g, out)
         torch.testing.assert_close(out, 1 + g.float().sum(0), rtol=1e-4, atol=1e-3)
         for act, fn in [(ops.ACT_GELU, F.gelu), (ops.ACT_TANH, torch.tanh), (ops.ACT_RELU, F.relu)]:
@@ -142,20 +161,21 @@ def test_cross_entropy_and_colsum_and_cast_and_act(emul):
             dx = ops.act_bwd(act, dy.to(dt), ref_in.to(dt))
             torch.testing.assert_close(dx.float(), pre.grad, **tol(dt, 1e-5, 3e-2))
     src = rnd(1003, seed=7)
-    torch.testing.assert_close(ops.cast(src, torch.empty(1003, dtype=torch.bfloat16)), src.bfloat16())
+    torch.testing.assert_close(ops.cast(src, torch.empty(1003, dtype=torch.bfloat16, device=DEV[0])), src.bfloat16())
 
 
-def test_adamw_matches_reference_restatement_with_clipping(emul):
+def test_adamw_matches_reference_restatement_with_clipping(hw):
     n = 1003
     p, g, m, v = rnd(n, seed=1), rnd(n, seed=2, scale=3.0), rnd(n, seed=3, scale=0.1), rnd(n, seed=4).abs() * 0.01
-    sq = torch.zeros(1)
+    sq = zeros(1)
     ops.sq_sum(g, sq)
     torch.testing.assert_close(sq[0], (g * g).sum(), rtol=1e-5, atol=1e-3)
-    gc, total = O.clip_grad_norm([g], 5.0)
-    pr, mr, vr = O.adamw_step(p, gc[0], m, v, step=3, lr=5e-5, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=1e-3)
-    w16 = torch.empty(n, dtype=torch.bfloat16)
+    gc, total = O.clip_grad_norm([g.cpu()], 5.0)
+    pr, mr, vr = O.adamw_step(p.cpu(), gc[0], m.cpu(), v.cpu(), step=3, lr=5e-5, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=1e-3)
+    pr, mr, vr = pr.to(DEV[0]), mr.to(DEV[0]), vr.to(DEV[0])
+    w16 = torch.empty(n, dtype=torch.bfloat16, device=DEV[0])
     p2, m2, v2 = p.clone(), m.clone(), v.clone()
-    hp = torch.tensor(ops.adamw_hyper(5e-5, 0.9, 0.98, 1e-6, 1e-3, 3, max_norm=5.0))
+    hp = torch.tensor(ops.adamw_hyper(5e-5, 0.9, 0.98, 1e-6, 1e-3, 3, max_norm=5.0), device=DEV[0])
     ops.adamw(p2, g, m2, v2, w16, hp, grad_sq_sum=sq)
     torch.testing.assert_close(p2, pr, rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(m2, mr, rtol=1e-5, atol=1e-7)
@@ -164,7 +184,7 @@ def test_adamw_matches_reference_restatement_with_clipping(emul):
 
 
 @pytest.mark.parametrize("dt", DT)
-def test_pool_stem_and_relu_bwd(emul, dt):
+def test_pool_stem_and_relu_bwd(hw, dt):
     x = rnd(2, 8, 9, 7, seed=1).to(dt)                  # NCHW reference
     xh = x.permute(0, 2, 3, 1).contiguous()
     y = ops.maxpool_fwd(xh, 3, 2, 1)
@@ -178,12 +198,12 @@ def test_pool_stem_and_relu_bwd(emul, dt):
     dx = ops.maxpool2_bwd(xh, y2, dy.permute(0, 2, 3, 1).contiguous(), relu=True)
     torch.testing.assert_close(dx.float().permute(0, 3, 1, 2), xr.grad)
     # stem pack: fp32 normalised input and fused uint8 path
-    img = torch.randint(0, 256, (2, 3, 6, 5), generator=torch.Generator().manual_seed(3), dtype=torch.uint8)
+    img = torch.randint(0, 256, (2, 3, 6, 5), generator=torch.Generator().manual_seed(3), dtype=torch.uint8).to(DEV[0])
     mean, std = (123.675, 116.28, 103.53), (1.0, 2.0, 0.5)
     norm = ops.image_norm(img, mean, std)
-    ref_norm = (img.float() - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    ref_norm = (img.float() - torch.tensor(mean, device=DEV[0]).view(1, 3, 1, 1)) / torch.tensor(std, device=DEV[0]).view(1, 3, 1, 1)
     torch.testing.assert_close(norm, ref_norm, rtol=1e-6, atol=1e-5)
-    ref_pack = torch.zeros(2, 12, 11, 4)
+    ref_pack = zeros(2, 12, 11, 4)
     ref_pack[:, 3:9, 3:8, :3] = ref_norm[:, [2, 1, 0]].permute(0, 2, 3, 1)
     for packed in (ops.stem_pack(norm, dt, 3), ops.stem_pack(img, dt, 3, mean, std)):
         torch.testing.assert_close(packed.float(), ref_pack.to(dt).float(), **tol(dt, 1e-5, 1.0))
@@ -197,10 +217,10 @@ def test_pool_stem_and_relu_bwd(emul, dt):
     torch.testing.assert_close(g2.float(), (refdz * sc2).to(dt).float(), **tol(dt))
 
 
-def test_dropout_kernel_and_seed_pointer(emul):
-    x = torch.ones(5001)
+def test_dropout_kernel_and_seed_pointer(hw):
+    x = ones(5001)
     a = ops.dropout(x, 0.1, seed=3)
-    b = ops.dropout(x, 0.1, seed=1, seed_ptr=torch.tensor([2], dtype=torch.int64))
+    b = ops.dropout(x, 0.1, seed=1, seed_ptr=torch.tensor([2], dtype=torch.int64, device=DEV[0]))
     assert torch.equal(a, b)                       # seed + *seed_ptr
     assert abs((a > 0).float().mean().item() - 0.9) < 0.02
     torch.testing.assert_close(a[a > 0], torch.full_like(a[a > 0], 1 / 0.9))
@@ -208,19 +228,19 @@ def test_dropout_kernel_and_seed_pointer(emul):
     assert not torch.equal(a, c)
 
 
-def test_layernorm_bwd_row_segments(emul):
+def test_layernorm_bwd_row_segments(hw):
     B, L, Lt, D = 3, 7, 4, 64
     x, dy = rnd(B * L, D, seed=1), rnd(B * L, D, seed=2)
     g = 1 + rnd(D, seed=3, scale=0.1)
     mean, var = x.mean(-1), x.var(-1, unbiased=False)
     rstd = (var + 1e-12).rsqrt()
     dx = torch.zeros_like(x)
-    dg, db = torch.zeros(D), torch.zeros(D)
+    dg, db = zeros(D), zeros(D)
     ops.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dx=dx, rows=B * Lt, seg=(Lt, L, 0))
     xr = x.clone().requires_grad_(True)
     gr = g.clone().requires_grad_(True)
-    y = F.layer_norm(xr, (D,), gr, torch.zeros(D), 1e-12)
-    sel = torch.zeros(B, L, 1)
+    y = F.layer_norm(xr, (D,), gr, zeros(D), 1e-12)
+    sel = zeros(B, L, 1)
     sel[:, :Lt] = 1
     y.backward(dy * sel.view(B * L, 1))
     torch.testing.assert_close(dx, xr.grad, rtol=1e-4, atol=1e-5)

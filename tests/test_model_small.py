@@ -1,7 +1,7 @@
 """End-to-end ClipBert forward + backward (CNN trunk, cross-modal encoder, heads, losses) through the
-product Python layer and the HIP sources compiled for the host emulator, against the CPU oracle and
-its autograd gradients.  Small widths / 2 layers / 64x128 frames keep the emulation to seconds; the
-full-size parity runs are the `-m gpu` tests."""
+product Python layer against the CPU oracle and its autograd gradients.  Small widths / 2 layers /
+64x128 frames keep the host-emulator run to seconds; the same cases run on the GPU (marked `gpu`), and
+the full-size parity runs live in test_gpu_full.py."""
 import pytest
 import torch
 
@@ -16,14 +16,18 @@ HEAD_CLS = dict(retrieval=M.ClipBertForVideoTextRetrieval, multiple_choice=M.Cli
                 sequence_classification=M.ClipBertForSequenceClassification, pretraining=M.ClipBertForPreTraining)
 
 
-def build(head, extra, dtype, seed=5):
+def build(head, extra, dtype, dev, seed=5):
     cfg = dict(SMALL, **extra)
     sd = S.full_state_dict(cfg, head, seed)
     model = M.ClipBert(cfg, detectron2_model_cfg="R-50-grid.yaml", transformer_cls=HEAD_CLS[head])
     missing, unexpected = model.load_state_dict(sd, strict=True)
-    model.eval()
-    model.prepare(dtype=dtype, device="cpu")
+    model.to(dev).eval()
+    model.prepare(dtype=dtype, device=dev)
     return cfg, sd, model
+
+
+def to_dev(batch, dev):
+    return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
 
 def make_batch(cfg, head, n_videos, repeat, lt, seed=5):
@@ -50,9 +54,9 @@ def grads_of_oracle(sd, batch, cfg, head, loss_fn):
     ("retrieval", dict(num_labels=2, loss_type="ce", margin=0.1), 2),
     ("pretraining", dict(), 1),
 ])
-def test_forward_backward_matches_oracle_fp32(emul, head, extra, repeat):
+def test_forward_backward_matches_oracle_fp32(hw, head, extra, repeat):
     torch.manual_seed(0)
-    cfg, sd, model = build(head, extra, torch.float32)
+    cfg, sd, model = build(head, extra, torch.float32, hw.dev)
     n_videos, lt = 2, 6
     batch = make_batch(cfg, head, n_videos, repeat, lt)
     n_pairs = n_videos * repeat
@@ -66,14 +70,14 @@ def test_forward_backward_matches_oracle_fp32(emul, head, extra, repeat):
         batch["labels"] = S.synthetic_labels(n_pairs, 2, 5)
         loss_fn = lambda o: o["loss"].mean()
     ref, sdr = grads_of_oracle(sd, batch, cfg, head, loss_fn)
-    out = model(dict(batch))
+    out = model(to_dev(batch, hw.dev))
     if head == "pretraining":
-        torch.testing.assert_close(out["itm_scores"], ref["itm_scores"], rtol=1e-3, atol=1e-4)
-        torch.testing.assert_close(out["mlm_scores"], ref["mlm_scores"], rtol=1e-3, atol=1e-4)
-        torch.testing.assert_close(out["mlm_loss"], ref["mlm_loss"], rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(out["itm_scores"].cpu(), ref["itm_scores"], rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(out["mlm_scores"].cpu(), ref["mlm_scores"], rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(out["mlm_loss"].cpu(), ref["mlm_loss"], rtol=1e-3, atol=1e-4)
     else:
-        torch.testing.assert_close(out["logits"], ref["logits"], rtol=1e-3, atol=1e-4)
-        torch.testing.assert_close(out["loss"], ref["loss"], rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(out["logits"].cpu(), ref["logits"], rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(out["loss"].cpu(), ref["loss"], rtol=1e-3, atol=1e-4)
     model.rt.bank.zero_grad()
     loss_fn(out).backward()
     checked = 0
@@ -85,7 +89,7 @@ def test_forward_backward_matches_oracle_fp32(emul, head, extra, repeat):
         if g_ref is None:
             g_ref = torch.zeros_like(p)
         scale = max(g_ref.abs().max().item(), 1e-5)   # key.bias has an exactly-zero gradient (softmax shift invariance)
-        err = (p.grad - g_ref).abs().max().item() / scale
+        err = (p.grad.cpu() - g_ref).abs().max().item() / scale
         if err > worst[0]:
             worst = (err, name)
         assert err < 2e-3, f"{name}: relative grad error {err:.3e} (|g|max {scale:.3e})"
@@ -95,12 +99,12 @@ def test_forward_backward_matches_oracle_fp32(emul, head, extra, repeat):
     assert model.cnn.feature.backbone.stem.conv1.weight.grad is None
 
 
-def test_bf16_mode_close_and_frozen_backbone(emul):
-    cfg, sd, model = build("retrieval", dict(num_labels=2, loss_type="ce", margin=0.1), torch.bfloat16)
+def test_bf16_mode_close(hw):
+    cfg, sd, model = build("retrieval", dict(num_labels=2, loss_type="ce", margin=0.1), torch.bfloat16, hw.dev)
     batch = make_batch(cfg, "retrieval", 1, 2, 5)
     batch["labels"] = torch.tensor([1, 0])
     with torch.no_grad():
         ref = O.clipbert_forward(sd, batch, cfg, "retrieval")
-        out = model(dict(batch))
-    assert (out["logits"] - ref["logits"]).abs().max() < 5e-2
-    assert (out["loss"] - ref["loss"]).abs().max() < 5e-2
+        out = model(to_dev(batch, hw.dev))
+    assert (out["logits"].cpu() - ref["logits"]).abs().max() < 5e-2
+    assert (out["loss"].cpu() - ref["loss"]).abs().max() < 5e-2

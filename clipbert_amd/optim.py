@@ -73,6 +73,7 @@ class FusedAdamW:
         """grad_scale multiplies the gradients first (1/world_size after a SUM all-reduce)."""
         bank = self.bank
         self.step_count += 1
+        self._last_scale = grad_scale
         for g, pg in enumerate(self.param_groups):
             hp = ops.adamw_hyper(pg["lr"], self.betas[0], self.betas[1], self.eps, pg["weight_decay"], self.step_count,
                                  self.max_grad_norm, grad_scale)
@@ -91,5 +92,5 @@ class FusedAdamW:
             ops.adamw(bank.master[a:b], bank.grad[a:b], bank.exp_avg[a:b], bank.exp_avg_sq[a:b], w16, self._hp_dev[g], sq)
 
     def grad_norm(self) -> float:
-        """Host-visible global gradient norm of the last step (syncs)."""
-        return float(self._sq.sqrt().item())
+        """Host-visible global norm of the (averaged) gradient of the last step (syncs)."""
+        return float(self._sq.sqrt().item()) * getattr(self, "_last_scale", 1.0)

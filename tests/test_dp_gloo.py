@@ -1,0 +1,83 @@
+"""Data-parallel path on CPU: 2 processes, gloo backend, the product DP code (clipbert_amd.dist.GradSync +
+FusedAdamW) over the host-emulator build of the kernels.  DP=2 on two half batches must produce the same
+updated weights as DP=1 on the full batch (gradient averaging == global-batch mean loss)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup_emul():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emul"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes
+    import build_emul
+    from clipbert_amd import _lib, ops
+    _lib._LIB = _lib.bind(ctypes.CDLL(build_emul.build()))
+    ops._ALLOW_HOST_POINTERS = True
+
+
+def _train_one_step(rank, world, out_path):
+    import test_model_small as T
+    from clipbert_amd.dist import GradSync
+    from clipbert_amd.optim import FusedAdamW
+    cfg, sd, model = T.build("retrieval", dict(num_labels=2, loss_type="ce", margin=0.1), torch.float32, torch.device("cpu"))
+    full = T.make_batch(cfg, "retrieval", 2, 2, 6)
+    full["labels"] = torch.tensor([1, 0, 0, 1])
+    if world == 1:
+        batch = full
+    else:                                   # DistributedSampler-style shard: one video (+ its 2 texts) per rank
+        batch = dict(visual_inputs=full["visual_inputs"][rank:rank + 1].contiguous(),
+                     text_input_ids=full["text_input_ids"][2 * rank:2 * rank + 2].contiguous(),
+                     text_input_mask=full["text_input_mask"][2 * rank:2 * rank + 2].contiguous(),
+                     n_examples_list=[2], labels=full["labels"][2 * rank:2 * rank + 2])
+    bank = model.rt.bank
+    sync = GradSync(bank)
+    sync.broadcast_parameters(0)
+    calls = []
+    model.rt.after_encoder_backward = lambda: (calls.append(1), sync.reduce_transformer())
+    opt = FusedAdamW(bank, lr=1e-3, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0)
+    opt.zero_grad()
+    out = model(batch)
+    out["loss"].mean().backward()
+    sync.reduce_cnn()
+    sync.wait()
+    opt.step(grad_scale=sync.grad_scale)
+    assert calls == [1]                     # transformer bucket was launched from inside the backward
+    if rank == 0:
+        torch.save(dict(master=bank.master.clone(), norm=opt.grad_norm()), out_path)
+
+
+def _worker(rank, world, port, out_path):
+    torch.set_num_threads(2)
+    os.environ["EMUL_THREADS"] = "4"
+    _setup_emul()
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        _train_one_step(rank, world, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp2_equals_dp1_on_the_global_batch(tmp_path):
+    p2, p1 = str(tmp_path / "dp2.pt"), str(tmp_path / "dp1.pt")
+    mp.spawn(_worker, args=(2, _free_port(), p2), nprocs=2, join=True)
+    mp.spawn(_worker, args=(1, _free_port(), p1), nprocs=1, join=True)
+    a, b = torch.load(p2), torch.load(p1)
+    assert abs(a["norm"] - b["norm"]) / b["norm"] < 1e-3
+    torch.testing.assert_close(a["master"], b["master"], rtol=1e-4, atol=2e-6)

@@ -52,7 +52,18 @@ def parse():
     return ap.parse_args()
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
+    import faulthandler
+    faulthandler.enable()
+    faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -73,12 +84,14 @@ def main():
     from clipbert_amd.dist import GradSync
     from clipbert_amd.optim import FusedAdamW
 
+    log("imports done")
     cfg = dict(BASE_CONFIG)
     model = M.ClipBert(cfg, detectron2_model_cfg="R-50-grid.yaml", transformer_cls=M.ClipBertForVideoTextRetrieval)
     model.load_state_dict(S.full_state_dict(cfg, "retrieval", 42), strict=True)
     model.to(dev)
     model.train(not args.forward_only)
     model.prepare(dtype=torch.bfloat16, device=dev)
+    log("model prepared")
     bank = model.rt.bank
     sync = GradSync(bank)
     sync.broadcast_parameters(0)
@@ -120,6 +133,7 @@ def main():
 
     step_fn = infer_step if args.forward_only else train_step
 
+    log("inputs ready")
     # ---- eager warm-up (also builds pixel tables etc.), then graph capture --------------------------------
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
@@ -128,6 +142,7 @@ def main():
             loss = step_fn()
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
+    log(f"eager warm-up done, loss {float(loss.item()):.4f}")
     graph = None
     if not args.no_graph:
         try:
@@ -140,6 +155,7 @@ def main():
             graph = None
             torch.cuda.synchronize()
     run = graph.replay if graph is not None else step_fn
+    log(f"graph captured: {graph is not None}")
 
     for _ in range(args.warmup):
         run()
@@ -161,6 +177,7 @@ def main():
     clips_per_step = bv * nclip * world
     value = clips_per_step / (elapsed / args.steps)
     final_loss = float(loss.item()) if loss is not None else float("nan")
+    log(f"timed region done: {ms_per_step:.3f} ms/step, {value:.1f} clips/s")
 
     out = {
         "metric": "clips/sec/node (2x2 frames, 224px, L_txt=32)" if not args.forward_only else "clips/sec/node forward-only (diagnostic)",
@@ -175,6 +192,7 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_roofline:
         out["roofline"] = measure_roofline(step_fn)
+        log("roofline measured")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, args)
     if rank == 0:
@@ -235,7 +253,7 @@ def cpu_baseline(cfg, args):
     same workload: 2 videos x 2 frames + 4 texts, forward + backward, this host's cores."""
     from clipbert_amd import synthetic as S
     from oracle import clipbert_oracle as O
-    ncores = os.cpu_count() or 1
+    ncores = min(os.cpu_count() or 1, 32)      # more threads than this only adds contention for 4-frame convs
     torch.set_num_threads(ncores)
     sd = S.full_state_dict(cfg, "retrieval", 42)
     sd = {k: v.clone().requires_grad_(v.is_floating_point() and ".norm." not in k and "stem" not in k and "res2" not in k) for k, v in sd.items()}

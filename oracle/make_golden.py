@@ -46,12 +46,19 @@ CASES = {
 }
 
 
+_SD_CACHE = {}
+
+
 def build_case(name: str, seed: int = 42):
     c = CASES[name]
     cfg = dict(O.BASE_CONFIG)
     cfg.update(c["cfg"])
     head = c["head"]
-    sd = S.full_state_dict(cfg if head == "pretraining" else dict(cfg), head, seed)
+    key = (head, seed, tuple(sorted((k, str(v)) for k, v in cfg.items())))
+    if key not in _SD_CACHE:          # ~150 M random values: generate once per process (callers never mutate it)
+        _SD_CACHE.clear()
+        _SD_CACHE[key] = S.full_state_dict(cfg, head, seed)
+    sd = _SD_CACHE[key]
     frames = S.synthetic_frames(c["n_videos"], c["n_frames"], c["size"], seed)
     n_pairs = c["n_videos"] * c["repeat"]
     ids, mask = S.synthetic_text(n_pairs, c["lt"], seed)

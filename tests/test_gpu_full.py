@@ -74,7 +74,7 @@ def test_backward_matches_oracle_autograd_full_size_fp32():
     model.rt.bank.zero_grad()
     out["loss"].mean().backward()
     torch.cuda.synchronize()
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     sdr = {k: v.clone().requires_grad_(v.is_floating_point() and ".norm." not in k) for k, v in sd.items()}
     ref = O.clipbert_forward(sdr, batch, cfg, head)
     ref["loss"].mean().backward()

@@ -71,13 +71,16 @@ def test_forward_backward_matches_oracle_fp32(hw, head, extra, repeat):
         loss_fn = lambda o: o["loss"].mean()
     ref, sdr = grads_of_oracle(sd, batch, cfg, head, loss_fn)
     out = model(to_dev(batch, hw.dev))
+    # the emulator shares the host libm with the oracle; on the GPU erf/exp/tanh differ in the last ulps
+    ft = dict(rtol=1e-3, atol=1e-4) if hw.name == "emul" else dict(rtol=2e-3, atol=1e-3)
+    gt = 2e-3 if hw.name == "emul" else 5e-3
     if head == "pretraining":
-        torch.testing.assert_close(out["itm_scores"].cpu(), ref["itm_scores"], rtol=1e-3, atol=1e-4)
-        torch.testing.assert_close(out["mlm_scores"].cpu(), ref["mlm_scores"], rtol=1e-3, atol=1e-4)
-        torch.testing.assert_close(out["mlm_loss"].cpu(), ref["mlm_loss"], rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(out["itm_scores"].cpu(), ref["itm_scores"], **ft)
+        torch.testing.assert_close(out["mlm_scores"].cpu(), ref["mlm_scores"], **ft)
+        torch.testing.assert_close(out["mlm_loss"].cpu(), ref["mlm_loss"], **ft)
     else:
-        torch.testing.assert_close(out["logits"].cpu(), ref["logits"], rtol=1e-3, atol=1e-4)
-        torch.testing.assert_close(out["loss"].cpu(), ref["loss"], rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(out["logits"].cpu(), ref["logits"], **ft)
+        torch.testing.assert_close(out["loss"].cpu(), ref["loss"], **ft)
     model.rt.bank.zero_grad()
     loss_fn(out).backward()
     checked = 0
@@ -92,7 +95,7 @@ def test_forward_backward_matches_oracle_fp32(hw, head, extra, repeat):
         err = (p.grad.cpu() - g_ref).abs().max().item() / scale
         if err > worst[0]:
             worst = (err, name)
-        assert err < 2e-3, f"{name}: relative grad error {err:.3e} (|g|max {scale:.3e})"
+        assert err < gt, f"{name}: relative grad error {err:.3e} (|g|max {scale:.3e})"
         checked += 1
     assert checked > 40, checked
     # frozen stem / res2 must not have been touched

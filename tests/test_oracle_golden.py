@@ -14,7 +14,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 @pytest.mark.parametrize("name", list(G.CASES))
 def test_oracle_matches_reference_golden(name):
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     gold = np.load(os.path.join(GOLDEN, name + ".npz"))
     cfg, head, sd, batch = G.build_case(name)
     taps = {}

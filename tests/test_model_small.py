@@ -90,7 +90,7 @@ def test_forward_backward_matches_oracle_fp32(hw, head, extra, repeat):
             continue
         g_ref = sdr[name].grad
         if g_ref is None:
-            g_ref = torch.zeros_like(p)
+            g_ref = torch.zeros_like(p, device="cpu")
         scale = max(g_ref.abs().max().item(), 1e-5)   # key.bias has an exactly-zero gradient (softmax shift invariance)
         err = (p.grad.cpu() - g_ref).abs().max().item() / scale
         if err > worst[0]:

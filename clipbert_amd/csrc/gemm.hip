@@ -3,33 +3,36 @@
 //
 //   C[m,n] (op)= epilogue( sum_k A(m,k) * B(n,k) )
 //
-// * 256 threads = 4 waves (2x2); block tile BMxBN (128x128 or 64x64), K step 32.
-// * LDS tiles are [rows][32] with k contiguous, so MFMA fragments are one 16-byte ds_read_b128 per lane
-//   (bf16) -- the 16-byte segment index is XOR-swizzled with f((row>>2)&3), f = {0,3,2,1}, which
-//   makes every ds_read_b128 lane group hit 16 distinct slots of the 256-byte bank row.
+// * 256 threads = 4 waves (2x2); block tile BMxBN (128x128 or 64x64), K step 64 (bf16) / 32 (fp32).
+// * LDS tiles are [rows][BK] with k contiguous (128-byte rows), so an MFMA fragment is one 16-byte
+//   ds_read_b128 per lane (bf16); the 16-byte segment index is XOR-swizzled with (row & 7), which makes
+//   every ds_read_b128 lane group hit 16 distinct slots of the 256-byte bank row.
+// * Latency hiding: a ring of PF register stages keeps PF K-tiles of global loads in flight per block
+//   (these problems are small -- often <= 1 block per CU -- so occupancy cannot hide HBM/L2 latency).
 // * Operands whose memory image has the reduction index OUTERMOST (weights in dgrad, both operands in
 //   wgrad) are transposed in registers (4x8 16-bit blocks) on their way into LDS -- no transposed
 //   copies of weights or activations are ever materialised in HBM.
 // * Convolution operands are gathered through a per-output-pixel table (cb_build_pixel_table), so the
-//   kernel has no integer divisions per row; a K step never straddles a filter tap (Cin % 32 == 0).
+//   kernel has no per-row integer divisions (one k -> (tap, channel) division per thread per K step).
 // * MFMA operands are swapped (acc = mfma(Bfrag, Afrag)) so each lane owns 4 CONSECUTIVE n of one
 //   row m: the epilogue reads scale/shift/residual and writes C with 8/16-byte accesses.
 // * bf16: v_mfma_f32_16x16x32_bf16; fp32 parity mode: v_mfma_f32_16x16x4_f32 (exact fp32).
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
-constexpr int BK = 32;
 constexpr int NTHREADS = 256;
 
+// EPS elements per 16-byte segment; BK = K step; SEGS segments per LDS row; ROWB bytes per LDS row;
+// RB rows per transposing block
 template <typename T> struct Tr;
-template <> struct Tr<bf16> { static constexpr int EPS = 8, SEGS = 4, ROWB = 64, RB = 8; };
-template <> struct Tr<float> { static constexpr int EPS = 4, SEGS = 8, ROWB = 144, RB = 4; };
+template <> struct Tr<bf16> { static constexpr int EPS = 8, BK = 64, SEGS = 8, ROWB = 128, RB = 8; };
+template <> struct Tr<float> { static constexpr int EPS = 4, BK = 32, SEGS = 8, ROWB = 144, RB = 4; };
 
 template <typename T> __device__ __forceinline__ int lds_off(int row, int seg);
-template <> __device__ __forceinline__ int lds_off<bf16>(int row, int seg) {
-    return row * 64 + ((seg ^ ((4 - ((row >> 2) & 3)) & 3)) << 4);
-}
+template <> __device__ __forceinline__ int lds_off<bf16>(int row, int seg) { return row * 128 + ((seg ^ (row & 7)) << 4); }
 template <> __device__ __forceinline__ int lds_off<float>(int row, int seg) { return row * 144 + (seg << 4); }
 
 struct GP {
@@ -57,19 +60,19 @@ template <typename T> __device__ __forceinline__ u32x4 load_guarded(const T* src
 }
 
 // ---------------------------------------------------------------------------------------------
-// ROWK loader: tile rows are GEMM rows, 16-byte segments run along k.
+// ROWK loader: tile rows are GEMM rows, 16-byte segments run along k.  The per-row state (offset,
+// ih0/iw0, validity) is fixed for the whole K loop; `Stage` holds one K-tile of loaded registers.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int ROWS> struct RowkLoader {
     using X = Tr<T>;
     static constexpr int NS = ROWS * X::SEGS / NTHREADS;
     static_assert(ROWS * X::SEGS % NTHREADS == 0, "tile/threads mismatch");
+    struct Stage { u32x4 r[NS]; };
     int64_t off[NS];
     int ih[NS], iw[NS];
     bool ok[NS];
-    u32x4 r[NS];
 
-    __device__ __forceinline__ void init(const GP& p, bool gather, const cb_pixel* tab, int64_t ld, int row0,
-                                         int bound, int tid) {
+    __device__ __forceinline__ void init(bool gather, const cb_pixel* tab, int64_t ld, int row0, int bound, int tid) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             int idx = tid + i * NTHREADS;
@@ -85,69 +88,67 @@ template <typename T, int ROWS> struct RowkLoader {
             }
         }
     }
-    __device__ __forceinline__ void load(const GP& p, const T* base, bool gather, bool vec, int kt, int tid) {
-        int k0 = kt * BK, c0 = k0, rr = 0, ss = 0, klim = p.K;
+    __device__ __forceinline__ void load(Stage& st, const GP& p, const T* base, bool gather, bool vec, int kt, int tid) const {
+        const int seg = tid % X::SEGS;                       // same for every slot of this thread
+        int kk = kt * X::BK + seg * X::EPS, rr = 0, ss = 0, klim = p.K;
         int64_t tapoff = 0;
         if (gather) {
-            int tap = k0 / p.Ct;
-            c0 = k0 - tap * p.Ct;
+            int tap = kk / p.Ct;                             // k -> (tap, channel); K = taps * Ct
+            klim = (kk < p.K) ? p.Ct : 0;
+            kk -= tap * p.Ct;
             rr = tap / p.S; ss = tap - rr * p.S;
             tapoff = rr * p.sH + ss * p.sW;
-            klim = p.Ct;
         }
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            int seg = (tid + i * NTHREADS) % X::SEGS;
-            int kk = c0 + seg * X::EPS;
             bool v = ok[i] && kk < klim;
             if (gather) v = v && (unsigned)(ih[i] + rr) < (unsigned)p.H && (unsigned)(iw[i] + ss) < (unsigned)p.W;
             const T* src = base + off[i] + tapoff + kk;
             u32x4 z = {0u, 0u, 0u, 0u};
-            if (!v) r[i] = z;
-            else if (vec) r[i] = *reinterpret_cast<const u32x4*>(src);
-            else r[i] = load_guarded<T>(src, klim - kk);
+            if (!v) st.r[i] = z;
+            else if (vec) st.r[i] = *reinterpret_cast<const u32x4*>(src);
+            else st.r[i] = load_guarded<T>(src, klim - kk);
         }
     }
-    __device__ __forceinline__ void store(unsigned char* tile, int tid) const {
+    __device__ __forceinline__ void store(const Stage& st, unsigned char* tile, int tid) const {
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             int idx = tid + i * NTHREADS;
-            *reinterpret_cast<u32x4*>(tile + lds_off<T>(idx / X::SEGS, idx % X::SEGS)) = r[i];
+            *reinterpret_cast<u32x4*>(tile + lds_off<T>(idx / X::SEGS, idx % X::SEGS)) = st.r[i];
         }
     }
 };
 
 // ---------------------------------------------------------------------------------------------
 // KROW loader: memory has the reduction index outermost; each thread moves a (4 k) x (RB rows) block
-// and transposes it in registers.
+// and transposes it in registers on its way into the [row][k] LDS tile.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int ROWS> struct KrowLoader {
     using X = Tr<T>;
     static constexpr int RBLK = ROWS / X::RB;              // row blocks per tile
-    static constexpr int CNT = RBLK * (BK / 4);            // thread-blocks per tile
+    static constexpr int CNT = RBLK * (X::BK / 4);         // thread-blocks per tile
     static constexpr int NI = (CNT + NTHREADS - 1) / NTHREADS;
-    u32x4 r[NI][4];
+    struct Stage { u32x4 r[NI][4]; };
 
-    __device__ __forceinline__ void load(const GP& p, const T* base, int mode, const cb_pixel* tab, int64_t ld,
-                                         bool vec, int row0, int bound, int kt, int tid) {
+    __device__ __forceinline__ void load(Stage& st, const GP& p, const T* base, int mode, const cb_pixel* tab, int64_t ld,
+                                         bool vec, int row0, int bound, int kt, int tid) const {
         u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             int b = tid + it * NTHREADS;
-            if (b >= CNT) { r[it][0] = z; r[it][1] = z; r[it][2] = z; r[it][3] = z; continue; }
+            if (b >= CNT) { st.r[it][0] = z; st.r[it][1] = z; st.r[it][2] = z; st.r[it][3] = z; continue; }
             int rb = b % RBLK, kb = b / RBLK;
             int row = row0 + rb * X::RB;           // global row of the first element
             int nvalid = bound - row;              // rows valid from here
-            int kbase = kt * BK + kb * 4;
-            // per-tile-uniform tap decomposition (weights of a transposed conv)
+            int kbase = kt * X::BK + kb * 4;       // the 4 k of a block never straddle a tap (Ct % 4 == 0)
             int64_t rowoff = row;
             int rr = 0, ss = 0, tapk = 0;
-            if (mode == CB_KROW_TAPS) {
-                int tap = (kt * BK) / p.Ct;
+            if (mode == CB_KROW_TAPS) {            // weights [Ct][taps][bound] read for a transposed conv
+                int tap = kbase / p.Ct;
                 tapk = tap * p.Ct;
                 int tapw = p.flip ? (p.R * p.S - 1 - tap) : tap;
-                rowoff = (int64_t)tapw * bound + row;      // weights [Ct][taps][bound]
-            } else if (mode == CB_KROW_GATHER) {
+                rowoff = (int64_t)tapw * bound + row;
+            } else if (mode == CB_KROW_GATHER) {   // row = (tap, channel) of the gathered image
                 int tap = row / p.Ct;
                 int c = row - tap * p.Ct;
                 rr = tap / p.S; ss = tap - rr * p.S;
@@ -166,13 +167,13 @@ template <typename T, int ROWS> struct KrowLoader {
                 } else {
                     src = base + (int64_t)(k - tapk) * ld + rowoff;
                 }
-                if (!v) r[it][j] = z;
-                else if (vec && nvalid >= X::RB) r[it][j] = *reinterpret_cast<const u32x4*>(src);
-                else r[it][j] = load_guarded<T>(src, nvalid);
+                if (!v) st.r[it][j] = z;
+                else if (vec && nvalid >= X::RB) st.r[it][j] = *reinterpret_cast<const u32x4*>(src);
+                else st.r[it][j] = load_guarded<T>(src, nvalid);
             }
         }
     }
-    __device__ __forceinline__ void store(unsigned char* tile, int tid) const {
+    __device__ __forceinline__ void store(const Stage& st, unsigned char* tile, int tid) const {
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             int b = tid + it * NTHREADS;
@@ -180,10 +181,10 @@ template <typename T, int ROWS> struct KrowLoader {
             int rb = b % RBLK, kb = b / RBLK;
             int row = rb * X::RB;
             if constexpr (sizeof(T) == 2) {
-                // r[it][j][d] holds rows (2d, 2d+1) at k = kb*4 + j
+                // st.r[it][j][d] holds rows (2d, 2d+1) at k = kb*4 + j
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    uint32_t a0 = r[it][0][d], a1 = r[it][1][d], a2 = r[it][2][d], a3 = r[it][3][d];
+                    uint32_t a0 = st.r[it][0][d], a1 = st.r[it][1][d], a2 = st.r[it][2][d], a3 = st.r[it][3][d];
                     u32x2 even = {(a0 & 0xffffu) | (a1 << 16), (a2 & 0xffffu) | (a3 << 16)};
                     u32x2 odd = {(a0 >> 16) | (a1 & 0xffff0000u), (a2 >> 16) | (a3 & 0xffff0000u)};
                     *reinterpret_cast<u32x2*>(tile + lds_off<T>(row + 2 * d, kb >> 1) + (kb & 1) * 8) = even;
@@ -192,14 +193,13 @@ template <typename T, int ROWS> struct KrowLoader {
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    u32x4 o = {r[it][0][e], r[it][1][e], r[it][2][e], r[it][3][e]};
+                    u32x4 o = {st.r[it][0][e], st.r[it][1][e], st.r[it][2][e], st.r[it][3][e]};
                     *reinterpret_cast<u32x4*>(tile + lds_off<T>(row + e, kb)) = o;
                 }
             }
         }
     }
 };
-
 
 // ---------------------------------------------------------------------------------------------
 // Epilogue of one 4-wide accumulator fragment (row m, columns nb..nb+3).
@@ -266,9 +266,10 @@ __device__ __forceinline__ void epilogue_elem(const GP& p, float x, int m, int64
     }
 }
 
-template <typename T, int BM, int BN, bool A_KROW, bool B_KROW>
+template <typename T, int BM, int BN, bool A_KROW, bool B_KROW, int PF>
 __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
     using X = Tr<T>;
+    constexpr int BK = X::BK;
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     constexpr int TILE_A = BM * X::ROWB, TILE_B = BN * X::ROWB;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (TILE_A + TILE_B)];
@@ -277,31 +278,33 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kt_per = (p.ktiles + p.split_k - 1) / p.split_k;
-    const int kt_begin = blockIdx.z * kt_per;
-    const int kt_end = (kt_begin + kt_per < p.ktiles) ? kt_begin + kt_per : p.ktiles;
-    if (kt_begin >= kt_end) return;
+    const int kt0 = blockIdx.z * kt_per;
+    const int nt = ((kt0 + kt_per < p.ktiles) ? kt0 + kt_per : p.ktiles) - kt0;
+    if (nt <= 0) return;
 
     const T* Ab = reinterpret_cast<const T*>(p.A);
     const T* Bb = reinterpret_cast<const T*>(p.B);
 
-    RowkLoader<T, BM> la;
-    RowkLoader<T, BN> lb;
-    KrowLoader<T, BM> ka;
-    KrowLoader<T, BN> kb;
-    if constexpr (!A_KROW) la.init(p, p.a_mode == CB_ROWK_GATHER, p.a_tab, p.lda, m0, p.M, tid);
-    if constexpr (!B_KROW) lb.init(p, false, nullptr, p.ldb, n0, p.N, tid);
+    using LA = typename std::conditional<A_KROW, KrowLoader<T, BM>, RowkLoader<T, BM>>::type;
+    using LB = typename std::conditional<B_KROW, KrowLoader<T, BN>, RowkLoader<T, BN>>::type;
+    LA la;
+    LB lb;
+    if constexpr (!A_KROW) la.init(p.a_mode == CB_ROWK_GATHER, p.a_tab, p.lda, m0, p.M, tid);
+    if constexpr (!B_KROW) lb.init(false, nullptr, p.ldb, n0, p.N, tid);
+    typename LA::Stage sa[PF];
+    typename LB::Stage sb[PF];
 
-    auto load_tiles = [&](int kt) {
-        if constexpr (A_KROW) ka.load(p, Ab, CB_KROW, nullptr, p.lda, p.a_vec, m0, p.M, kt, tid);
-        else la.load(p, Ab, p.a_mode == CB_ROWK_GATHER, p.a_vec, kt, tid);
-        if constexpr (B_KROW) kb.load(p, Bb, p.b_mode, p.b_tab, p.ldb, p.b_vec, n0, p.N, kt, tid);
-        else lb.load(p, Bb, false, p.b_vec, kt, tid);
+    auto load_tiles = [&](typename LA::Stage& xa, typename LB::Stage& xb, int t) {
+        const int kt = kt0 + t;
+        if constexpr (A_KROW) la.load(xa, p, Ab, CB_KROW, nullptr, p.lda, p.a_vec, m0, p.M, kt, tid);
+        else la.load(xa, p, Ab, p.a_mode == CB_ROWK_GATHER, p.a_vec, kt, tid);
+        if constexpr (B_KROW) lb.load(xb, p, Bb, p.b_mode, p.b_tab, p.ldb, p.b_vec, n0, p.N, kt, tid);
+        else lb.load(xb, p, Bb, false, p.b_vec, kt, tid);
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](const typename LA::Stage& xa, const typename LB::Stage& xb, int buf) {
         unsigned char* As = smem + buf * (TILE_A + TILE_B);
-        unsigned char* Bs = As + TILE_A;
-        if constexpr (A_KROW) ka.store(As, tid); else la.store(As, tid);
-        if constexpr (B_KROW) kb.store(Bs, tid); else lb.store(Bs, tid);
+        la.store(xa, As, tid);
+        lb.store(xb, As + TILE_A, tid);
     };
 
     f32x4 acc[FM][FN];
@@ -310,48 +313,63 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
 
-    load_tiles(kt_begin);
-    store_tiles(0);
+    // prologue: K-tile j lives in register stage j % PF
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+        if (s < nt) load_tiles(sa[s], sb[s], s);
+    store_tiles(sa[0], sb[0], 0);
+    if (PF < nt) load_tiles(sa[0], sb[0], PF);
     __syncthreads();
 
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int cur = (kt - kt_begin) & 1;
-        const bool more = kt + 1 < kt_end;
-        if (more) load_tiles(kt + 1);
-        const unsigned char* As = smem + cur * (TILE_A + TILE_B);
-        const unsigned char* Bs = As + TILE_A;
-        if constexpr (sizeof(T) == 2) {
-            bf16x8 af[FM], bfr[FN];
+    int t = 0;
+    while (t < nt) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
-                af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off<T>(wm * WM + i * 16 + (lane & 15), lane >> 4));
+        for (int s = 0; s < PF; ++s) {            // t % PF == s: static register-stage indices
+            if (t < nt) {
+                const unsigned char* As = smem + (t & 1) * (TILE_A + TILE_B);
+                const unsigned char* Bs = As + TILE_A;
+                if constexpr (sizeof(T) == 2) {
 #pragma unroll
-            for (int j = 0; j < FN; ++j)
-                bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<T>(wn * WN + j * 16 + (lane & 15), lane >> 4));
+                    for (int kk = 0; kk < BK / 32; ++kk) {
+                        bf16x8 af[FM], bfr[FN];
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+                        for (int i = 0; i < FM; ++i)
+                            af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off<T>(wm * WM + i * 16 + (lane & 15), kk * 4 + (lane >> 4)));
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        } else {
+                        for (int j = 0; j < FN; ++j)
+                            bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<T>(wn * WN + j * 16 + (lane & 15), kk * 4 + (lane >> 4)));
 #pragma unroll
-            for (int kk = 0; kk < BK / 4; ++kk) {
-                float af[FM], bfr[FN];
+                        for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int i = 0; i < FM; ++i)
-                    af[i] = *reinterpret_cast<const float*>(As + lds_off<T>(wm * WM + i * 16 + (lane & 15), kk) + (lane >> 4) * 4);
+                            for (int j = 0; j < FN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    }
+                } else {
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    bfr[j] = *reinterpret_cast<const float*>(Bs + lds_off<T>(wn * WN + j * 16 + (lane & 15), kk) + (lane >> 4) * 4);
+                    for (int kk = 0; kk < BK / 4; ++kk) {
+                        float af[FM], bfr[FN];
 #pragma unroll
-                for (int i = 0; i < FM; ++i)
+                        for (int i = 0; i < FM; ++i)
+                            af[i] = *reinterpret_cast<const float*>(As + lds_off<T>(wm * WM + i * 16 + (lane & 15), kk) + (lane >> 4) * 4);
 #pragma unroll
-                    for (int j = 0; j < FN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < FN; ++j)
+                            bfr[j] = *reinterpret_cast<const float*>(Bs + lds_off<T>(wn * WN + j * 16 + (lane & 15), kk) + (lane >> 4) * 4);
+#pragma unroll
+                        for (int i = 0; i < FM; ++i)
+#pragma unroll
+                            for (int j = 0; j < FN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    }
+                }
+                if (t + 1 < nt) {
+                    const int S1 = (s + 1) % PF;
+                    store_tiles(sa[S1], sb[S1], (t + 1) & 1);
+                    if (t + 1 + PF < nt) load_tiles(sa[S1], sb[S1], t + 1 + PF);
+                }
+                __syncthreads();
+                ++t;
             }
         }
-        if (more) store_tiles(cur ^ 1);
-        __syncthreads();
     }
 
     // ---- epilogue: lane owns n = nb..nb+3 of row m ------------------------------------------------
@@ -413,13 +431,13 @@ __global__ void __launch_bounds__(256) pixel_table_kernel(cb_pixel* tab, int tot
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int PF>
 int launch_gemm(const GP& p, bool a_krow, bool b_krow, hipStream_t st) {
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.split_k);
     dim3 block(NTHREADS);
-    if (!a_krow && !b_krow) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, false>), grid, block, 0, st, p);
-    else if (!a_krow && b_krow) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, true>), grid, block, 0, st, p);
-    else if (a_krow && b_krow) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, true, true>), grid, block, 0, st, p);
+    if (!a_krow && !b_krow) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, false, PF>), grid, block, 0, st, p);
+    else if (!a_krow && b_krow) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, true, PF>), grid, block, 0, st, p);
+    else if (a_krow && b_krow) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, true, true, PF>), grid, block, 0, st, p);
     else return cb_fail("cb_gemm: unsupported operand mode combination (A KROW with B ROWK)");
     return cb_launch_status("cb_gemm");
 }
@@ -446,7 +464,8 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     p.act = d->act; p.relu_after = d->relu_after;
     p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
     p.dropout_p = d->dropout_p; p.seed = d->dropout_seed; p.seed_ptr = d->dropout_seed_ptr;
-    p.ktiles = (d->K + BK - 1) / BK;
+    const int bk = d->dtype == CB_BF16 ? Tr<bf16>::BK : Tr<float>::BK;
+    p.ktiles = (d->K + bk - 1) / bk;
 
     const bool a_krow = d->a_mode == CB_KROW;
     const bool b_krow = d->b_mode == CB_KROW || d->b_mode == CB_KROW_TAPS || d->b_mode == CB_KROW_GATHER;
@@ -456,7 +475,6 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     const bool tapped = d->a_mode == CB_ROWK_GATHER || d->b_mode == CB_KROW_TAPS || d->b_mode == CB_KROW_GATHER;
     if (tapped) {
         CB_REQUIRE(p.Ct > 0, "cb_gemm: Cin (channels per tap) must be set for conv modes");
-        CB_REQUIRE(taps == 1 || p.Ct % BK == 0, "cb_gemm: channels per tap (%d) must be a multiple of %d", p.Ct, BK);
         CB_REQUIRE(p.Ct % eps == 0, "cb_gemm: channels per tap (%d) must be a multiple of %d", p.Ct, eps);
     }
     if (d->a_mode == CB_ROWK_GATHER) {
@@ -502,14 +520,14 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     p.c_vec = cv;
 
     hipStream_t st = cb_stream(stream);
-    if (d->dtype == CB_F32) return launch_gemm<float, 64, 64>(p, a_krow, b_krow, st);
+    if (d->dtype == CB_F32) return launch_gemm<float, 64, 64, 2>(p, a_krow, b_krow, st);
     int tile = d->tile;
     if (tile == 0) {
         int64_t blocks128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * p.split_k;
-        tile = blocks128 >= 192 ? 1 : 2;
+        tile = blocks128 >= 160 ? 1 : 2;
     }
-    if (tile == 1) return launch_gemm<bf16, 128, 128>(p, a_krow, b_krow, st);
-    return launch_gemm<bf16, 64, 64>(p, a_krow, b_krow, st);
+    if (tile == 1) return launch_gemm<bf16, 128, 128, 2>(p, a_krow, b_krow, st);
+    return launch_gemm<bf16, 64, 64, 3>(p, a_krow, b_krow, st);
 }
 
 extern "C" int cb_build_pixel_table(cb_pixel* tab, int32_t N, int32_t OH, int32_t OW, int32_t stride, int32_t pad,

@@ -44,6 +44,34 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* g, int64_t ldg, fl
     atomicAdd(out + n, s);
 }
 
+// vectorised variant: 32 column groups (4 columns each) x 8 row lanes per block; 8/16-byte loads,
+// the 8 row lanes are combined through LDS, one atomic per column per block.
+template <typename T>
+__global__ void __launch_bounds__(256) colsum4_kernel(const T* g, int64_t ldg, float* out, int64_t M, int N, int64_t rows_per) {
+    __shared__ float red[8][32 * 4 + 4];
+    const int cg = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int n = (blockIdx.x * 32 + cg) * 4;
+    int64_t m0 = (int64_t)blockIdx.y * rows_per;
+    int64_t m1 = m0 + rows_per < M ? m0 + rows_per : M;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+        for (int64_t m = m0 + ry; m < m1; m += 8) s = s + load4(g + m * ldg + n);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[ry][cg * 4 + e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        int c = threadIdx.x;
+        int col = blockIdx.x * 128 + c;
+        if (col < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t += red[r][c];
+            atomicAdd(out + col, t);
+        }
+    }
+}
+
 template <typename S, typename D>
 __global__ void __launch_bounds__(256) cast_kernel(const S* src, D* dst, int64_t n) {
     int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -124,6 +152,20 @@ extern "C" int cb_cross_entropy(const float* logits, int64_t ld, const int64_t* 
 extern "C" int cb_colsum(int32_t dtype, const void* g, int64_t ldg, float* out, int64_t M, int32_t N, void* stream) {
     CB_REQUIRE(g && out && N > 0, "cb_colsum: bad arguments");
     if (M == 0) return 0;
+    const int esz = dtype == CB_BF16 ? 2 : 4;
+    if (N % 4 == 0 && ldg % 4 == 0 && (reinterpret_cast<uintptr_t>(g) % (4 * esz)) == 0) {
+        unsigned cb = nblk(N, 128);
+        int64_t slabs = (M + 63) / 64;
+        int64_t want = (1024 + cb - 1) / cb;              // ~1024 blocks in flight
+        if (slabs > want) slabs = want;
+        int64_t rows_per = ((M + slabs - 1) / slabs + 7) / 8 * 8;
+        slabs = (M + rows_per - 1) / rows_per;
+        dim3 gr(cb, (unsigned)slabs), b(256);
+        if (dtype == CB_BF16) hipLaunchKernelGGL((colsum4_kernel<bf16>), gr, b, 0, cb_stream(stream), (const bf16*)g, ldg, out, M, N, rows_per);
+        else if (dtype == CB_F32) hipLaunchKernelGGL((colsum4_kernel<float>), gr, b, 0, cb_stream(stream), (const float*)g, ldg, out, M, N, rows_per);
+        else return cb_fail("cb_colsum: bad dtype");
+        return cb_launch_status("cb_colsum");
+    }
     int64_t slabs = (M + 127) / 128;
     if (slabs > 256) slabs = 256;
     int64_t rows_per = (M + slabs - 1) / slabs;

@@ -148,10 +148,11 @@ def test_cross_entropy_and_colsum_and_cast_and_act(hw):
     ref.backward(dloss)
     torch.testing.assert_close(dl, lr.grad, rtol=1e-5, atol=1e-6)
     for dt in DT:
-        g = rnd(300, 70, seed=4).to(dt)
-        out = ones(70)
-        ops.colsum(g, out)
-        torch.testing.assert_close(out, 1 + g.float().sum(0), rtol=1e-4, atol=1e-3)
+        for n_cols in (70, 72, 776):            # scalar fallback, vector path, several column blocks
+            g = rnd(300, n_cols, seed=4).to(dt)
+            out = ones(n_cols)
+            ops.colsum(g, out)
+            torch.testing.assert_close(out, 1 + g.float().sum(0), rtol=1e-4, atol=1e-3)
         for act, fn in [(ops.ACT_GELU, F.gelu), (ops.ACT_TANH, torch.tanh), (ops.ACT_RELU, F.relu)]:
             pre = rnd(1001, seed=5).requires_grad_(True)
             y = fn(pre)

@@ -47,7 +47,8 @@ struct GP {
     float alpha, dropout_p;
     uint64_t seed;
     const uint64_t* seed_ptr;
-    int a_vec, b_vec, c_vec;
+    int c_vec;
+    uint32_t a_bytes, b_bytes;
     int ktiles;
 };
 
@@ -59,55 +60,87 @@ template <typename T> __device__ __forceinline__ u32x4 load_guarded(const T* src
     return u.v;
 }
 
+// Buffer-descriptor loads: the hardware range check returns zeros for any byte offset >= num_records, so
+// predication (rows past M, taps in the padding, K tails) is ONE select of the offset to OOB -- no branches,
+// no 64-bit address arithmetic in the K loop.  Operands must be < 2 GiB (else the generic loaders run).
+constexpr uint32_t OOB = 0x80000000u;
+typedef decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0)) rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 bload16(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
+
+// one operand of the GEMM as the loaders see it
+struct Opnd {
+    const void* base; const cb_pixel* tab; int64_t ld; int mode; uint32_t bytes;
+};
+
 // ---------------------------------------------------------------------------------------------
-// ROWK loader: tile rows are GEMM rows, 16-byte segments run along k.  The per-row state (offset,
-// ih0/iw0, validity) is fixed for the whole K loop; `Stage` holds one K-tile of loaded registers.
+// ROWK loaders: tile rows are GEMM rows, 16-byte segments run along k.  Per-row state is fixed for the
+// whole K loop; `Stage` holds one K-tile of loaded registers; load() must be called for consecutive
+// K-tiles (it advances the thread's k -> (tap, channel) position incrementally: no divisions).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int ROWS> struct RowkLoader {
+template <typename T, int ROWS, bool FAST> struct RowkLoader {
     using X = Tr<T>;
     static constexpr int NS = ROWS * X::SEGS / NTHREADS;
+    static constexpr int ESZ = (int)sizeof(T);
     static_assert(ROWS * X::SEGS % NTHREADS == 0, "tile/threads mismatch");
     struct Stage { u32x4 r[NS]; };
-    int64_t off[NS];
+    int64_t off[NS];            // element offset of (row, k=0)        (generic path)
+    uint32_t boff[NS];          // byte offset of (row, k=0), or OOB   (fast path)
     int ih[NS], iw[NS];
     bool ok[NS];
+    int c, rr, ss;              // this thread's segment: channel within the tap, tap = (rr, ss)
+    bool gather;
+    rsrc_t rs;
+    const T* base;
 
-    __device__ __forceinline__ void init(bool gather, const cb_pixel* tab, int64_t ld, int row0, int bound, int tid) {
+    __device__ __forceinline__ void init(const GP& p, const Opnd& o, int row0, int bound, int kt0, int tid) {
+        gather = o.mode == CB_ROWK_GATHER;
+        base = reinterpret_cast<const T*>(o.base);
+        if constexpr (FAST) rs = make_rsrc(o.base, o.bytes);
+        int k = kt0 * X::BK + (tid % X::SEGS) * X::EPS;
+        c = k; rr = 0; ss = 0;
+        if (gather) {
+            int tap = k / p.Ct;
+            c = k - tap * p.Ct;
+            rr = tap / p.S; ss = tap - rr * p.S;
+        }
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             int idx = tid + i * NTHREADS;
             int row = row0 + idx / X::SEGS;
             ok[i] = row < bound;
             ih[i] = 0; iw[i] = 0;
+            int64_t e = (int64_t)row * o.ld;
             if (gather) {
                 cb_pixel px = {0, 0, 0};
-                if (ok[i]) px = tab[row];
-                off[i] = px.off; ih[i] = px.ih0; iw[i] = px.iw0;
-            } else {
-                off[i] = (int64_t)row * ld;
+                if (ok[i]) px = o.tab[row];
+                e = px.off; ih[i] = px.ih0; iw[i] = px.iw0;
             }
+            off[i] = e;
+            boff[i] = ok[i] ? (uint32_t)e * (uint32_t)ESZ : OOB;
         }
     }
-    __device__ __forceinline__ void load(Stage& st, const GP& p, const T* base, bool gather, bool vec, int kt, int tid) const {
-        const int seg = tid % X::SEGS;                       // same for every slot of this thread
-        int kk = kt * X::BK + seg * X::EPS, rr = 0, ss = 0, klim = p.K;
-        int64_t tapoff = 0;
-        if (gather) {
-            int tap = kk / p.Ct;                             // k -> (tap, channel); K = taps * Ct
-            klim = (kk < p.K) ? p.Ct : 0;
-            kk -= tap * p.Ct;
-            rr = tap / p.S; ss = tap - rr * p.S;
-            tapoff = rr * p.sH + ss * p.sW;
-        }
+    __device__ __forceinline__ void load(Stage& st, const GP& p) {
+        const bool kv = gather ? (rr < p.R) : (c < p.K);
+        const int klim = gather ? p.Ct : p.K;
+        const int64_t tapoff = gather ? (rr * p.sH + ss * p.sW) : 0;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            bool v = ok[i] && kk < klim;
+            bool v = kv && ok[i];
             if (gather) v = v && (unsigned)(ih[i] + rr) < (unsigned)p.H && (unsigned)(iw[i] + ss) < (unsigned)p.W;
-            const T* src = base + off[i] + tapoff + kk;
-            u32x4 z = {0u, 0u, 0u, 0u};
-            if (!v) st.r[i] = z;
-            else if (vec) st.r[i] = *reinterpret_cast<const u32x4*>(src);
-            else st.r[i] = load_guarded<T>(src, klim - kk);
+            if constexpr (FAST) {
+                uint32_t o32 = boff[i] + (uint32_t)(tapoff + c) * (uint32_t)ESZ;
+                st.r[i] = bload16(rs, v ? o32 : OOB);
+            } else {
+                u32x4 z = {0u, 0u, 0u, 0u};
+                st.r[i] = v ? load_guarded<T>(base + off[i] + tapoff + c, klim - c) : z;
+            }
+        }
+        c += X::BK;
+        if (gather) {
+            while (c >= p.Ct) { c -= p.Ct; if (++ss == p.S) { ss = 0; ++rr; } }
         }
     }
     __device__ __forceinline__ void store(const Stage& st, unsigned char* tile, int tid) const {
@@ -120,56 +153,90 @@ template <typename T, int ROWS> struct RowkLoader {
 };
 
 // ---------------------------------------------------------------------------------------------
-// KROW loader: memory has the reduction index outermost; each thread moves a (4 k) x (RB rows) block
+// KROW loaders: memory has the reduction index outermost; each thread moves a (4 k) x (RB rows) block
 // and transposes it in registers on its way into the [row][k] LDS tile.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int ROWS> struct KrowLoader {
+template <typename T, int ROWS, bool FAST> struct KrowLoader {
     using X = Tr<T>;
     static constexpr int RBLK = ROWS / X::RB;              // row blocks per tile
     static constexpr int CNT = RBLK * (X::BK / 4);         // thread-blocks per tile
     static constexpr int NI = (CNT + NTHREADS - 1) / NTHREADS;
+    static constexpr int ESZ = (int)sizeof(T);
     struct Stage { u32x4 r[NI][4]; };
+    int mode, bound;
+    int64_t ld;
+    const cb_pixel* tab;
+    const T* base;
+    rsrc_t rs;
+    int kb0[NI];        // k of the block's first row (advances by BK per tile)
+    int co[NI], tap[NI];// CB_KROW_TAPS: k -> (tap, co)
+    int row[NI];        // global row of the block's first element
+    int rr[NI], ss[NI]; // CB_KROW_GATHER: tap of this row block
+    int64_t rowoff[NI]; // element offset contributed by the row (and its tap for GATHER)
+    bool act[NI];
 
-    __device__ __forceinline__ void load(Stage& st, const GP& p, const T* base, int mode, const cb_pixel* tab, int64_t ld,
-                                         bool vec, int row0, int bound, int kt, int tid) const {
-        u32x4 z = {0u, 0u, 0u, 0u};
+    __device__ __forceinline__ void init(const GP& p, const Opnd& o, int row0, int bnd, int kt0, int tid) {
+        mode = o.mode; bound = bnd; ld = o.ld; tab = o.tab;
+        base = reinterpret_cast<const T*>(o.base);
+        if constexpr (FAST) rs = make_rsrc(o.base, o.bytes);
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             int b = tid + it * NTHREADS;
-            if (b >= CNT) { st.r[it][0] = z; st.r[it][1] = z; st.r[it][2] = z; st.r[it][3] = z; continue; }
+            act[it] = b < CNT;
             int rb = b % RBLK, kb = b / RBLK;
-            int row = row0 + rb * X::RB;           // global row of the first element
-            int nvalid = bound - row;              // rows valid from here
-            int kbase = kt * X::BK + kb * 4;       // the 4 k of a block never straddle a tap (Ct % 4 == 0)
-            int64_t rowoff = row;
-            int rr = 0, ss = 0, tapk = 0;
+            row[it] = row0 + rb * X::RB;
+            kb0[it] = kt0 * X::BK + kb * 4;        // the 4 k of a block never straddle a tap (Ct % 4 == 0)
+            rowoff[it] = row[it];
+            co[it] = kb0[it]; tap[it] = 0; rr[it] = 0; ss[it] = 0;
             if (mode == CB_KROW_TAPS) {            // weights [Ct][taps][bound] read for a transposed conv
-                int tap = kbase / p.Ct;
-                tapk = tap * p.Ct;
-                int tapw = p.flip ? (p.R * p.S - 1 - tap) : tap;
-                rowoff = (int64_t)tapw * bound + row;
+                tap[it] = kb0[it] / p.Ct;
+                co[it] = kb0[it] - tap[it] * p.Ct;
             } else if (mode == CB_KROW_GATHER) {   // row = (tap, channel) of the gathered image
-                int tap = row / p.Ct;
-                int c = row - tap * p.Ct;
-                rr = tap / p.S; ss = tap - rr * p.S;
-                rowoff = rr * p.sH + ss * p.sW + c;
+                int tp = row[it] / p.Ct;
+                int ch = row[it] - tp * p.Ct;
+                rr[it] = tp / p.S; ss[it] = tp - rr[it] * p.S;
+                rowoff[it] = rr[it] * p.sH + ss[it] * p.sW + ch;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(Stage& st, const GP& p) {
+        u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            if (!act[it]) { st.r[it][0] = z; st.r[it][1] = z; st.r[it][2] = z; st.r[it][3] = z; continue; }
+            const int nvalid = bound - row[it];
+            int64_t ro = rowoff[it];
+            if (mode == CB_KROW_TAPS) {
+                int tapw = p.flip ? (p.R * p.S - 1 - tap[it]) : tap[it];
+                ro = (int64_t)tapw * bound + row[it];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                int k = kbase + j;
+                const int k = kb0[it] + j;
                 bool v = k < p.K && nvalid > 0;
-                const T* src;
+                int64_t e;
                 if (mode == CB_KROW_GATHER) {
                     cb_pixel px = {0, 0, 0};
                     if (v) px = tab[k];
-                    v = v && (unsigned)(px.ih0 + rr) < (unsigned)p.H && (unsigned)(px.iw0 + ss) < (unsigned)p.W;
-                    src = base + px.off + rowoff;
+                    v = v && (unsigned)(px.ih0 + rr[it]) < (unsigned)p.H && (unsigned)(px.iw0 + ss[it]) < (unsigned)p.W;
+                    e = px.off + ro;
+                } else if (mode == CB_KROW_TAPS) {
+                    e = (int64_t)(co[it] + j) * ld + ro;
                 } else {
-                    src = base + (int64_t)(k - tapk) * ld + rowoff;
+                    e = (int64_t)k * ld + ro;
                 }
-                if (!v) st.r[it][j] = z;
-                else if (vec && nvalid >= X::RB) st.r[it][j] = *reinterpret_cast<const u32x4*>(src);
-                else st.r[it][j] = load_guarded<T>(src, nvalid);
+                if constexpr (FAST) {
+                    // rows past `bound` inside a block read neighbouring (in-buffer) data: those tile rows only feed
+                    // outputs the epilogue discards; past the buffer end the descriptor returns zeros
+                    st.r[it][j] = bload16(rs, v ? (uint32_t)e * (uint32_t)ESZ : OOB);
+                } else {
+                    st.r[it][j] = v ? load_guarded<T>(base + e, nvalid) : z;
+                }
+            }
+            kb0[it] += X::BK;
+            if (mode == CB_KROW_TAPS) {
+                co[it] += X::BK;
+                while (co[it] >= p.Ct) { co[it] -= p.Ct; ++tap[it]; }
             }
         }
     }
@@ -179,7 +246,7 @@ template <typename T, int ROWS> struct KrowLoader {
             int b = tid + it * NTHREADS;
             if (b >= CNT) continue;
             int rb = b % RBLK, kb = b / RBLK;
-            int row = rb * X::RB;
+            int r0 = rb * X::RB;
             if constexpr (sizeof(T) == 2) {
                 // st.r[it][j][d] holds rows (2d, 2d+1) at k = kb*4 + j
 #pragma unroll
@@ -187,14 +254,14 @@ template <typename T, int ROWS> struct KrowLoader {
                     uint32_t a0 = st.r[it][0][d], a1 = st.r[it][1][d], a2 = st.r[it][2][d], a3 = st.r[it][3][d];
                     u32x2 even = {(a0 & 0xffffu) | (a1 << 16), (a2 & 0xffffu) | (a3 << 16)};
                     u32x2 odd = {(a0 >> 16) | (a1 & 0xffff0000u), (a2 >> 16) | (a3 & 0xffff0000u)};
-                    *reinterpret_cast<u32x2*>(tile + lds_off<T>(row + 2 * d, kb >> 1) + (kb & 1) * 8) = even;
-                    *reinterpret_cast<u32x2*>(tile + lds_off<T>(row + 2 * d + 1, kb >> 1) + (kb & 1) * 8) = odd;
+                    *reinterpret_cast<u32x2*>(tile + lds_off<T>(r0 + 2 * d, kb >> 1) + (kb & 1) * 8) = even;
+                    *reinterpret_cast<u32x2*>(tile + lds_off<T>(r0 + 2 * d + 1, kb >> 1) + (kb & 1) * 8) = odd;
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     u32x4 o = {st.r[it][0][e], st.r[it][1][e], st.r[it][2][e], st.r[it][3][e]};
-                    *reinterpret_cast<u32x4*>(tile + lds_off<T>(row + e, kb)) = o;
+                    *reinterpret_cast<u32x4*>(tile + lds_off<T>(r0 + e, kb)) = o;
                 }
             }
         }
@@ -266,7 +333,7 @@ __device__ __forceinline__ void epilogue_elem(const GP& p, float x, int m, int64
     }
 }
 
-template <typename T, int BM, int BN, bool A_KROW, bool B_KROW, int PF>
+template <typename T, int BM, int BN, bool A_KROW, bool B_KROW, int PF, bool FAST>
 __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
     using X = Tr<T>;
     constexpr int BK = X::BK;
@@ -282,24 +349,23 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
     const int nt = ((kt0 + kt_per < p.ktiles) ? kt0 + kt_per : p.ktiles) - kt0;
     if (nt <= 0) return;
 
-    const T* Ab = reinterpret_cast<const T*>(p.A);
-    const T* Bb = reinterpret_cast<const T*>(p.B);
-
-    using LA = typename std::conditional<A_KROW, KrowLoader<T, BM>, RowkLoader<T, BM>>::type;
-    using LB = typename std::conditional<B_KROW, KrowLoader<T, BN>, RowkLoader<T, BN>>::type;
+    using LA = typename std::conditional<A_KROW, KrowLoader<T, BM, FAST>, RowkLoader<T, BM, FAST>>::type;
+    using LB = typename std::conditional<B_KROW, KrowLoader<T, BN, FAST>, RowkLoader<T, BN, FAST>>::type;
     LA la;
     LB lb;
-    if constexpr (!A_KROW) la.init(p.a_mode == CB_ROWK_GATHER, p.a_tab, p.lda, m0, p.M, tid);
-    if constexpr (!B_KROW) lb.init(false, nullptr, p.ldb, n0, p.N, tid);
+    {
+        Opnd oa = {p.A, p.a_tab, p.lda, p.a_mode, p.a_bytes};
+        Opnd ob = {p.B, p.b_tab, p.ldb, p.b_mode, p.b_bytes};
+        la.init(p, oa, m0, p.M, kt0, tid);
+        lb.init(p, ob, n0, p.N, kt0, tid);
+    }
     typename LA::Stage sa[PF];
     typename LB::Stage sb[PF];
 
-    auto load_tiles = [&](typename LA::Stage& xa, typename LB::Stage& xb, int t) {
-        const int kt = kt0 + t;
-        if constexpr (A_KROW) la.load(xa, p, Ab, CB_KROW, nullptr, p.lda, p.a_vec, m0, p.M, kt, tid);
-        else la.load(xa, p, Ab, p.a_mode == CB_ROWK_GATHER, p.a_vec, kt, tid);
-        if constexpr (B_KROW) lb.load(xb, p, Bb, p.b_mode, p.b_tab, p.ldb, p.b_vec, n0, p.N, kt, tid);
-        else lb.load(xb, p, Bb, false, p.b_vec, kt, tid);
+    // tiles are loaded strictly in order (the loaders advance their k position on every call)
+    auto load_tiles = [&](typename LA::Stage& xa, typename LB::Stage& xb) {
+        la.load(xa, p);
+        lb.load(xb, p);
     };
     auto store_tiles = [&](const typename LA::Stage& xa, const typename LB::Stage& xb, int buf) {
         unsigned char* As = smem + buf * (TILE_A + TILE_B);
@@ -316,9 +382,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
     // prologue: K-tile j lives in register stage j % PF
 #pragma unroll
     for (int s = 0; s < PF; ++s)
-        if (s < nt) load_tiles(sa[s], sb[s], s);
+        if (s < nt) load_tiles(sa[s], sb[s]);
     store_tiles(sa[0], sb[0], 0);
-    if (PF < nt) load_tiles(sa[0], sb[0], PF);
+    if (PF < nt) load_tiles(sa[0], sb[0]);
     __syncthreads();
 
     int t = 0;
@@ -364,7 +430,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
                 if (t + 1 < nt) {
                     const int S1 = (s + 1) % PF;
                     store_tiles(sa[S1], sb[S1], (t + 1) & 1);
-                    if (t + 1 + PF < nt) load_tiles(sa[S1], sb[S1], t + 1 + PF);
+                    if (t + 1 + PF < nt) load_tiles(sa[S1], sb[S1]);
                 }
                 __syncthreads();
                 ++t;
@@ -431,15 +497,19 @@ __global__ void __launch_bounds__(256) pixel_table_kernel(cb_pixel* tab, int tot
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <typename T, int BM, int BN, int PF>
-int launch_gemm(const GP& p, bool a_krow, bool b_krow, hipStream_t st) {
+template <typename T, int BM, int BN, int PF, bool FAST>
+int launch_gemm2(const GP& p, bool a_krow, bool b_krow, hipStream_t st) {
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.split_k);
     dim3 block(NTHREADS);
-    if (!a_krow && !b_krow) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, false, PF>), grid, block, 0, st, p);
-    else if (!a_krow && b_krow) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, true, PF>), grid, block, 0, st, p);
-    else if (a_krow && b_krow) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, true, true, PF>), grid, block, 0, st, p);
+    if (!a_krow && !b_krow) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, false, PF, FAST>), grid, block, 0, st, p);
+    else if (!a_krow && b_krow) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, true, PF, FAST>), grid, block, 0, st, p);
+    else if (a_krow && b_krow) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, true, true, PF, FAST>), grid, block, 0, st, p);
     else return cb_fail("cb_gemm: unsupported operand mode combination (A KROW with B ROWK)");
     return cb_launch_status("cb_gemm");
+}
+template <typename T, int BM, int BN, int PF>
+int launch_gemm(const GP& p, bool fast, bool a_krow, bool b_krow, hipStream_t st) {
+    return fast ? launch_gemm2<T, BM, BN, PF, true>(p, a_krow, b_krow, st) : launch_gemm2<T, BM, BN, PF, false>(p, a_krow, b_krow, st);
 }
 
 }  // namespace
@@ -477,31 +547,36 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
         CB_REQUIRE(p.Ct > 0, "cb_gemm: Cin (channels per tap) must be set for conv modes");
         CB_REQUIRE(p.Ct % eps == 0, "cb_gemm: channels per tap (%d) must be a multiple of %d", p.Ct, eps);
     }
+    // fast path: 16-byte buffer loads -- every row/tap start 16-byte aligned and operands < 2 GiB
+    const int64_t lim = 0x7fffffffll;
+    bool fast = d->a_bytes > 0 && d->b_bytes > 0 && d->a_bytes < lim && d->b_bytes < lim && aligned16(d->A) && aligned16(d->B);
     if (d->a_mode == CB_ROWK_GATHER) {
         CB_REQUIRE(d->a_tab, "cb_gemm: a_tab missing");
         CB_REQUIRE(d->K == taps * p.Ct, "cb_gemm: K (%d) != R*S*Cin (%d)", d->K, taps * p.Ct);
-        CB_REQUIRE((p.R == 1 || d->sH % eps == 0) && (p.S == 1 || d->sW % eps == 0) && aligned16(d->A),
-                   "cb_gemm: gather strides/base must be 16-byte multiples");
-        p.a_vec = 1;
+        fast = fast && (p.R == 1 || d->sH % eps == 0) && (p.S == 1 || d->sW % eps == 0);
     } else if (d->a_mode == CB_ROWK) {
-        p.a_vec = (d->lda % eps == 0) && (d->K % eps == 0) && aligned16(d->A);
+        fast = fast && (d->lda % eps == 0) && (d->K % eps == 0);
     } else {
-        p.a_vec = (d->lda % eps == 0) && aligned16(d->A);
+        // a 16-byte load that is only partly inside the buffer returns zeros for ALL of it: the last (partial)
+        // row block must still lie inside the buffer
+        const int64_t need = ((int64_t)(d->K - 1) * d->lda + (d->M + eps - 1) / eps * eps) * esz;
+        fast = fast && (d->lda % eps == 0) && (d->M % eps == 0 || need <= d->a_bytes);
     }
     if (d->b_mode == CB_ROWK) {
-        p.b_vec = (d->ldb % eps == 0) && (d->K % eps == 0) && aligned16(d->B);
+        fast = fast && (d->ldb % eps == 0) && (d->K % eps == 0);
     } else if (d->b_mode == CB_KROW) {
-        p.b_vec = (d->ldb % eps == 0) && aligned16(d->B);
+        const int64_t need = ((int64_t)(d->K - 1) * d->ldb + (d->N + eps - 1) / eps * eps) * esz;
+        fast = fast && (d->ldb % eps == 0) && (d->N % eps == 0 || need <= d->b_bytes);
     } else if (d->b_mode == CB_KROW_TAPS) {
         CB_REQUIRE(d->K == taps * p.Ct, "cb_gemm: K (%d) != R*S*Ct (%d)", d->K, taps * p.Ct);
-        p.b_vec = (d->ldb % eps == 0) && (d->N % eps == 0) && aligned16(d->B);
+        fast = fast && (d->ldb % eps == 0) && (d->N % eps == 0);
     } else {
         CB_REQUIRE(d->b_tab, "cb_gemm: b_tab missing");
         CB_REQUIRE(d->N == taps * p.Ct, "cb_gemm: N (%d) != R*S*Cin (%d)", d->N, taps * p.Ct);
-        CB_REQUIRE((p.R == 1 || d->sH % eps == 0) && (p.S == 1 || d->sW % eps == 0) && aligned16(d->B),
-                   "cb_gemm: gather strides/base must be 16-byte multiples");
-        p.b_vec = 1;
+        fast = fast && (p.R == 1 || d->sH % eps == 0) && (p.S == 1 || d->sW % eps == 0);
     }
+    p.a_bytes = (uint32_t)(fast ? d->a_bytes : 0);
+    p.b_bytes = (uint32_t)(fast ? d->b_bytes : 0);
     if (p.split_k > 1) {
         CB_REQUIRE(d->c_f32, "cb_gemm: split_k > 1 needs an fp32 output");
         CB_REQUIRE(!d->C2 && !d->residual && !d->mask && d->act == CB_ACT_NONE && !d->relu_after && !d->shift && d->dropout_p <= 0.f,
@@ -520,14 +595,14 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     p.c_vec = cv;
 
     hipStream_t st = cb_stream(stream);
-    if (d->dtype == CB_F32) return launch_gemm<float, 64, 64, 2>(p, a_krow, b_krow, st);
+    if (d->dtype == CB_F32) return launch_gemm<float, 64, 64, 2>(p, fast, a_krow, b_krow, st);
     int tile = d->tile;
     if (tile == 0) {
         int64_t blocks128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * p.split_k;
         tile = blocks128 >= 160 ? 1 : 2;
     }
-    if (tile == 1) return launch_gemm<bf16, 128, 128, 2>(p, a_krow, b_krow, st);
-    return launch_gemm<bf16, 64, 64, 3>(p, a_krow, b_krow, st);
+    if (tile == 1) return launch_gemm<bf16, 128, 128, 2>(p, fast, a_krow, b_krow, st);
+    return launch_gemm<bf16, 64, 64, 3>(p, fast, a_krow, b_krow, st);
 }
 
 extern "C" int cb_build_pixel_table(cb_pixel* tab, int32_t N, int32_t OH, int32_t OW, int32_t stride, int32_t pad,

@@ -32,6 +32,11 @@ def _ptr(t: Optional[torch.Tensor]):
     return t.data_ptr()
 
 
+def _extent_bytes(t: torch.Tensor) -> int:
+    """bytes from data_ptr() to the end of the tensor's storage (upper bound of any strided view)"""
+    return t.untyped_storage().nbytes() - t.storage_offset() * t.element_size()
+
+
 def _stream(t: torch.Tensor):
     if t.is_cuda:
         return torch.cuda.current_stream(t.device).cuda_stream
@@ -79,6 +84,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch
     d.dropout_seed = dropout_seed
     d.dropout_seed_ptr = _ptr(seed_ptr)
     d.tile = tile
+    d.a_bytes = _extent_bytes(a)
+    d.b_bytes = _extent_bytes(b)
     _chk(_lib.get().cb_gemm(C.byref(d), _stream(a)), "cb_gemm")
     return out
 

@@ -80,6 +80,9 @@ typedef struct {
     const uint64_t* dropout_seed_ptr;  /* optional DEVICE word added to the seed (varies per hipGraph replay) */
     int32_t tile;             /* 0 auto, 1 = 128x128, 2 = 64x64                                      */
     int32_t reserved2;
+    int64_t a_bytes, b_bytes; /* sizes of the A / B buffers in bytes (0 = unknown).  When both are known, < 2 GiB
+                                 and every row / tap start is 16-byte aligned the kernel uses range-checked
+                                 buffer loads (fast path); otherwise element-wise guarded loads.           */
 } cb_gemm_desc;
 
 /* GEMM / implicit-GEMM convolution, all forms.  Replaces torch.nn.Linear / F.conv2d (+ apex-amp

@@ -180,6 +180,19 @@ static inline emul_f32x4 emul_mfma_f32_16x16x4f32(float a, float b, emul_f32x4 c
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emul_mfma_f32_16x16x4f32
 
+// ---- buffer descriptor loads (range-checked: offsets past num_records read zeros) --------------------
+struct emul_rsrc { const unsigned char* base; uint32_t n; };
+static inline emul_rsrc emul_make_buffer_rsrc(void* p, short, int n, int) { return emul_rsrc{(const unsigned char*)p, (uint32_t)n}; }
+typedef __attribute__((ext_vector_type(4))) uint32_t emul_u32x4;
+static inline emul_u32x4 emul_raw_buffer_load_b128(emul_rsrc r, uint32_t voff, uint32_t soff, int) {
+    emul_u32x4 v = {0u, 0u, 0u, 0u};
+    uint64_t o = (uint64_t)voff + soff;
+    if (o + 16 <= r.n) memcpy(&v, r.base + o, 16);
+    return v;
+}
+#define __builtin_amdgcn_make_buffer_rsrc emul_make_buffer_rsrc
+#define __builtin_amdgcn_raw_buffer_load_b128 emul_raw_buffer_load_b128
+
 // ---- atomics -------------------------------------------------------------------------------
 static inline float atomicAdd(float* p, float v) {
     uint32_t* u = reinterpret_cast<uint32_t*>(p);

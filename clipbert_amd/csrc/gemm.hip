@@ -387,48 +387,66 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
     if (PF < nt) load_tiles(sa[0], sb[0]);
     __syncthreads();
 
+    auto compute_tile = [&](int buf) {
+        const unsigned char* As = smem + buf * (TILE_A + TILE_B);
+        const unsigned char* Bs = As + TILE_A;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int kk = 0; kk < BK / 32; ++kk) {
+                bf16x8 af[FM], bfr[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off<T>(wm * WM + i * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<T>(wn * WN + j * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                float af[FM], bfr[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    af[i] = *reinterpret_cast<const float*>(As + lds_off<T>(wm * WM + i * 16 + (lane & 15), kk) + (lane >> 4) * 4);
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    bfr[j] = *reinterpret_cast<const float*>(Bs + lds_off<T>(wn * WN + j * 16 + (lane & 15), kk) + (lane >> 4) * 4);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
     int t = 0;
-    while (t < nt) {
+    // steady state: branch-free body (compute tile t, stage tile t+1 into LDS, issue the loads of tile t+1+PF),
+    // so the PF register stages really stay in flight across iterations
+    while (t + 2 * PF < nt) {
 #pragma unroll
         for (int s = 0; s < PF; ++s) {            // t % PF == s: static register-stage indices
+            const int S1 = (s + 1) % PF;
+            compute_tile(t & 1);
+            store_tiles(sa[S1], sb[S1], (t + 1) & 1);
+            load_tiles(sa[S1], sb[S1]);
+            __syncthreads();
+            ++t;
+        }
+    }
+    // tail: at most 2*PF tiles, guarded
+    while (t < nt) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
             if (t < nt) {
-                const unsigned char* As = smem + (t & 1) * (TILE_A + TILE_B);
-                const unsigned char* Bs = As + TILE_A;
-                if constexpr (sizeof(T) == 2) {
-#pragma unroll
-                    for (int kk = 0; kk < BK / 32; ++kk) {
-                        bf16x8 af[FM], bfr[FN];
-#pragma unroll
-                        for (int i = 0; i < FM; ++i)
-                            af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off<T>(wm * WM + i * 16 + (lane & 15), kk * 4 + (lane >> 4)));
-#pragma unroll
-                        for (int j = 0; j < FN; ++j)
-                            bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<T>(wn * WN + j * 16 + (lane & 15), kk * 4 + (lane >> 4)));
-#pragma unroll
-                        for (int i = 0; i < FM; ++i)
-#pragma unroll
-                            for (int j = 0; j < FN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int kk = 0; kk < BK / 4; ++kk) {
-                        float af[FM], bfr[FN];
-#pragma unroll
-                        for (int i = 0; i < FM; ++i)
-                            af[i] = *reinterpret_cast<const float*>(As + lds_off<T>(wm * WM + i * 16 + (lane & 15), kk) + (lane >> 4) * 4);
-#pragma unroll
-                        for (int j = 0; j < FN; ++j)
-                            bfr[j] = *reinterpret_cast<const float*>(Bs + lds_off<T>(wn * WN + j * 16 + (lane & 15), kk) + (lane >> 4) * 4);
-#pragma unroll
-                        for (int i = 0; i < FM; ++i)
-#pragma unroll
-                            for (int j = 0; j < FN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[j], af[i], acc[i][j], 0, 0, 0);
-                    }
-                }
+                const int S1 = (s + 1) % PF;
+                compute_tile(t & 1);
                 if (t + 1 < nt) {
-                    const int S1 = (s + 1) % PF;
                     store_tiles(sa[S1], sb[S1], (t + 1) & 1);
                     if (t + 1 + PF < nt) load_tiles(sa[S1], sb[S1]);
                 }

@@ -122,7 +122,7 @@ template <typename T, int ROWS, bool FAST> struct RowkLoader {
             boff[i] = ok[i] ? (uint32_t)e * (uint32_t)ESZ : OOB;
         }
     }
-    __device__ __forceinline__ void load(Stage& st, const GP& p) {
+    template <bool CHECK> __device__ __forceinline__ void load(Stage& st, const GP& p) {
         const bool kv = gather ? (rr < p.R) : (c < p.K);
         const int klim = gather ? p.Ct : p.K;
         const int64_t tapoff = gather ? (rr * p.sH + ss * p.sW) : 0;
@@ -199,7 +199,7 @@ template <typename T, int ROWS, bool FAST> struct KrowLoader {
             }
         }
     }
-    __device__ __forceinline__ void load(Stage& st, const GP& p) {
+    template <bool CHECK> __device__ __forceinline__ void load(Stage& st, const GP& p) {
         u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
@@ -249,6 +249,195 @@ template <typename T, int ROWS, bool FAST> struct KrowLoader {
             int r0 = rb * X::RB;
             if constexpr (sizeof(T) == 2) {
                 // st.r[it][j][d] holds rows (2d, 2d+1) at k = kb*4 + j
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    uint32_t a0 = st.r[it][0][d], a1 = st.r[it][1][d], a2 = st.r[it][2][d], a3 = st.r[it][3][d];
+                    u32x2 even = {(a0 & 0xffffu) | (a1 << 16), (a2 & 0xffffu) | (a3 << 16)};
+                    u32x2 odd = {(a0 >> 16) | (a1 & 0xffff0000u), (a2 >> 16) | (a3 & 0xffff0000u)};
+                    *reinterpret_cast<u32x2*>(tile + lds_off<T>(r0 + 2 * d, kb >> 1) + (kb & 1) * 8) = even;
+                    *reinterpret_cast<u32x2*>(tile + lds_off<T>(r0 + 2 * d + 1, kb >> 1) + (kb & 1) * 8) = odd;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u32x4 o = {st.r[it][0][e], st.r[it][1][e], st.r[it][2][e], st.r[it][3][e]};
+                    *reinterpret_cast<u32x4*>(tile + lds_off<T>(r0 + e, kb)) = o;
+                }
+            }
+        }
+    }
+};
+
+// =============================================================================================
+// FAST loaders (compile-time addressing mode, range-checked buffer loads): the steady-state K loop costs
+// one v_add + one buffer_load per 16 bytes (plus two compares per load for convolution gathers).
+// =============================================================================================
+enum { KM_PLAIN = 0, KM_TAPS = 1, KM_GATHER = 2 };
+
+template <typename T, int ROWS, bool GATHER> struct RowkFast {
+    using X = Tr<T>;
+    static constexpr int NS = ROWS * X::SEGS / NTHREADS;
+    static constexpr uint32_t ESZ = (uint32_t)sizeof(T);
+    struct Stage { u32x4 r[NS]; };
+    rsrc_t rs;
+    uint32_t voff[NS];          // byte offset of this thread's segment (k position included unless GATHER), or OOB
+    int ih[NS], iw[NS];         // GATHER: top-left input pixel of the row's receptive field
+    int c, rr, ss;              // GATHER: channel within the tap, tap = (rr, ss)
+    int krem;                   // !GATHER: K - (k of this thread's segment)
+
+    __device__ __forceinline__ void init(const GP& p, const Opnd& o, int row0, int bound, int kt0, int tid) {
+        rs = make_rsrc(o.base, o.bytes);
+        const int k = kt0 * X::BK + (tid % X::SEGS) * X::EPS;
+        c = k; rr = 0; ss = 0; krem = p.K - k;
+        if constexpr (GATHER) {
+            int tap = k / p.Ct;
+            c = k - tap * p.Ct;
+            rr = tap / p.S; ss = tap - rr * p.S;
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int row = row0 + (tid + i * NTHREADS) / X::SEGS;
+            const bool ok = row < bound;
+            ih[i] = 0; iw[i] = 0;
+            if constexpr (GATHER) {
+                cb_pixel px = {0, 0, 0};
+                if (ok) px = o.tab[row];
+                ih[i] = px.ih0; iw[i] = px.iw0;
+                voff[i] = ok ? (uint32_t)px.off * ESZ : OOB;
+            } else {
+                voff[i] = ok ? ((uint32_t)row * (uint32_t)o.ld + (uint32_t)k) * ESZ : OOB;
+            }
+        }
+    }
+    template <bool CHECK> __device__ __forceinline__ void load(Stage& st, const GP& p) {
+        if constexpr (GATHER) {
+            const bool kv = rr < p.R;
+            const uint32_t koff = (uint32_t)(rr * (int)p.sH + ss * (int)p.sW + c) * ESZ;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const bool v = kv && (unsigned)(ih[i] + rr) < (unsigned)p.H && (unsigned)(iw[i] + ss) < (unsigned)p.W;
+                st.r[i] = bload16(rs, v ? voff[i] + koff : OOB);
+            }
+            if (p.Ct >= X::BK) {
+                c += X::BK;
+                if (c >= p.Ct) { c -= p.Ct; if (++ss == p.S) { ss = 0; ++rr; } }
+            } else {                                   // several taps per K step (stem: 32 channels per tap)
+                ss += X::BK / p.Ct;
+                while (ss >= p.S) { ss -= p.S; ++rr; }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                uint32_t o32 = voff[i];
+                if (CHECK && krem <= 0) o32 = OOB;
+                st.r[i] = bload16(rs, o32);
+                voff[i] += X::BK * ESZ;
+            }
+            krem -= X::BK;
+        }
+    }
+    __device__ __forceinline__ void store(const Stage& st, unsigned char* tile, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            int idx = tid + i * NTHREADS;
+            *reinterpret_cast<u32x4*>(tile + lds_off<T>(idx / X::SEGS, idx % X::SEGS)) = st.r[i];
+        }
+    }
+};
+
+template <typename T, int ROWS, int KMODE> struct KrowFast {
+    using X = Tr<T>;
+    static constexpr int RBLK = ROWS / X::RB;
+    static constexpr int CNT = RBLK * (X::BK / 4);
+    static constexpr int NI = (CNT + NTHREADS - 1) / NTHREADS;
+    static constexpr uint32_t ESZ = (uint32_t)sizeof(T);
+    struct Stage { u32x4 r[NI][4]; };
+    rsrc_t rs;
+    const cb_pixel* tab;
+    uint32_t ldb;               // bytes between consecutive reduction indices
+    uint32_t voff[NI];          // PLAIN: byte offset of (k = kb0, row) | TAPS/GATHER: byte offset contributed by the row
+    int kb0[NI];                // k of the block's first line
+    int co[NI], tap[NI];        // TAPS
+    int rr[NI], ss[NI];         // GATHER
+    cb_pixel px[NI][4];         // GATHER: table entries of the NEXT tile (prefetched one call ahead)
+    bool act[NI];
+    uint32_t bound;
+
+    __device__ __forceinline__ void init(const GP& p, const Opnd& o, int row0, int bnd, int kt0, int tid) {
+        rs = make_rsrc(o.base, o.bytes);
+        tab = o.tab; ldb = (uint32_t)o.ld * ESZ; bound = (uint32_t)bnd;
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int b = tid + it * NTHREADS;
+            const int rb = b % RBLK, kb = b / RBLK;
+            const int row = row0 + rb * X::RB;
+            act[it] = (b < CNT) && (row < bnd);
+            kb0[it] = kt0 * X::BK + kb * 4;
+            co[it] = kb0[it]; tap[it] = 0; rr[it] = 0; ss[it] = 0;
+            if constexpr (KMODE == KM_PLAIN) {
+                voff[it] = ((uint32_t)kb0[it] * (uint32_t)o.ld + (uint32_t)row) * ESZ;
+            } else if constexpr (KMODE == KM_TAPS) {        // weights [Ct][taps][bound] of a transposed conv
+                tap[it] = kb0[it] / p.Ct;
+                co[it] = kb0[it] - tap[it] * p.Ct;
+                voff[it] = (uint32_t)row * ESZ;
+            } else {                                        // row = (tap, channel) of the gathered image
+                const int tp = row / p.Ct, ch = row - tp * p.Ct;
+                rr[it] = tp / p.S; ss[it] = tp - rr[it] * p.S;
+                voff[it] = (uint32_t)(rr[it] * (int)p.sH + ss[it] * (int)p.sW + ch) * ESZ;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    cb_pixel e = {0, (int16_t)-30000, (int16_t)-30000};
+                    if (act[it] && kb0[it] + j < p.K) e = tab[kb0[it] + j];
+                    px[it][j] = e;
+                }
+            }
+        }
+    }
+    template <bool CHECK> __device__ __forceinline__ void load(Stage& st, const GP& p) {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            if constexpr (KMODE == KM_PLAIN) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bool v = act[it];
+                    if (CHECK) v = v && (kb0[it] + j < p.K);
+                    st.r[it][j] = bload16(rs, v ? voff[it] + (uint32_t)j * ldb : OOB);
+                }
+                voff[it] += X::BK * ldb;
+                kb0[it] += X::BK;
+            } else if constexpr (KMODE == KM_TAPS) {
+                const int tapw = p.flip ? (p.R * p.S - 1 - tap[it]) : tap[it];
+                const bool v = act[it] && tap[it] < p.R * p.S;
+                const uint32_t base = (uint32_t)co[it] * ldb + (uint32_t)tapw * bound * ESZ + voff[it];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) st.r[it][j] = bload16(rs, v ? base + (uint32_t)j * ldb : OOB);
+                co[it] += X::BK;
+                while (co[it] >= p.Ct) { co[it] -= p.Ct; ++tap[it]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const cb_pixel e = px[it][j];
+                    const bool v = (unsigned)(e.ih0 + rr[it]) < (unsigned)p.H && (unsigned)(e.iw0 + ss[it]) < (unsigned)p.W;
+                    st.r[it][j] = bload16(rs, v ? (uint32_t)e.off * ESZ + voff[it] : OOB);
+                }
+                kb0[it] += X::BK;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {               // table entries of the next K tile
+                    cb_pixel e = {0, (int16_t)-30000, (int16_t)-30000};
+                    if (act[it] && kb0[it] + j < p.K) e = tab[kb0[it] + j];
+                    px[it][j] = e;
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void store(const Stage& st, unsigned char* tile, int tid) const {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int b = tid + it * NTHREADS;
+            if (b >= CNT) continue;
+            const int rb = b % RBLK, kb = b / RBLK;
+            const int r0 = rb * X::RB;
+            if constexpr (sizeof(T) == 2) {
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     uint32_t a0 = st.r[it][0][d], a1 = st.r[it][1][d], a2 = st.r[it][2][d], a3 = st.r[it][3][d];
@@ -333,7 +522,7 @@ __device__ __forceinline__ void epilogue_elem(const GP& p, float x, int m, int64
     }
 }
 
-template <typename T, int BM, int BN, bool A_KROW, bool B_KROW, int PF, bool FAST>
+template <typename T, int BM, int BN, typename LA, typename LB, int PF>
 __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
     using X = Tr<T>;
     constexpr int BK = X::BK;
@@ -349,8 +538,6 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
     const int nt = ((kt0 + kt_per < p.ktiles) ? kt0 + kt_per : p.ktiles) - kt0;
     if (nt <= 0) return;
 
-    using LA = typename std::conditional<A_KROW, KrowLoader<T, BM, FAST>, RowkLoader<T, BM, FAST>>::type;
-    using LB = typename std::conditional<B_KROW, KrowLoader<T, BN, FAST>, RowkLoader<T, BN, FAST>>::type;
     LA la;
     LB lb;
     {
@@ -363,9 +550,13 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
     typename LB::Stage sb[PF];
 
     // tiles are loaded strictly in order (the loaders advance their k position on every call)
-    auto load_tiles = [&](typename LA::Stage& xa, typename LB::Stage& xb) {
-        la.load(xa, p);
-        lb.load(xb, p);
+    auto load_tiles = [&](typename LA::Stage& xa, typename LB::Stage& xb) {      // steady state: full K tiles only
+        la.template load<false>(xa, p);
+        lb.template load<false>(xb, p);
+    };
+    auto load_tiles_checked = [&](typename LA::Stage& xa, typename LB::Stage& xb) {
+        la.template load<true>(xa, p);
+        lb.template load<true>(xb, p);
     };
     auto store_tiles = [&](const typename LA::Stage& xa, const typename LB::Stage& xb, int buf) {
         unsigned char* As = smem + buf * (TILE_A + TILE_B);
@@ -382,9 +573,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
     // prologue: K-tile j lives in register stage j % PF
 #pragma unroll
     for (int s = 0; s < PF; ++s)
-        if (s < nt) load_tiles(sa[s], sb[s]);
+        if (s < nt) load_tiles_checked(sa[s], sb[s]);
     store_tiles(sa[0], sb[0], 0);
-    if (PF < nt) load_tiles(sa[0], sb[0]);
+    if (PF < nt) load_tiles_checked(sa[0], sb[0]);
     __syncthreads();
 
     auto compute_tile = [&](int buf) {
@@ -428,7 +619,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
     int t = 0;
     // steady state: branch-free body (compute tile t, stage tile t+1 into LDS, issue the loads of tile t+1+PF),
     // so the PF register stages really stay in flight across iterations
-    while (t + 2 * PF < nt) {
+    while (t + 2 * PF < nt - 1) {                 // ... and never the last (possibly partial) K tile
 #pragma unroll
         for (int s = 0; s < PF; ++s) {            // t % PF == s: static register-stage indices
             const int S1 = (s + 1) % PF;
@@ -439,7 +630,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
             ++t;
         }
     }
-    // tail: at most 2*PF tiles, guarded
+    // tail: at most 2*PF+1 tiles, guarded (K tail handled by the checked loads)
     while (t < nt) {
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
@@ -448,7 +639,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
                 compute_tile(t & 1);
                 if (t + 1 < nt) {
                     store_tiles(sa[S1], sb[S1], (t + 1) & 1);
-                    if (t + 1 + PF < nt) load_tiles(sa[S1], sb[S1]);
+                    if (t + 1 + PF < nt) load_tiles_checked(sa[S1], sb[S1]);
                 }
                 __syncthreads();
                 ++t;
@@ -515,19 +706,37 @@ __global__ void __launch_bounds__(256) pixel_table_kernel(cb_pixel* tab, int tot
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <typename T, int BM, int BN, int PF, bool FAST>
-int launch_gemm2(const GP& p, bool a_krow, bool b_krow, hipStream_t st) {
+template <typename T, int BM, int BN, int PF, typename LA, typename LB>
+int launch_k(const GP& p, hipStream_t st) {
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.split_k);
-    dim3 block(NTHREADS);
-    if (!a_krow && !b_krow) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, false, PF, FAST>), grid, block, 0, st, p);
-    else if (!a_krow && b_krow) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, true, PF, FAST>), grid, block, 0, st, p);
-    else if (a_krow && b_krow) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, true, true, PF, FAST>), grid, block, 0, st, p);
-    else return cb_fail("cb_gemm: unsupported operand mode combination (A KROW with B ROWK)");
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, LA, LB, PF>), grid, dim3(NTHREADS), 0, st, p);
     return cb_launch_status("cb_gemm");
 }
+
+// addressing-mode dispatch: lean compile-time loaders on the fast path, the generic loaders otherwise
 template <typename T, int BM, int BN, int PF>
-int launch_gemm(const GP& p, bool fast, bool a_krow, bool b_krow, hipStream_t st) {
-    return fast ? launch_gemm2<T, BM, BN, PF, true>(p, a_krow, b_krow, st) : launch_gemm2<T, BM, BN, PF, false>(p, a_krow, b_krow, st);
+int launch_gemm(const GP& p, bool fast, hipStream_t st) {
+    const bool a_krow = p.a_mode == CB_KROW;
+    const bool b_krow = p.b_mode != CB_ROWK;
+    if (a_krow && !b_krow) return cb_fail("cb_gemm: unsupported operand mode combination (A KROW with B ROWK)");
+    if (fast) {
+        const int taps = p.R * p.S;
+        if (p.a_mode == CB_ROWK && p.b_mode == CB_ROWK)
+            return launch_k<T, BM, BN, PF, RowkFast<T, BM, false>, RowkFast<T, BN, false>>(p, st);
+        if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_ROWK)
+            return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, RowkFast<T, BN, false>>(p, st);
+        if (p.a_mode == CB_ROWK && (p.b_mode == CB_KROW || (p.b_mode == CB_KROW_TAPS && taps == 1)))
+            return launch_k<T, BM, BN, PF, RowkFast<T, BM, false>, KrowFast<T, BN, KM_PLAIN>>(p, st);
+        if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_KROW_TAPS)
+            return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, KrowFast<T, BN, KM_TAPS>>(p, st);
+        if (p.a_mode == CB_KROW && p.b_mode == CB_KROW)
+            return launch_k<T, BM, BN, PF, KrowFast<T, BM, KM_PLAIN>, KrowFast<T, BN, KM_PLAIN>>(p, st);
+        if (p.a_mode == CB_KROW && p.b_mode == CB_KROW_GATHER)
+            return launch_k<T, BM, BN, PF, KrowFast<T, BM, KM_PLAIN>, KrowFast<T, BN, KM_GATHER>>(p, st);
+    }
+    if (!a_krow && !b_krow) return launch_k<T, BM, BN, PF, RowkLoader<T, BM, false>, RowkLoader<T, BN, false>>(p, st);
+    if (!a_krow) return launch_k<T, BM, BN, PF, RowkLoader<T, BM, false>, KrowLoader<T, BN, false>>(p, st);
+    return launch_k<T, BM, BN, PF, KrowLoader<T, BM, false>, KrowLoader<T, BN, false>>(p, st);
 }
 
 }  // namespace
@@ -613,14 +822,14 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     p.c_vec = cv;
 
     hipStream_t st = cb_stream(stream);
-    if (d->dtype == CB_F32) return launch_gemm<float, 64, 64, 2>(p, fast, a_krow, b_krow, st);
+    if (d->dtype == CB_F32) return launch_gemm<float, 64, 64, 2>(p, fast, st);
     int tile = d->tile;
     if (tile == 0) {
         int64_t blocks128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * p.split_k;
         tile = blocks128 >= 160 ? 1 : 2;
     }
-    if (tile == 1) return launch_gemm<bf16, 128, 128, 2>(p, fast, a_krow, b_krow, st);
-    return launch_gemm<bf16, 64, 64, 3>(p, fast, a_krow, b_krow, st);
+    if (tile == 1) return launch_gemm<bf16, 128, 128, 2>(p, fast, st);
+    return launch_gemm<bf16, 64, 64, 3>(p, fast, st);
 }
 
 extern "C" int cb_build_pixel_table(cb_pixel* tab, int32_t N, int32_t OH, int32_t OW, int32_t stride, int32_t pad,

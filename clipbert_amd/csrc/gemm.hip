@@ -345,13 +345,18 @@ template <typename T, int ROWS, bool GATHER> struct RowkFast {
     }
 };
 
+// KB = k-lines per thread block: 8 for 128-row bf16 tiles (8x8 transpose -> ds_write_b128), else 4.
+// Lane mapping: the k-block index varies fastest, so the lanes of one LDS write group fill ONE tile row
+// (all 32 banks, conflict-free) while lanes 8/16 apart read adjacent 16-byte chunks of the same k-line.
 template <typename T, int ROWS, int KMODE> struct KrowFast {
     using X = Tr<T>;
+    static constexpr int KB = (sizeof(T) == 2 && ROWS >= 128) ? 8 : 4;
+    static constexpr int NKB = X::BK / KB;
     static constexpr int RBLK = ROWS / X::RB;
-    static constexpr int CNT = RBLK * (X::BK / 4);
+    static constexpr int CNT = RBLK * NKB;
     static constexpr int NI = (CNT + NTHREADS - 1) / NTHREADS;
     static constexpr uint32_t ESZ = (uint32_t)sizeof(T);
-    struct Stage { u32x4 r[NI][4]; };
+    struct Stage { u32x4 r[NI][KB]; };
     rsrc_t rs;
     const cb_pixel* tab;
     uint32_t ldb;               // bytes between consecutive reduction indices
@@ -359,7 +364,7 @@ template <typename T, int ROWS, int KMODE> struct KrowFast {
     int kb0[NI];                // k of the block's first line
     int co[NI], tap[NI];        // TAPS
     int rr[NI], ss[NI];         // GATHER
-    cb_pixel px[NI][4];         // GATHER: table entries of the NEXT tile (prefetched one call ahead)
+    cb_pixel px[NI][KB];        // GATHER: table entries of the NEXT tile (prefetched one call ahead)
     bool act[NI];
     uint32_t bound;
 
@@ -369,10 +374,10 @@ template <typename T, int ROWS, int KMODE> struct KrowFast {
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             const int b = tid + it * NTHREADS;
-            const int rb = b % RBLK, kb = b / RBLK;
+            const int kb = b % NKB, rb = b / NKB;
             const int row = row0 + rb * X::RB;
             act[it] = (b < CNT) && (row < bnd);
-            kb0[it] = kt0 * X::BK + kb * 4;
+            kb0[it] = kt0 * X::BK + kb * KB;
             co[it] = kb0[it]; tap[it] = 0; rr[it] = 0; ss[it] = 0;
             if constexpr (KMODE == KM_PLAIN) {
                 voff[it] = ((uint32_t)kb0[it] * (uint32_t)o.ld + (uint32_t)row) * ESZ;
@@ -385,7 +390,7 @@ template <typename T, int ROWS, int KMODE> struct KrowFast {
                 rr[it] = tp / p.S; ss[it] = tp - rr[it] * p.S;
                 voff[it] = (uint32_t)(rr[it] * (int)p.sH + ss[it] * (int)p.sW + ch) * ESZ;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < KB; ++j) {
                     cb_pixel e = {0, (int16_t)-30000, (int16_t)-30000};
                     if (act[it] && kb0[it] + j < p.K) e = tab[kb0[it] + j];
                     px[it][j] = e;
@@ -398,31 +403,31 @@ template <typename T, int ROWS, int KMODE> struct KrowFast {
         for (int it = 0; it < NI; ++it) {
             if constexpr (KMODE == KM_PLAIN) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < KB; ++j) {
                     bool v = act[it];
                     if (CHECK) v = v && (kb0[it] + j < p.K);
                     st.r[it][j] = bload16(rs, v ? voff[it] + (uint32_t)j * ldb : OOB);
                 }
                 voff[it] += X::BK * ldb;
                 kb0[it] += X::BK;
-            } else if constexpr (KMODE == KM_TAPS) {
+            } else if constexpr (KMODE == KM_TAPS) {        // (Ct % 8 == 0: a block never straddles a tap)
                 const int tapw = p.flip ? (p.R * p.S - 1 - tap[it]) : tap[it];
                 const bool v = act[it] && tap[it] < p.R * p.S;
                 const uint32_t base = (uint32_t)co[it] * ldb + (uint32_t)tapw * bound * ESZ + voff[it];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) st.r[it][j] = bload16(rs, v ? base + (uint32_t)j * ldb : OOB);
+                for (int j = 0; j < KB; ++j) st.r[it][j] = bload16(rs, v ? base + (uint32_t)j * ldb : OOB);
                 co[it] += X::BK;
                 while (co[it] >= p.Ct) { co[it] -= p.Ct; ++tap[it]; }
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < KB; ++j) {
                     const cb_pixel e = px[it][j];
                     const bool v = (unsigned)(e.ih0 + rr[it]) < (unsigned)p.H && (unsigned)(e.iw0 + ss[it]) < (unsigned)p.W;
                     st.r[it][j] = bload16(rs, v ? (uint32_t)e.off * ESZ + voff[it] : OOB);
                 }
                 kb0[it] += X::BK;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {               // table entries of the next K tile
+                for (int j = 0; j < KB; ++j) {              // table entries of the next K tile
                     cb_pixel e = {0, (int16_t)-30000, (int16_t)-30000};
                     if (act[it] && kb0[it] + j < p.K) e = tab[kb0[it] + j];
                     px[it][j] = e;
@@ -435,14 +440,28 @@ template <typename T, int ROWS, int KMODE> struct KrowFast {
         for (int it = 0; it < NI; ++it) {
             const int b = tid + it * NTHREADS;
             if (b >= CNT) continue;
-            const int rb = b % RBLK, kb = b / RBLK;
+            const int kb = b % NKB, rb = b / NKB;
             const int r0 = rb * X::RB;
-            if constexpr (sizeof(T) == 2) {
+            if constexpr (sizeof(T) == 2 && KB == 8) {
+                // 8x8 16-bit transpose: st.r[it][j][d] holds rows (2d, 2d+1) at k = kb*8 + j; one 16-byte store per row
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    uint32_t a0 = st.r[it][0][d], a1 = st.r[it][1][d], a2 = st.r[it][2][d], a3 = st.r[it][3][d];
-                    u32x2 even = {(a0 & 0xffffu) | (a1 << 16), (a2 & 0xffffu) | (a3 << 16)};
-                    u32x2 odd = {(a0 >> 16) | (a1 & 0xffff0000u), (a2 >> 16) | (a3 & 0xffff0000u)};
+                    u32x4 even, odd;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        even[q] = __builtin_amdgcn_perm(st.r[it][2 * q + 1][d], st.r[it][2 * q][d], 0x05040100u);
+                        odd[q] = __builtin_amdgcn_perm(st.r[it][2 * q + 1][d], st.r[it][2 * q][d], 0x07060302u);
+                    }
+                    *reinterpret_cast<u32x4*>(tile + lds_off<T>(r0 + 2 * d, kb)) = even;
+                    *reinterpret_cast<u32x4*>(tile + lds_off<T>(r0 + 2 * d + 1, kb)) = odd;
+                }
+            } else if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    u32x2 even = {__builtin_amdgcn_perm(st.r[it][1][d], st.r[it][0][d], 0x05040100u),
+                                  __builtin_amdgcn_perm(st.r[it][3][d], st.r[it][2][d], 0x05040100u)};
+                    u32x2 odd = {__builtin_amdgcn_perm(st.r[it][1][d], st.r[it][0][d], 0x07060302u),
+                                 __builtin_amdgcn_perm(st.r[it][3][d], st.r[it][2][d], 0x07060302u)};
                     *reinterpret_cast<u32x2*>(tile + lds_off<T>(r0 + 2 * d, kb >> 1) + (kb & 1) * 8) = even;
                     *reinterpret_cast<u32x2*>(tile + lds_off<T>(r0 + 2 * d + 1, kb >> 1) + (kb & 1) * 8) = odd;
                 }

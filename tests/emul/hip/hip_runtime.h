@@ -193,6 +193,19 @@ static inline emul_u32x4 emul_raw_buffer_load_b128(emul_rsrc r, uint32_t voff, u
 #define __builtin_amdgcn_make_buffer_rsrc emul_make_buffer_rsrc
 #define __builtin_amdgcn_raw_buffer_load_b128 emul_raw_buffer_load_b128
 
+// v_perm_b32: result byte i = byte sel[i] of the 8 bytes {s1 (0..3), s0 (4..7)}
+static inline uint32_t emul_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
+    uint64_t src = ((uint64_t)s0 << 32) | s1;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) {
+        uint32_t b = (sel >> (8 * i)) & 0xff;
+        uint32_t v = b < 8 ? (uint32_t)((src >> (8 * b)) & 0xff) : (b >= 0xd ? 0xffu : 0u);
+        r |= v << (8 * i);
+    }
+    return r;
+}
+#define __builtin_amdgcn_perm emul_perm
+
 // ---- atomics -------------------------------------------------------------------------------
 static inline float atomicAdd(float* p, float v) {
     uint32_t* u = reinterpret_cast<uint32_t*>(p);

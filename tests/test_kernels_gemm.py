@@ -36,14 +36,17 @@ def test_linear_forward_epilogues(hw, dt, M, N, K, tile):
 
 
 @pytest.mark.parametrize("dt", DT)
-def test_linear_dgrad_wgrad(hw, dt):
+@pytest.mark.parametrize("tile", [2, 1])
+def test_linear_dgrad_wgrad(hw, dt, tile):
+    if dt == torch.float32 and tile == 1:
+        pytest.skip("fp32 parity mode has one tile size")
     M, N, K = 70, 48, 64
     x, w, g = hw(rnd(M, K, seed=1).to(dt)), hw(rnd(N, K, seed=2, scale=0.2).to(dt)), hw(rnd(M, N, seed=3).to(dt))
     dx = torch.empty(M, K, dtype=dt, device=hw.dev)
-    ops.gemm(g, w, M, K, N, out=dx, b_mode=ops.KROW)                      # dX = g W
+    ops.gemm(g, w, M, K, N, out=dx, b_mode=ops.KROW, tile=tile)           # dX = g W
     torch.testing.assert_close(dx.float(), g.float() @ w.float(), **tol(dt))
     dw = torch.zeros(N, K, dtype=torch.float32, device=hw.dev)
-    ops.gemm(g, x, N, K, M, out=dw, a_mode=ops.KROW, b_mode=ops.KROW, accumulate=True, split_k=3)   # dW = g^T x
+    ops.gemm(g, x, N, K, M, out=dw, a_mode=ops.KROW, b_mode=ops.KROW, accumulate=True, split_k=3, tile=tile)   # dW = g^T x
     torch.testing.assert_close(dw, g.float().t() @ x.float(), **tol(dt))
     # tiny / unaligned head shapes (num_labels = 2): scalar guarded loaders
     g2, w2 = hw(rnd(M, 2, seed=5).to(dt)), hw(rnd(2, K, seed=6).to(dt))
@@ -60,8 +63,11 @@ def _nhwc(x):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("tile", [2, 1])
 @pytest.mark.parametrize("k,stride,pad,H,W,Cin,Cout", [(3, 1, 1, 7, 9, 32, 64), (1, 2, 0, 8, 6, 64, 40), (1, 1, 0, 5, 5, 32, 64)])
-def test_conv_forward_backward(hw, dt, k, stride, pad, H, W, Cin, Cout):
+def test_conv_forward_backward(hw, dt, tile, k, stride, pad, H, W, Cin, Cout):
+    if dt == torch.float32 and tile == 1:
+        pytest.skip("fp32 parity mode has one tile size")
     n = 2
     x = hw(rnd(n, Cin, H, W, seed=1).to(dt))
     w = hw(rnd(Cout, Cin, k, k, seed=2, scale=0.1).to(dt))
@@ -74,7 +80,7 @@ def test_conv_forward_backward(hw, dt, k, stride, pad, H, W, Cin, Cout):
     res = hw(rnd(M, Cout, seed=5).to(dt))
     y = torch.empty(M, Cout, dtype=dt, device=hw.dev)
     ops.gemm(xh, wk, M, Cout, k * k * Cin, out=y, a_mode=ops.ROWK_GATHER, a_tab=tab, lda=0, ldb=k * k * Cin,
-             R=k, S=k, Cin=Cin, H=H, W=W, sH=W * Cin, sW=Cin, scale=scale, shift=shift, residual=res, relu_after=True)
+             R=k, S=k, Cin=Cin, H=H, W=W, sH=W * Cin, sW=Cin, scale=scale, shift=shift, residual=res, relu_after=True, tile=tile)
     xr = x.float().requires_grad_(True)
     wr = w.float().requires_grad_(True)
     conv = F.conv2d(xr, wr, None, stride, pad)
@@ -91,16 +97,16 @@ def test_conv_forward_backward(hw, dt, k, stride, pad, H, W, Cin, Cout):
         tab_in = ops.build_pixel_table(n, H, W, 1, k - 1 - pad, OH * OW * Cout, OW * Cout, Cout, x.device)
         ops.gemm(gh, wk, n * H * W, Cin, k * k * Cout, out=dx, a_mode=ops.ROWK_GATHER, a_tab=tab_in, lda=0,
                  b_mode=ops.KROW_TAPS, ldb=k * k * Cin, R=k, S=k, Cin=Cout, H=OH, W=OW, sH=OW * Cout, sW=Cout,
-                 flip_taps=True)
+                 flip_taps=True, tile=tile)
     else:
         rowmap = (torch.arange(n).view(n, 1, 1) * H * W + (torch.arange(OH) * stride).view(1, OH, 1) * W
                   + (torch.arange(OW) * stride).view(1, 1, OW)).reshape(-1).int().to(hw.dev)
-        ops.gemm(gh, wk, M, Cin, Cout, out=dx, b_mode=ops.KROW_TAPS, ldb=Cin, R=1, S=1, Cin=Cout, c_rowmap=rowmap)
+        ops.gemm(gh, wk, M, Cin, Cout, out=dx, b_mode=ops.KROW_TAPS, ldb=Cin, R=1, S=1, Cin=Cout, c_rowmap=rowmap, tile=tile)
     torch.testing.assert_close(dx.float().view(n, H, W, Cin), xr.grad.permute(0, 2, 3, 1), **tol(dt))
     # wgrad: dW[co][(r,s,c)] = sum_m g[m,co] X[pix(m,r,s), c], split over the pixel reduction
     dw = torch.zeros(Cout, k * k * Cin, dtype=torch.float32, device=hw.dev)
     ops.gemm(gh, xh, Cout, k * k * Cin, M, out=dw, a_mode=ops.KROW, lda=Cout, b_mode=ops.KROW_GATHER, b_tab=tab,
-             ldb=0, R=k, S=k, Cin=Cin, H=H, W=W, sH=W * Cin, sW=Cin, accumulate=True, split_k=2)
+             ldb=0, R=k, S=k, Cin=Cin, H=H, W=W, sH=W * Cin, sW=Cin, accumulate=True, split_k=2, tile=tile)
     torch.testing.assert_close(dw.view(Cout, k, k, Cin), wr.grad.permute(0, 2, 3, 1), **tol(dt))
 
 

@@ -846,8 +846,11 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     if (tile == 0) {
         int64_t blocks128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * p.split_k;
         tile = blocks128 >= 160 ? 1 : 2;
+        if (d->N <= 64 && (int64_t)((d->M + 127) / 128) * p.split_k >= 160) tile = 3;
     }
+    if (tile == 1 && d->N <= 64) tile = 3;           // narrow outputs (stem / res2 convs): 128x64 tile
     if (tile == 1) return launch_gemm<bf16, 128, 128, 2>(p, fast, st);
+    if (tile == 3) return launch_gemm<bf16, 128, 64, 2>(p, fast, st);
     return launch_gemm<bf16, 64, 64, 3>(p, fast, st);
 }
 

@@ -193,12 +193,19 @@ class Runtime:
 
 
 def _pick_split(mo, no, kred):
-    """split-K factor for weight-gradient GEMMs (tiny outputs, long pixel reductions)."""
-    blocks = ((mo + 63) // 64) * ((no + 63) // 64)
-    ktiles = (kred + 31) // 32
-    if blocks >= 384 or ktiles < 16:
-        return 1
-    return max(1, min((512 + blocks - 1) // blocks, ktiles // 8))
+    """(split_k, tile) for weight-gradient GEMMs: small outputs, long pixel/token reductions, fp32 atomics allowed.
+    Prefer the 128x128 tile and split the reduction until ~1.5 blocks per CU are in flight."""
+    ktiles = (kred + 63) // 64
+    if mo >= 128 and no >= 128:
+        blocks = ((mo + 127) // 128) * ((no + 127) // 128)
+        tile = 1
+    else:
+        blocks = ((mo + 63) // 64) * ((no + 63) // 64)
+        tile = 2
+    split = 1
+    if blocks < 320 and ktiles >= 8:
+        split = max(1, min((384 + blocks - 1) // blocks, ktiles // 4))
+    return split, tile
 
 
 # =================================================================================================
@@ -261,14 +268,15 @@ def _conv_wgrad(rt: Runtime, g, x, conv):
     k, s, p = conv.k, conv.stride, conv.pad
     m = n * oh * ow
     kk = k * k * cin
-    split = _pick_split(cout, kk, m)
+    split, tile = _pick_split(cout, kk, m)
     if k == 1 and s == 1:
         ops.gemm(g.view(m, cout), x.view(m, cin), cout, cin, m, out=gw.view(cout, kk), a_mode=KROW, lda=cout,
-                 b_mode=KROW, ldb=cin, accumulate=True, split_k=split)
+                 b_mode=KROW, ldb=cin, accumulate=True, split_k=split, tile=tile)
     else:
         tab = rt.table(n, oh, ow, s, p, h * w * cin, w * cin, cin, x.device)
         ops.gemm(g.view(m, cout), x, cout, kk, m, out=gw.view(cout, kk), a_mode=KROW, lda=cout, b_mode=KROW_GATHER,
-                 b_tab=tab, ldb=0, R=k, S=k, Cin=cin, H=h, W=w, sH=w * cin, sW=cin, accumulate=True, split_k=split)
+                 b_tab=tab, ldb=0, R=k, S=k, Cin=cin, H=h, W=w, sH=w * cin, sW=cin, accumulate=True, split_k=split,
+                 tile=tile)
 
 
 def _stem_weight(rt: Runtime, conv: Conv2d):
@@ -610,8 +618,9 @@ def _linear_wgrad(rt: Runtime, g, x, lin_weight, lin_bias, m, n, k, ldx=None, gr
     """dW[n,k] += g[m,n]^T x[m,k];  db[n] += colsum(g)."""
     gw = grad_w if grad_w is not None else rt.bank.grad_image(lin_weight)
     if gw is not None:
+        split, tile = _pick_split(n, k, m)
         ops.gemm(g, x, n, k, m, out=gw, a_mode=KROW, lda=g.stride(0), b_mode=KROW, ldb=ldx if ldx is not None else x.stride(0),
-                 accumulate=True, split_k=_pick_split(n, k, m))
+                 accumulate=True, split_k=split, tile=tile)
     gb = grad_b if grad_b is not None else (rt.bank.grad_image(lin_bias) if lin_bias is not None else None)
     if gb is not None:
         ops.colsum(g, gb, m, n)
@@ -763,16 +772,18 @@ class _LinearFn(torch.autograd.Function):
         gb = bank.grad_image(bias) if bias is not None else None
         if ctx.rows is None:
             if gw is not None:
+                split, tile = _pick_split(n, k, m)
                 ops.gemm(g, x2, n, k, m, out=gw, a_mode=KROW, lda=g.stride(0), b_mode=KROW, ldb=x2.stride(0), accumulate=True,
-                         split_k=_pick_split(n, k, m))
+                         split_k=split, tile=tile)
             dx = torch.empty(x2.shape, dtype=dt, device=dy.device)
             ops.gemm(g, bank.compute(weight), m, k, n, out=dx, lda=g.stride(0), b_mode=KROW)
         else:
             nseg, seglen, segstride = ctx.rows
             tab = rt.table(nseg, 1, seglen, 1, 0, segstride * k, 0, k, dy.device)
             if gw is not None:
+                split, tile = _pick_split(n, k, m)
                 ops.gemm(g, x2, n, k, m, out=gw, a_mode=KROW, lda=g.stride(0), b_mode=KROW_GATHER, b_tab=tab, ldb=0, R=1, S=1,
-                         Cin=k, H=1, W=seglen, sH=0, sW=k, accumulate=True, split_k=_pick_split(n, k, m))
+                         Cin=k, H=1, W=seglen, sH=0, sW=k, accumulate=True, split_k=split, tile=tile)
             rowmap = rt.strided_rowmap(nseg, 1, segstride, 1, seglen, 1, dy.device)
             dx = torch.zeros(x2.shape, dtype=dt, device=dy.device)
             ops.gemm(g, bank.compute(weight), m, k, n, out=dx, lda=g.stride(0), b_mode=KROW, c_rowmap=rowmap)

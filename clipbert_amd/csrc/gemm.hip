@@ -345,12 +345,14 @@ template <typename T, int ROWS, bool GATHER> struct RowkFast {
     }
 };
 
-// KB = k-lines per thread block: 8 for 128-row bf16 tiles (8x8 transpose -> ds_write_b128), else 4.
+// KB = k-lines per thread block (8: 8x8 transpose -> ds_write_b128; 4: ds_write_b64; 2: ds_write_b32), chosen so
+// that the tile's blocks cover all 256 threads; SHIFT rotates the thread -> block map so that two half-occupancy
+// operands (A and B both KROW) land on different waves.
 // Lane mapping: the k-block index varies fastest, so the lanes of one LDS write group fill ONE tile row
-// (all 32 banks, conflict-free) while lanes 8/16 apart read adjacent 16-byte chunks of the same k-line.
-template <typename T, int ROWS, int KMODE> struct KrowFast {
+// (all 32 banks, conflict-free) while lanes NKB apart read adjacent 16-byte chunks of the same k-line.
+template <typename T, int ROWS, int KMODE, int KB_ = 4, int SHIFT = 0> struct KrowFast {
     using X = Tr<T>;
-    static constexpr int KB = (sizeof(T) == 2 && ROWS >= 128) ? 8 : 4;
+    static constexpr int KB = sizeof(T) == 2 ? KB_ : 4;
     static constexpr int NKB = X::BK / KB;
     static constexpr int RBLK = ROWS / X::RB;
     static constexpr int CNT = RBLK * NKB;
@@ -373,7 +375,7 @@ template <typename T, int ROWS, int KMODE> struct KrowFast {
         tab = o.tab; ldb = (uint32_t)o.ld * ESZ; bound = (uint32_t)bnd;
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
-            const int b = tid + it * NTHREADS;
+            const int b = ((tid + SHIFT) % NTHREADS) + it * NTHREADS;
             const int kb = b % NKB, rb = b / NKB;
             const int row = row0 + rb * X::RB;
             act[it] = (b < CNT) && (row < bnd);
@@ -438,7 +440,7 @@ template <typename T, int ROWS, int KMODE> struct KrowFast {
     __device__ __forceinline__ void store(const Stage& st, unsigned char* tile, int tid) const {
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
-            const int b = tid + it * NTHREADS;
+            const int b = ((tid + SHIFT) % NTHREADS) + it * NTHREADS;
             if (b >= CNT) continue;
             const int kb = b % NKB, rb = b / NKB;
             const int r0 = rb * X::RB;
@@ -454,6 +456,14 @@ template <typename T, int ROWS, int KMODE> struct KrowFast {
                     }
                     *reinterpret_cast<u32x4*>(tile + lds_off<T>(r0 + 2 * d, kb)) = even;
                     *reinterpret_cast<u32x4*>(tile + lds_off<T>(r0 + 2 * d + 1, kb)) = odd;
+                }
+            } else if constexpr (sizeof(T) == 2 && KB == 2) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const uint32_t even = __builtin_amdgcn_perm(st.r[it][1][d], st.r[it][0][d], 0x05040100u);
+                    const uint32_t odd = __builtin_amdgcn_perm(st.r[it][1][d], st.r[it][0][d], 0x07060302u);
+                    *reinterpret_cast<uint32_t*>(tile + lds_off<T>(r0 + 2 * d, kb >> 2) + (kb & 3) * 4) = even;
+                    *reinterpret_cast<uint32_t*>(tile + lds_off<T>(r0 + 2 * d + 1, kb >> 2) + (kb & 3) * 4) = odd;
                 }
             } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -744,14 +754,18 @@ int launch_gemm(const GP& p, bool fast, hipStream_t st) {
             return launch_k<T, BM, BN, PF, RowkFast<T, BM, false>, RowkFast<T, BN, false>>(p, st);
         if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_ROWK)
             return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, RowkFast<T, BN, false>>(p, st);
+        // k-lines per thread block: one KROW operand next to a ROWK one is spread over all 256 threads; two KROW
+        // operands take half the threads each (B shifted by 128 threads)
+        constexpr int KB1A = BM >= 128 ? 4 : 2, KB1B = BN >= 128 ? 4 : 2;
+        constexpr int KB2A = BM >= 128 ? 8 : 4, KB2B = BN >= 128 ? 8 : 4;
         if (p.a_mode == CB_ROWK && (p.b_mode == CB_KROW || (p.b_mode == CB_KROW_TAPS && taps == 1)))
-            return launch_k<T, BM, BN, PF, RowkFast<T, BM, false>, KrowFast<T, BN, KM_PLAIN>>(p, st);
+            return launch_k<T, BM, BN, PF, RowkFast<T, BM, false>, KrowFast<T, BN, KM_PLAIN, KB1B, 0>>(p, st);
         if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_KROW_TAPS)
-            return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, KrowFast<T, BN, KM_TAPS>>(p, st);
+            return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, KrowFast<T, BN, KM_TAPS, KB1B, 0>>(p, st);
         if (p.a_mode == CB_KROW && p.b_mode == CB_KROW)
-            return launch_k<T, BM, BN, PF, KrowFast<T, BM, KM_PLAIN>, KrowFast<T, BN, KM_PLAIN>>(p, st);
+            return launch_k<T, BM, BN, PF, KrowFast<T, BM, KM_PLAIN, KB2A, 0>, KrowFast<T, BN, KM_PLAIN, KB2B, 128>>(p, st);
         if (p.a_mode == CB_KROW && p.b_mode == CB_KROW_GATHER)
-            return launch_k<T, BM, BN, PF, KrowFast<T, BM, KM_PLAIN>, KrowFast<T, BN, KM_GATHER>>(p, st);
+            return launch_k<T, BM, BN, PF, KrowFast<T, BM, KM_PLAIN, KB2A, 0>, KrowFast<T, BN, KM_GATHER, KB2B, 128>>(p, st);
     }
     if (!a_krow && !b_krow) return launch_k<T, BM, BN, PF, RowkLoader<T, BM, false>, RowkLoader<T, BN, false>>(p, st);
     if (!a_krow) return launch_k<T, BM, BN, PF, RowkLoader<T, BM, false>, KrowLoader<T, BN, false>>(p, st);

@@ -193,19 +193,17 @@ class Runtime:
 
 
 def _pick_split(mo, no, kred):
-    """(split_k, tile) for weight-gradient GEMMs: small outputs, long pixel/token reductions, fp32 atomics allowed.
-    Prefer the 128x128 tile and split the reduction until ~1.5 blocks per CU are in flight."""
+    """(split_k, tile) for weight-gradient GEMMs (small outputs, long pixel/token reductions).  Split-K combines
+    through fp32 atomics, which the L2 serialises: only split when the output is small."""
     ktiles = (kred + 63) // 64
-    if mo >= 128 and no >= 128:
-        blocks = ((mo + 127) // 128) * ((no + 127) // 128)
-        tile = 1
-    else:
-        blocks = ((mo + 63) // 64) * ((no + 63) // 64)
-        tile = 2
-    split = 1
-    if blocks < 320 and ktiles >= 8:
-        split = max(1, min((384 + blocks - 1) // blocks, ktiles // 4))
-    return split, tile
+    b64 = ((mo + 63) // 64) * ((no + 63) // 64)
+    b128 = ((mo + 127) // 128) * ((no + 127) // 128)
+    if b128 >= 200:
+        return 1, 1
+    if b64 >= 200:
+        return 1, 2
+    split = max(1, min((320 + b64 - 1) // b64, ktiles // 4))
+    return split, 2
 
 
 # =================================================================================================

@@ -82,6 +82,7 @@ struct Opnd {
 // ---------------------------------------------------------------------------------------------
 template <typename T, int ROWS, bool FAST> struct RowkLoader {
     using X = Tr<T>;
+    static constexpr bool TR = false;
     static constexpr int NS = ROWS * X::SEGS / NTHREADS;
     static constexpr int ESZ = (int)sizeof(T);
     static_assert(ROWS * X::SEGS % NTHREADS == 0, "tile/threads mismatch");
@@ -158,6 +159,7 @@ template <typename T, int ROWS, bool FAST> struct RowkLoader {
 // ---------------------------------------------------------------------------------------------
 template <typename T, int ROWS, bool FAST> struct KrowLoader {
     using X = Tr<T>;
+    static constexpr bool TR = false;
     static constexpr int RBLK = ROWS / X::RB;              // row blocks per tile
     static constexpr int CNT = RBLK * (X::BK / 4);         // thread-blocks per tile
     static constexpr int NI = (CNT + NTHREADS - 1) / NTHREADS;
@@ -276,6 +278,7 @@ enum { KM_PLAIN = 0, KM_TAPS = 1, KM_GATHER = 2 };
 
 template <typename T, int ROWS, bool GATHER> struct RowkFast {
     using X = Tr<T>;
+    static constexpr bool TR = false;
     static constexpr int NS = ROWS * X::SEGS / NTHREADS;
     static constexpr uint32_t ESZ = (uint32_t)sizeof(T);
     struct Stage { u32x4 r[NS]; };
@@ -352,6 +355,7 @@ template <typename T, int ROWS, bool GATHER> struct RowkFast {
 // (all 32 banks, conflict-free) while lanes NKB apart read adjacent 16-byte chunks of the same k-line.
 template <typename T, int ROWS, int KMODE, int KB_ = 4, int SHIFT = 0> struct KrowFast {
     using X = Tr<T>;
+    static constexpr bool TR = false;
     static constexpr int KB = sizeof(T) == 2 ? KB_ : 4;
     static constexpr int NKB = X::BK / KB;
     static constexpr int RBLK = ROWS / X::RB;
@@ -486,6 +490,121 @@ template <typename T, int ROWS, int KMODE, int KB_ = 4, int SHIFT = 0> struct Kr
     }
 };
 
+// =============================================================================================
+// KROW operands, bf16: no register transpose at all.  The tile is stored in LDS in its NATURAL image
+// [k][rows] (each k-line = ROWS contiguous elements = what a fully coalesced global read delivers) and the MFMA
+// fragments are produced by the LDS transpose-read ds_read_b64_tr_b16: per 16-lane group, lane p supplies the
+// address of 4 consecutive rows of line (kbase + p/4) and lane i receives column i of that 4 x 16 block
+// (semantics verified on gfx950 by tools/tr_probe.hip).  16-byte chunks of a line are XOR-swizzled with the
+// line index so that the 8 lines read by one 32-lane bank group fall into 8 distinct 32-byte windows.
+// =============================================================================================
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ s16x4 lds_read_tr(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+
+template <int ROWS> __device__ __forceinline__ int tr_chunk_swz(int kline) {
+    if constexpr (ROWS >= 128) return (((kline & 3) | (((kline >> 3) & 1) << 2)) << 1);          // 8 windows per line
+    else return ((((kline >> 1) & 1) | (((kline >> 3) & 1) << 1)) << 1);                        // 4 windows, 2 lines per bank row
+}
+// byte offset of rows [r, r+4) of line k in a KROW tile
+template <int ROWS> __device__ __forceinline__ int tr_off(int kline, int r) {
+    const int chunk = (r >> 3) ^ tr_chunk_swz<ROWS>(kline);
+    return kline * (ROWS * 2) + (chunk << 4) + ((r & 7) << 1);
+}
+
+// MFMA fragment (rows r0..r0+15, k = kk*32 + 8*(lane>>4) .. +7) of a natural-image KROW tile
+template <int ROWS> __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int r0, int kk, int lane) {
+    const int p = lane & 15, kbase = kk * 32 + 8 * (lane >> 4) + (p >> 2);
+    const int r = r0 + 4 * (p & 3);
+    union { struct { s16x4 lo, hi; } h; bf16x8 v; } u;
+    u.h.lo = lds_read_tr(tile + tr_off<ROWS>(kbase, r));
+    u.h.hi = lds_read_tr(tile + tr_off<ROWS>(kbase + 4, r));
+    return u.v;
+}
+
+template <int ROWS, int KMODE> struct KrowTr {
+    using X = Tr<bf16>;
+    static constexpr bool TR = true;
+    static constexpr int CH = ROWS / 8;                           // 16-byte chunks per k-line
+    static constexpr int NS = CH * X::BK / NTHREADS;
+    static_assert(CH * X::BK % NTHREADS == 0, "tile/threads mismatch");
+    static constexpr uint32_t ESZ = 2;
+    struct Stage { u32x4 r[NS]; };
+    rsrc_t rs;
+    const cb_pixel* tab;
+    uint32_t ldb, bound;
+    uint32_t voff[NS];          // PLAIN: byte offset of (k-line, chunk) | TAPS / GATHER: the part contributed by the rows
+    int kl[NS];                 // global k of the slot's line
+    int co[NS], tap[NS];        // TAPS
+    int rr, ss;                 // GATHER (the 8 rows of a chunk share a tap)
+    cb_pixel px[NS];            // GATHER: table entries of the NEXT tile
+    bool act[NS];
+
+    __device__ __forceinline__ void init(const GP& p, const Opnd& o, int row0, int bnd, int kt0, int tid) {
+        rs = make_rsrc(o.base, o.bytes);
+        tab = o.tab; ldb = (uint32_t)o.ld * ESZ; bound = (uint32_t)bnd;
+        rr = 0; ss = 0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int idx = tid + i * NTHREADS;
+            const int chunk = idx % CH, kline = idx / CH;
+            const int row = row0 + chunk * 8;
+            act[i] = row < bnd;
+            kl[i] = kt0 * X::BK + kline;
+            co[i] = kl[i]; tap[i] = 0;
+            if constexpr (KMODE == KM_PLAIN) {
+                voff[i] = ((uint32_t)kl[i] * (uint32_t)o.ld + (uint32_t)row) * ESZ;
+            } else if constexpr (KMODE == KM_TAPS) {
+                tap[i] = kl[i] / p.Ct;
+                co[i] = kl[i] - tap[i] * p.Ct;
+                voff[i] = (uint32_t)row * ESZ;
+            } else {
+                const int tp = row / p.Ct, ch = row - tp * p.Ct;        // chunk is the same for all slots of a thread
+                rr = tp / p.S; ss = tp - rr * p.S;
+                voff[i] = (uint32_t)(rr * (int)p.sH + ss * (int)p.sW + ch) * ESZ;
+                cb_pixel e = {0, (int16_t)-30000, (int16_t)-30000};
+                if (act[i] && kl[i] < p.K) e = tab[kl[i]];
+                px[i] = e;
+            }
+        }
+    }
+    template <bool CHECK> __device__ __forceinline__ void load(Stage& st, const GP& p) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            if constexpr (KMODE == KM_PLAIN) {
+                bool v = act[i];
+                if (CHECK) v = v && (kl[i] < p.K);
+                st.r[i] = bload16(rs, v ? voff[i] : OOB);
+                voff[i] += X::BK * ldb;
+                kl[i] += X::BK;
+            } else if constexpr (KMODE == KM_TAPS) {
+                const int tapw = p.flip ? (p.R * p.S - 1 - tap[i]) : tap[i];
+                const bool v = act[i] && tap[i] < p.R * p.S;
+                st.r[i] = bload16(rs, v ? (uint32_t)co[i] * ldb + (uint32_t)tapw * bound * ESZ + voff[i] : OOB);
+                co[i] += X::BK;
+                while (co[i] >= p.Ct) { co[i] -= p.Ct; ++tap[i]; }
+            } else {
+                const cb_pixel e = px[i];
+                const bool v = (unsigned)(e.ih0 + rr) < (unsigned)p.H && (unsigned)(e.iw0 + ss) < (unsigned)p.W;
+                st.r[i] = bload16(rs, v ? (uint32_t)e.off * ESZ + voff[i] : OOB);
+                kl[i] += X::BK;
+                cb_pixel nx = {0, (int16_t)-30000, (int16_t)-30000};
+                if (act[i] && kl[i] < p.K) nx = tab[kl[i]];
+                px[i] = nx;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(const Stage& st, unsigned char* tile, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int idx = tid + i * NTHREADS;
+            const int chunk = idx % CH, kline = idx / CH;
+            *reinterpret_cast<u32x4*>(tile + kline * (ROWS * 2) + ((chunk ^ tr_chunk_swz<ROWS>(kline)) << 4)) = st.r[i];
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Epilogue of one 4-wide accumulator fragment (row m, columns nb..nb+3).
 // ---------------------------------------------------------------------------------------------
@@ -615,11 +734,15 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
             for (int kk = 0; kk < BK / 32; ++kk) {
                 bf16x8 af[FM], bfr[FN];
 #pragma unroll
-                for (int i = 0; i < FM; ++i)
-                    af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off<T>(wm * WM + i * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+                for (int i = 0; i < FM; ++i) {
+                    if constexpr (LA::TR) af[i] = tr_frag<BM>(As, wm * WM + i * 16, kk, lane);
+                    else af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off<T>(wm * WM + i * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+                }
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<T>(wn * WN + j * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+                for (int j = 0; j < FN; ++j) {
+                    if constexpr (LB::TR) bfr[j] = tr_frag<BN>(Bs, wn * WN + j * 16, kk, lane);
+                    else bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<T>(wn * WN + j * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+                }
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -754,9 +877,19 @@ int launch_gemm(const GP& p, bool fast, hipStream_t st) {
             return launch_k<T, BM, BN, PF, RowkFast<T, BM, false>, RowkFast<T, BN, false>>(p, st);
         if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_ROWK)
             return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, RowkFast<T, BN, false>>(p, st);
-        // k-lines per thread block: one KROW operand next to a ROWK one is spread over all 256 threads; two KROW
-        // operands take half the threads each (B shifted by 128 threads)
-        constexpr int KB1A = BM >= 128 ? 4 : 2, KB1B = BN >= 128 ? 4 : 2;
+        if constexpr (sizeof(T) == 2) {
+            if (p.a_mode == CB_ROWK && (p.b_mode == CB_KROW || (p.b_mode == CB_KROW_TAPS && taps == 1)))
+                return launch_k<T, BM, BN, PF, RowkFast<T, BM, false>, KrowTr<BN, KM_PLAIN>>(p, st);
+            if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_KROW_TAPS && p.Ct % Tr<bf16>::BK == 0)
+                return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, KrowTr<BN, KM_TAPS>>(p, st);
+            if (p.a_mode == CB_KROW && p.b_mode == CB_KROW)
+                return launch_k<T, BM, BN, PF, KrowTr<BM, KM_PLAIN>, KrowTr<BN, KM_PLAIN>>(p, st);
+            if (p.a_mode == CB_KROW && p.b_mode == CB_KROW_GATHER)
+                return launch_k<T, BM, BN, PF, KrowTr<BM, KM_PLAIN>, KrowTr<BN, KM_GATHER>>(p, st);
+        }
+        // fp32 parity mode (and odd channel counts): register-transposing loaders.  One KROW operand next to a ROWK
+        // one is spread over all 256 threads; two KROW operands take half the threads each (B shifted by 128)
+        constexpr int KB1B = BN >= 128 ? 4 : 2;
         constexpr int KB2A = BM >= 128 ? 8 : 4, KB2B = BN >= 128 ? 8 : 4;
         if (p.a_mode == CB_ROWK && (p.b_mode == CB_KROW || (p.b_mode == CB_KROW_TAPS && taps == 1)))
             return launch_k<T, BM, BN, PF, RowkFast<T, BM, false>, KrowFast<T, BN, KM_PLAIN, KB1B, 0>>(p, st);

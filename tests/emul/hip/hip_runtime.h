@@ -206,6 +206,24 @@ static inline uint32_t emul_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
 }
 #define __builtin_amdgcn_perm emul_perm
 
+// ds_read_b64_tr_b16: per 16-lane group, lane p supplies 4 consecutive 16-bit elements of row p/4
+// (columns 4*(p%4)..+3); lane i receives column i of that 4 x 16 block (verified on gfx950, tools/tr_probe.hip)
+typedef __attribute__((ext_vector_type(4))) short emul_s16x4;
+static inline emul_s16x4 emul_ds_read_tr16(const void* addr) {
+    emul_s16x4 mine;
+    memcpy(&mine, addr, 8);
+    auto tab = emul::wave_collect(&mine, 8);
+    const int lane = emul::cur->lane, base = lane & ~15, i = lane & 15;
+    emul_s16x4 r;
+    for (int e = 0; e < 4; ++e) {
+        emul_s16x4 src;
+        memcpy(&src, tab[base + 4 * e + i / 4], 8);
+        r[e] = src[i % 4];
+    }
+    return r;
+}
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emul_ds_read_tr16((const void*)(p))
+
 // ---- atomics -------------------------------------------------------------------------------
 static inline float atomicAdd(float* p, float v) {
     uint32_t* u = reinterpret_cast<uint32_t*>(p);

@@ -878,10 +878,15 @@ int launch_gemm(const GP& p, bool fast, hipStream_t st) {
         if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_ROWK)
             return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, RowkFast<T, BN, false>>(p, st);
         if constexpr (sizeof(T) == 2) {
-            if (p.a_mode == CB_ROWK && (p.b_mode == CB_KROW || (p.b_mode == CB_KROW_TAPS && taps == 1)))
-                return launch_k<T, BM, BN, PF, RowkFast<T, BM, false>, KrowTr<BN, KM_PLAIN>>(p, st);
-            if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_KROW_TAPS && p.Ct % Tr<bf16>::BK == 0)
-                return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, KrowTr<BN, KM_TAPS>>(p, st);
+            // measured on MI355X: next to a ROWK operand the transpose-read image wins for 64-row tiles, the
+            // register transpose (KB = 4, all 256 threads) for 128-row tiles; with two KROW operands the
+            // transpose-read image wins for both tile sizes (profiles/r01_gemm_microbench.md)
+            if constexpr (BN < 128) {
+                if (p.a_mode == CB_ROWK && (p.b_mode == CB_KROW || (p.b_mode == CB_KROW_TAPS && taps == 1)))
+                    return launch_k<T, BM, BN, PF, RowkFast<T, BM, false>, KrowTr<BN, KM_PLAIN>>(p, st);
+                if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_KROW_TAPS && p.Ct % Tr<bf16>::BK == 0)
+                    return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, KrowTr<BN, KM_TAPS>>(p, st);
+            }
             if (p.a_mode == CB_KROW && p.b_mode == CB_KROW)
                 return launch_k<T, BM, BN, PF, KrowTr<BM, KM_PLAIN>, KrowTr<BN, KM_PLAIN>>(p, st);
             if (p.a_mode == CB_KROW && p.b_mode == CB_KROW_GATHER)

@@ -997,8 +997,8 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     int tile = d->tile;
     if (tile == 0) {
         int64_t blocks128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * p.split_k;
-        tile = blocks128 >= 160 ? 1 : 2;
-        if (d->N <= 64 && (int64_t)((d->M + 127) / 128) * p.split_k >= 160) tile = 3;
+        tile = blocks128 >= 448 ? 1 : 2;               // below ~2 blocks per CU the 64x64 tile fills the chip better
+        if (d->N <= 64 && (int64_t)((d->M + 127) / 128) * p.split_k >= 448) tile = 3;
     }
     if (tile == 1 && d->N <= 64) tile = 3;           // narrow outputs (stem / res2 convs): 128x64 tile
     if (tile == 1) return launch_gemm<bf16, 128, 128, 2>(p, fast, st);

@@ -198,7 +198,7 @@ def _pick_split(mo, no, kred):
     ktiles = (kred + 63) // 64
     b64 = ((mo + 63) // 64) * ((no + 63) // 64)
     b128 = ((mo + 127) // 128) * ((no + 127) // 128)
-    if b128 >= 200:
+    if b128 >= 448:
         return 1, 1
     if b64 >= 200:
         return 1, 2

@@ -240,9 +240,18 @@ def measure_roofline(step_fn):
     tot_t = sum(a[1] for a in agg.values())
     dom = max(agg.items(), key=lambda kv: kv[1][1])
     achieved = dom[1][0] / dom[1][1] / 1e12
+    # HBM bytes per launch of that kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    # separate runs, gfx950 correction applied -- profiles/r01_pmc_traffic.json); null when no PMC data is committed
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            traffic = json.load(fh)["families"][dom[0]]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     return {"bound": "mfma", "kernel": dom[0], "launches": dom[1][2], "avg_launch_us": round(dom[1][1] / dom[1][2] * 1e6, 2),
             "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-            "traffic": None,
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
+            "algorithmic_flop_per_launch": round(dom[1][0] / dom[1][2]),
             "all_gemm_kernels": {"achieved": round(tot_fl / tot_t / 1e12, 2), "time_ms": round(tot_t * 1e3, 3),
                                  "gflop_per_step": round(tot_fl / 1e9, 1)},
             "by_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms": round(v[1] * 1e3, 3), "launches": v[2]} for k, v in agg.items()}}

@@ -15,6 +15,7 @@ sums, ReLU/FrozenBN masks and bias/LayerNorm reductions are fused into kernel ep
 being left to autograd's eager tensor ops.  Parameter gradients are accumulated by the kernels
 directly into the flat fp32 gradient buffer (``p.grad`` is a view of it).
 """
+import contextlib
 import math
 from types import SimpleNamespace
 from typing import List, Optional
@@ -173,6 +174,26 @@ class Runtime:
         self.anchor: Optional[torch.Tensor] = None       # requires_grad leaf that keeps the coarse nodes alive
         self.stem_w = None
         self.after_encoder_backward = None               # hook: launch the transformer-bucket all-reduce
+        self.side_stream = None                          # second HIP stream: weight-gradient GEMMs run beside the dgrad chain
+        self._side_refs = []
+
+    def side(self, *tensors):
+        """Context manager: run the enclosed launches on the side stream, ordered after everything issued so far on
+        the current stream.  The weight-gradient GEMMs of the backward pass are independent of the data-gradient
+        chain and each fills well under one block per CU, so the two streams overlap on the chip.  `tensors` are
+        kept alive until join() so the caching allocator cannot hand their memory out while the side stream reads it."""
+        if self.side_stream is None:
+            return contextlib.nullcontext()
+        ev = torch.cuda.Event()
+        ev.record()
+        self.side_stream.wait_event(ev)
+        self._side_refs.extend(tensors)
+        return torch.cuda.stream(self.side_stream)
+
+    def join(self):
+        if self.side_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.side_stream)
+            self._side_refs.clear()
 
     def table(self, n, oh, ow, stride, pad, sN, sH, sW, device):
         key = (n, oh, ow, stride, pad, sN, sH, sW, str(device))
@@ -336,8 +357,10 @@ def cnn_backward(bb: "GridFeatBackbone", saved_pack, dgrid: torch.Tensor):
     saved, res5, gy, grid = saved_pack
     gconv = bb.grid_encoder[0]
     dg = ops.maxpool2_bwd(gy, grid, dgrid.reshape(grid.shape).contiguous(), relu=True)
-    _conv_wgrad(rt, dg, res5, gconv)
+    with rt.side(dg, res5):
+        _conv_wgrad(rt, dg, res5, gconv)
     if not saved:
+        rt.join()
         return
     dout = _conv_dgrad(rt, dg, gconv, res5.shape)
     for idx in range(len(saved) - 1, -1, -1):
@@ -352,19 +375,23 @@ def cnn_backward(bb: "GridFeatBackbone", saved_pack, dgrid: torch.Tensor):
             dz = None
         else:
             g3, dz, gsc = ops.relu_scale_bwd(dout, out, s3, True, None)
-        _conv_wgrad(rt, g3, y2, blk.conv3)
+        with rt.side(g3, y2, gsc):
+            _conv_wgrad(rt, g3, y2, blk.conv3)
+            if blk.shortcut is not None:
+                _conv_wgrad(rt, gsc, x, blk.shortcut)
         g2 = _conv_dgrad(rt, g3, blk.conv3, y2.shape, scale=s2, mask=y2)       # -> d(conv2 out) * mask * scale2
-        _conv_wgrad(rt, g2, y1, blk.conv2)
+        with rt.side(g2, y1):
+            _conv_wgrad(rt, g2, y1, blk.conv2)
         g1 = _conv_dgrad(rt, g2, blk.conv2, y1.shape, scale=s1, mask=y1)
-        _conv_wgrad(rt, g1, x, blk.conv1)
-        if blk.shortcut is not None:
-            _conv_wgrad(rt, gsc, x, blk.shortcut)
+        with rt.side(g1, x):
+            _conv_wgrad(rt, g1, x, blk.conv1)
         if need_dx:
             if blk.shortcut is None:
                 dout = _conv_dgrad(rt, g1, blk.conv1, x.shape, residual=dz)
             else:
                 dout = _conv_dgrad(rt, g1, blk.conv1, x.shape)
                 _conv_dgrad(rt, gsc, blk.shortcut, x.shape, out=dout, accumulate=True)
+    rt.join()
 
 
 class _CnnFn(torch.autograd.Function):
@@ -656,28 +683,33 @@ def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
         d_o_pre, d_o_drop = ops.layernorm_bwd(dx, o_pre, ou.LayerNorm.weight, mean2, rstd2, bank.grad_image(ou.LayerNorm.weight),
                                               bank.grad_image(ou.LayerNorm.bias), pk.p_h, _seed(_SITE_OUT, li), rt.seed_dev)
         g = d_o_drop if d_o_drop is not None else d_o_pre
-        _linear_wgrad(rt, g, hact, ou.dense.weight, ou.dense.bias, M, d, ff)
+        with rt.side(g, hact):
+            _linear_wgrad(rt, g, hact, ou.dense.weight, ou.dense.bias, M, d, ff)
         dh = torch.empty(M, ff, dtype=dt, device=dev)
         ops.gemm(g, bank.compute(ou.dense.weight), M, ff, d, out=dh, b_mode=KROW)
         dhp = ops.act_bwd(ACT_GELU, dh, hpre)
-        _linear_wgrad(rt, dhp, a, it.dense.weight, it.dense.bias, M, ff, d)
+        with rt.side(dhp, a):
+            _linear_wgrad(rt, dhp, a, it.dense.weight, it.dense.bias, M, ff, d)
         da = torch.empty(M, d, dtype=dt, device=dev)
         ops.gemm(dhp, bank.compute(it.dense.weight), M, d, ff, out=da, b_mode=KROW, residual=d_o_pre)
         d_a_pre, d_a_drop = ops.layernorm_bwd(da, a_pre, so.LayerNorm.weight, mean1, rstd1, bank.grad_image(so.LayerNorm.weight),
                                               bank.grad_image(so.LayerNorm.bias), pk.p_h, _seed(_SITE_SELF_OUT, li), rt.seed_dev)
         g = d_a_drop if d_a_drop is not None else d_a_pre
-        _linear_wgrad(rt, g, ctx, so.dense.weight, so.dense.bias, M, d, d)
+        with rt.side(g, ctx):
+            _linear_wgrad(rt, g, ctx, so.dense.weight, so.dense.bias, M, d, d)
         dctx = torch.empty(M, d, dtype=dt, device=dev)
         ops.gemm(g, bank.compute(so.dense.weight), M, d, d, out=dctx, b_mode=KROW)
         dqkv = ops.attention_bwd(qkv, pk.key_mask, ctx, dctx, lse, bsz, L, nh, pk.p_a, _seed(_SITE_ATTN, li), rt.seed_dev)
         gw = bank.grad_span(att.query.weight, att.value.weight, (3 * d, d)) if bank.is_trainable(att.query.weight) else None
         gb = bank.grad_span(att.query.bias, att.value.bias, (3 * d,)) if bank.is_trainable(att.query.bias) else None
         if gw is not None:
-            _linear_wgrad(rt, dqkv, x, None, None, M, 3 * d, d, grad_w=gw, grad_b=gb)
+            with rt.side(dqkv, x):
+                _linear_wgrad(rt, dqkv, x, None, None, M, 3 * d, d, grad_w=gw, grad_b=gb)
         wqkv = bank.compute_span(att.query.weight, att.value.weight, (3 * d, d))
         dx = torch.empty(M, d, dtype=dt, device=dev)
         ops.gemm(dqkv, wqkv, M, d, 3 * d, out=dx, b_mode=KROW, residual=d_a_pre)
     # ---- embeddings -----------------------------------------------------------------------------------
+    rt.join()
     if pk.p_h > 0:
         dx = ops.dropout(dx, pk.p_h, _seed(_SITE_EMB), rt.seed_dev)
     emb, vemb = model.embeddings, model.visual_embeddings
@@ -1004,7 +1036,8 @@ class ClipBert(nn.Module):
         self._src_cache = {}
 
     # ---- MI355X runtime --------------------------------------------------------------------------------
-    def prepare(self, dtype=torch.bfloat16, device=None, transformer_lr_mul_prefix="", cnn_lr_mul_prefix="grid_encoder"):
+    def prepare(self, dtype=torch.bfloat16, device=None, transformer_lr_mul_prefix="", cnn_lr_mul_prefix="grid_encoder",
+                overlap_wgrad=True):
         """Move parameters into the flat HBM buffers and build compute copies.  Call after loading
         weights / changing requires_grad (freeze_cnn_backbone) and before the first forward."""
         device = torch.device(device) if device is not None else next(self.parameters()).device
@@ -1016,6 +1049,8 @@ class ClipBert(nn.Module):
         rt.bank = ParamBank(self, device, dtype, transformer_lr_mul_prefix, cnn_lr_mul_prefix)
         rt.seed_dev = torch.zeros(1, dtype=torch.int64, device=device)
         rt.anchor = torch.zeros(1, dtype=torch.float32, device=device, requires_grad=True)
+        if device.type == "cuda" and overlap_wgrad:
+            rt.side_stream = torch.cuda.Stream(device=device)
         for m in self.modules():
             if hasattr(m, "rt"):
                 m.rt = rt

@@ -19,6 +19,8 @@
 // * bf16: v_mfma_f32_16x16x32_bf16; fp32 parity mode: v_mfma_f32_16x16x4_f32 (exact fp32).
 #include "common.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 namespace {
@@ -670,13 +672,65 @@ __device__ __forceinline__ void epilogue_elem(const GP& p, float x, int m, int64
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tile epilogue shared by both kernel structures.  acc[i][j] = 4 consecutive n of row m (swapped MFMA operands).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int SMEM_BYTES>
+__device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 32], unsigned char* smem, int m0, int n0, int tid) {
+    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    if (p.dropout_p > 0.f && p.seed_ptr) p.seed += *p.seed_ptr;
+    const bool fast = p.c_vec && (n0 + BN <= p.N);      // block-uniform
+    if (fast) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * WM + i * 16 + (lane & 15);
+            const bool mok = m < p.M;
+            const int64_t orow = (mok && p.c_rowmap) ? (int64_t)p.c_rowmap[m] : (int64_t)m;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int nb = n0 + wn * WN + j * 16 + 4 * (lane >> 4);
+                if (mok) epilogue_vec<T>(p, acc[i][j], m, orow, nb);
+            }
+        }
+    } else {
+        // ragged N edge or unaligned output: stage the accumulators through LDS (free after the main
+        // loop), half the tile rows at a time, then run a plain bounds-checked per-element loop.
+        float* stage = reinterpret_cast<float*>(smem);
+        static_assert(WM * BN * 4 <= SMEM_BYTES, "staging does not fit");
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();
+            if (wm == h) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        *reinterpret_cast<f32x4*>(stage + (i * 16 + (lane & 15)) * BN + wn * WN + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+            }
+            __syncthreads();
+            for (int idx = tid; idx < WM * BN; idx += NTHREADS) {
+                const int rl = idx / BN, cl = idx % BN;
+                const int m = m0 + h * WM + rl, n = n0 + cl;
+                if (m < p.M && n < p.N) {
+                    const int64_t orow = p.c_rowmap ? (int64_t)p.c_rowmap[m] : (int64_t)m;
+                    epilogue_elem<T>(p, stage[idx], m, orow, n);
+                }
+            }
+        }
+    }
+}
+
+
 template <typename T, int BM, int BN, typename LA, typename LB, int PF>
 __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
     using X = Tr<T>;
     constexpr int BK = X::BK;
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     constexpr int TILE_A = BM * X::ROWB, TILE_B = BN * X::ROWB;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (TILE_A + TILE_B)];
+    constexpr int SMEM_BYTES = 2 * (TILE_A + TILE_B);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -799,47 +853,222 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
         }
     }
 
-    // ---- epilogue: lane owns n = nb..nb+3 of row m ------------------------------------------------
-    if (p.dropout_p > 0.f && p.seed_ptr) p.seed += *p.seed_ptr;
-    const bool fast = p.c_vec && (n0 + BN <= p.N);      // block-uniform
-    if (fast) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int m = m0 + wm * WM + i * 16 + (lane & 15);
-            const bool mok = m < p.M;
-            const int64_t orow = (mok && p.c_rowmap) ? (int64_t)p.c_rowmap[m] : (int64_t)m;
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int nb = n0 + wn * WN + j * 16 + 4 * (lane >> 4);
-                if (mok) epilogue_vec<T>(p, acc[i][j], m, orow, nb);
-            }
+    tile_epilogue<T, BM, BN, SMEM_BYTES>(p, acc, smem, m0, n0, tid);
+}
+
+// =============================================================================================
+// v6 structure (bf16 fast path without convolution-gathered KROW operands): operands go global -> LDS by
+// LDS-DMA (buffer_load_dwordx4 ... lds): no VGPR staging, no ds_write, and an NST-deep LDS ring whose depth is
+// spent with counted s_waitcnt vmcnt(N) + one raw s_barrier per K step.  The LDS destination of an LDS-DMA is
+// wave-uniform base + lane*16, so the XOR swizzles of the tile images are applied to each lane's SOURCE address.
+// =============================================================================================
+__device__ __forceinline__ void dma16(rsrc_t rs, unsigned char* lds_wave_base, uint32_t voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
+}
+// s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields left at "no wait")
+#define CB_WAIT_VMCNT(N) __builtin_amdgcn_s_waitcnt((((N) & 15) | (7 << 4) | (15 << 8) | ((((N) >> 4) & 3) << 14)))
+
+// ROWK image [rows][128 B], 16-byte segment s of row r stored at segment s ^ (r & 7)  (same image as RowkFast)
+template <int ROWS, bool GATHER> struct RowkDma {
+    using X = Tr<bf16>;
+    static constexpr bool TR = false;
+    static constexpr int NI = ROWS / 8 / 4;            // 1-KiB DMA instructions per wave per tile
+    rsrc_t rs;
+    uint32_t voff[NI];
+    int ih[NI], iw[NI];
+    int c, rr, ss, krem;
+
+    __device__ __forceinline__ void init(const GP& p, const Opnd& o, int row0, int bound, int kt0, int tid) {
+        rs = make_rsrc(o.base, o.bytes);
+        const int lane = tid & 63, wave = tid >> 6;
+        const int rin = lane >> 3;                                   // row within the 8-row group (= row & 7)
+        const int lseg = (lane & 7) ^ rin;                           // logical segment this lane fetches
+        const int k = kt0 * X::BK + lseg * 8;
+        c = k; rr = 0; ss = 0; krem = p.K - k;
+        if constexpr (GATHER) {
+            int tap = k / p.Ct;
+            c = k - tap * p.Ct;
+            rr = tap / p.S; ss = tap - rr * p.S;
         }
-    } else {
-        // ragged N edge or unaligned output: stage the accumulators through LDS (free after the main
-        // loop), half the tile rows at a time, then run a plain bounds-checked per-element loop.
-        float* stage = reinterpret_cast<float*>(smem);
-        static_assert(WM * BN * 4 <= 2 * (TILE_A + TILE_B), "staging does not fit");
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            __syncthreads();
-            if (wm == h) {
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j)
-                        *reinterpret_cast<f32x4*>(stage + (i * 16 + (lane & 15)) * BN + wn * WN + j * 16 + 4 * (lane >> 4)) = acc[i][j];
-            }
-            __syncthreads();
-            for (int idx = tid; idx < WM * BN; idx += NTHREADS) {
-                const int rl = idx / BN, cl = idx % BN;
-                const int m = m0 + h * WM + rl, n = n0 + cl;
-                if (m < p.M && n < p.N) {
-                    const int64_t orow = p.c_rowmap ? (int64_t)p.c_rowmap[m] : (int64_t)m;
-                    epilogue_elem<T>(p, stage[idx], m, orow, n);
-                }
+        for (int i = 0; i < NI; ++i) {
+            const int row = row0 + (i * 4 + wave) * 8 + rin;
+            const bool ok = row < bound;
+            ih[i] = 0; iw[i] = 0;
+            if constexpr (GATHER) {
+                cb_pixel px = {0, 0, 0};
+                if (ok) px = o.tab[row];
+                ih[i] = px.ih0; iw[i] = px.iw0;
+                voff[i] = ok ? (uint32_t)px.off * 2u : OOB;
+            } else {
+                voff[i] = ok ? ((uint32_t)row * (uint32_t)o.ld + (uint32_t)k) * 2u : OOB;
             }
         }
     }
+    template <bool CHECK> __device__ __forceinline__ void issue(const GP& p, unsigned char* tile, int wave) {
+        if constexpr (GATHER) {
+            const bool kv = rr < p.R;
+            const uint32_t koff = (uint32_t)(rr * (int)p.sH + ss * (int)p.sW + c) * 2u;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const bool v = kv && (unsigned)(ih[i] + rr) < (unsigned)p.H && (unsigned)(iw[i] + ss) < (unsigned)p.W;
+                dma16(rs, tile + (i * 4 + wave) * 1024, v ? voff[i] + koff : OOB);
+            }
+            if (p.Ct >= X::BK) {
+                c += X::BK;
+                if (c >= p.Ct) { c -= p.Ct; if (++ss == p.S) { ss = 0; ++rr; } }
+            } else {
+                ss += X::BK / p.Ct;
+                while (ss >= p.S) { ss -= p.S; ++rr; }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                uint32_t o32 = voff[i];
+                if (CHECK && krem <= 0) o32 = OOB;
+                dma16(rs, tile + (i * 4 + wave) * 1024, o32);
+                voff[i] += X::BK * 2u;
+            }
+            krem -= X::BK;
+        }
+    }
+};
+
+// KROW natural image [64 k-lines][ROWS*2 B], 16-byte chunk c of line k stored at chunk c ^ tr_chunk_swz(k)
+template <int ROWS, int KMODE> struct KrowDma {
+    using X = Tr<bf16>;
+    static constexpr bool TR = true;
+    static constexpr int CH = ROWS / 8;                 // chunks per k-line
+    static constexpr int LPI = 64 / CH;                 // k-lines per DMA instruction
+    static constexpr int NI = X::BK / LPI / 4;          // DMA instructions per wave per tile
+    static_assert(KMODE != KM_GATHER, "gathered KROW operands use the register path");
+    rsrc_t rs;
+    uint32_t ldb, bound;
+    uint32_t voff[NI];
+    int kl[NI], co[NI], tap[NI];
+    bool act;
+
+    __device__ __forceinline__ void init(const GP& p, const Opnd& o, int row0, int bnd, int kt0, int tid) {
+        rs = make_rsrc(o.base, o.bytes);
+        ldb = (uint32_t)o.ld * 2u; bound = (uint32_t)bnd;
+        const int lane = tid & 63, wave = tid >> 6;
+        act = false;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int kline = (i * 4 + wave) * LPI + lane / CH;
+            const int lchunk = (lane % CH) ^ tr_chunk_swz<ROWS>(kline);
+            const int row = row0 + lchunk * 8;
+            act = row < bnd;                                        // (lchunk depends on kline only through the swizzle:
+            kl[i] = kt0 * X::BK + kline;                            //  validity is tracked per instruction below)
+            co[i] = kl[i]; tap[i] = 0;
+            if constexpr (KMODE == KM_PLAIN) {
+                voff[i] = (row < bnd) ? ((uint32_t)kl[i] * (uint32_t)o.ld + (uint32_t)row) * 2u : OOB;
+            } else {
+                tap[i] = kl[i] / p.Ct;
+                co[i] = kl[i] - tap[i] * p.Ct;
+                voff[i] = (row < bnd) ? (uint32_t)row * 2u : OOB;
+            }
+        }
+    }
+    template <bool CHECK> __device__ __forceinline__ void issue(const GP& p, unsigned char* tile, int wave) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if constexpr (KMODE == KM_PLAIN) {
+                uint32_t o32 = voff[i];
+                if (CHECK && kl[i] >= p.K) o32 = OOB;
+                dma16(rs, tile + (i * 4 + wave) * 1024, o32);
+                voff[i] += X::BK * ldb;                             // (OOB + n * BK * ld stays >= 2 GiB: K * ld < 2 GiB)
+                kl[i] += X::BK;
+            } else {
+                const int tapw = p.flip ? (p.R * p.S - 1 - tap[i]) : tap[i];
+                const bool v = tap[i] < p.R * p.S;
+                dma16(rs, tile + (i * 4 + wave) * 1024, v ? (uint32_t)co[i] * ldb + (uint32_t)tapw * bound * 2u + voff[i] : OOB);
+                co[i] += X::BK;
+                while (co[i] >= p.Ct) { co[i] -= p.Ct; ++tap[i]; }
+            }
+        }
+    }
+};
+
+template <int BM, int BN, typename LA, typename LB, int NST>
+__global__ void __launch_bounds__(256) gemm_dma_kernel(GP p) {
+    using T = bf16;
+    using X = Tr<bf16>;
+    constexpr int BK = X::BK;
+    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+    constexpr int TILE_A = BM * 128, TILE_B = BN * 128, STAGE = TILE_A + TILE_B;
+    constexpr int SMEM_BYTES = NST * STAGE;
+    constexpr int LPT = LA::NI + LB::NI;                      // DMA instructions per wave per K tile
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kt_per = (p.ktiles + p.split_k - 1) / p.split_k;
+    const int kt0 = blockIdx.z * kt_per;
+    const int nt = ((kt0 + kt_per < p.ktiles) ? kt0 + kt_per : p.ktiles) - kt0;
+    if (nt <= 0) return;
+
+    LA la;
+    LB lb;
+    {
+        Opnd oa = {p.A, p.a_tab, p.lda, p.a_mode, p.a_bytes};
+        Opnd ob = {p.B, p.b_tab, p.ldb, p.b_mode, p.b_bytes};
+        la.init(p, oa, m0, p.M, kt0, tid);
+        lb.init(p, ob, n0, p.N, kt0, tid);
+    }
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
+
+    auto issue = [&](int stage) {                     // (K tails and rows past M/N read zeros through the descriptor)
+        unsigned char* base = smem + stage * STAGE;
+        la.template issue<true>(p, base, wave);
+        lb.template issue<true>(p, base + TILE_A, wave);
+    };
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nt) issue(s);
+
+    int stage = 0;                                    // stage holding K tile t
+    for (int t = 0; t < nt; ++t) {
+        // this wave's share of tile t has landed when at most min(NST-2, tiles issued beyond t) tiles are in flight
+        if (nt - 1 - t >= NST - 2) { CB_WAIT_VMCNT(LPT * (NST - 2)); }
+        else { CB_WAIT_VMCNT(0); }
+        __builtin_amdgcn_s_barrier();                 // everyone's share landed; everyone is done reading stage (t-1)
+        if (t + NST - 1 < nt) {
+            int ns = stage + NST - 1;
+            if (ns >= NST) ns -= NST;
+            issue(ns);
+        }
+        const unsigned char* As = smem + stage * STAGE;
+        const unsigned char* Bs = As + TILE_A;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8 af[FM], bfr[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                if constexpr (LA::TR) af[i] = tr_frag<BM>(As, wm * WM + i * 16, kk, lane);
+                else af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off<T>(wm * WM + i * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                if constexpr (LB::TR) bfr[j] = tr_frag<BN>(Bs, wn * WN + j * 16, kk, lane);
+                else bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<T>(wn * WN + j * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (++stage == NST) stage = 0;
+    }
+    __syncthreads();
+    tile_epilogue<T, BM, BN, SMEM_BYTES>(p, acc, smem, m0, n0, tid);
 }
 
 __global__ void __launch_bounds__(256) pixel_table_kernel(cb_pixel* tab, int total, int OH, int OW, int stride,
@@ -878,6 +1107,25 @@ int launch_gemm(const GP& p, bool fast, hipStream_t st) {
         if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_ROWK)
             return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, RowkFast<T, BN, false>>(p, st);
         if constexpr (sizeof(T) == 2) {
+            static const bool use_dma = getenv("CB_GEMM_NO_DMA") == nullptr;
+            constexpr int NST = (BM >= 128 && BN >= 128) ? 3 : 4;
+            const bool ct_ok = p.Ct % Tr<bf16>::BK == 0;
+            if (use_dma) {
+                dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.split_k);
+#define CB_LAUNCH_DMA(LA_, LB_)                                                                               \
+    do {                                                                                                      \
+        hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, LA_, LB_, NST>), grid, dim3(NTHREADS), 0, st, p);         \
+        return cb_launch_status("cb_gemm");                                                                   \
+    } while (0)
+                using RA0 = RowkDma<BM, false>; using RA1 = RowkDma<BM, true>; using RB0 = RowkDma<BN, false>;
+                using KA0 = KrowDma<BM, KM_PLAIN>; using KB0 = KrowDma<BN, KM_PLAIN>; using KB1 = KrowDma<BN, KM_TAPS>;
+                if (p.a_mode == CB_ROWK && p.b_mode == CB_ROWK) CB_LAUNCH_DMA(RA0, RB0);
+                if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_ROWK) CB_LAUNCH_DMA(RA1, RB0);
+                if (p.a_mode == CB_ROWK && (p.b_mode == CB_KROW || (p.b_mode == CB_KROW_TAPS && taps == 1))) CB_LAUNCH_DMA(RA0, KB0);
+                if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_KROW_TAPS && ct_ok) CB_LAUNCH_DMA(RA1, KB1);
+                if (p.a_mode == CB_KROW && p.b_mode == CB_KROW) CB_LAUNCH_DMA(KA0, KB0);
+#undef CB_LAUNCH_DMA
+            }
             // measured on MI355X: next to a ROWK operand the transpose-read image wins for 64-row tiles, the
             // register transpose (KB = 4, all 256 threads) for 128-row tiles; with two KROW operands the
             // transpose-read image wins for both tile sizes (profiles/r01_gemm_microbench.md)

@@ -193,6 +193,15 @@ static inline emul_u32x4 emul_raw_buffer_load_b128(emul_rsrc r, uint32_t voff, u
 #define __builtin_amdgcn_make_buffer_rsrc emul_make_buffer_rsrc
 #define __builtin_amdgcn_raw_buffer_load_b128 emul_raw_buffer_load_b128
 
+// LDS-DMA: 16 bytes per lane from the (range-checked) buffer to wave-uniform LDS base + lane*16
+static inline void emul_buffer_load_lds(emul_rsrc r, void* lds_base, unsigned size, uint32_t voff, uint32_t soff, uint32_t, uint32_t) {
+    unsigned char* dst = (unsigned char*)lds_base + emul::cur->lane * size;
+    uint64_t o = (uint64_t)voff + soff;
+    if (o + size <= r.n) memcpy(dst, r.base + o, size); else memset(dst, 0, size);
+}
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, p, sz, vo, so, off, aux) emul_buffer_load_lds((r), (void*)(p), (sz), (vo), (so), (off), (aux))
+static inline void __builtin_amdgcn_s_waitcnt(int) {}
+
 // v_perm_b32: result byte i = byte sel[i] of the 8 bytes {s1 (0..3), s0 (4..7)}
 static inline uint32_t emul_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
     uint64_t src = ((uint64_t)s0 << 32) | s1;

@@ -1121,9 +1121,14 @@ int launch_gemm(const GP& p, bool fast, hipStream_t st) {
                 using KA0 = KrowDma<BM, KM_PLAIN>; using KB0 = KrowDma<BN, KM_PLAIN>; using KB1 = KrowDma<BN, KM_TAPS>;
                 if (p.a_mode == CB_ROWK && p.b_mode == CB_ROWK) CB_LAUNCH_DMA(RA0, RB0);
                 if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_ROWK) CB_LAUNCH_DMA(RA1, RB0);
-                if (p.a_mode == CB_ROWK && (p.b_mode == CB_KROW || (p.b_mode == CB_KROW_TAPS && taps == 1))) CB_LAUNCH_DMA(RA0, KB0);
-                if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_KROW_TAPS && ct_ok) CB_LAUNCH_DMA(RA1, KB1);
-                if (p.a_mode == CB_KROW && p.b_mode == CB_KROW) CB_LAUNCH_DMA(KA0, KB0);
+                // measured (profiles/r01_gemm_microbench.md): the DMA ring wins for k-contiguous operands only; with a
+                // transpose-read (KROW) operand the register-staged kernels below are faster, so those stay opt-in
+                static const bool dma_krow = getenv("CB_GEMM_DMA_KROW") != nullptr;
+                if (dma_krow) {
+                    if (p.a_mode == CB_ROWK && (p.b_mode == CB_KROW || (p.b_mode == CB_KROW_TAPS && taps == 1))) CB_LAUNCH_DMA(RA0, KB0);
+                    if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_KROW_TAPS && ct_ok) CB_LAUNCH_DMA(RA1, KB1);
+                    if (p.a_mode == CB_KROW && p.b_mode == CB_KROW) CB_LAUNCH_DMA(KA0, KB0);
+                }
 #undef CB_LAUNCH_DMA
             }
             // measured on MI355X: next to a ROWK operand the transpose-read image wins for 64-row tiles, the

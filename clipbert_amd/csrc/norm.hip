@@ -4,6 +4,8 @@
 // FusedLayerNorm does, and every global access is an 8/16-byte vector.  These kernels are HBM-bound.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int MAXD = 2048;  // NCH chunks of 256 elements, NCH in {3, 4, 8}
@@ -297,7 +299,8 @@ void run_ln_bwd(hipStream_t st, const void* dy, const void* x, const float* gamm
                 float* dgamma, float* dbeta, int64_t rows, int D, void* dx2, float p, uint64_t seed, const uint64_t* seed_ptr,
                 int seg_len, int seg_stride, int seg_off) {
     unsigned blocks = nblk(rows, 4);
-    if (blocks > 128) blocks = 128;          // every block ends with 2*D atomics: keep them few
+    static const unsigned cap = getenv("CB_LN_BWD_BLOCKS") ? (unsigned)atoi(getenv("CB_LN_BWD_BLOCKS")) : 128u;
+    if (blocks > cap) blocks = cap;          // every block ends with 2*D atomics: keep them few
     hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd,
                        (T*)dx, dgamma, dbeta, rows, D, (T*)dx2, p, seed, seed_ptr, seg_len, seg_stride, seg_off);
 }

@@ -49,7 +49,8 @@ struct GP {
     float alpha, dropout_p;
     uint64_t seed;
     const uint64_t* seed_ptr;
-    int c_vec;
+    int c_vec, c_vec8;
+    int xcd_remap;              // 1: remap workgroup ids so that each XCD (own L2) owns a contiguous chunk of tiles
     uint32_t a_bytes, b_bytes;
     int ktiles;
 };
@@ -607,6 +608,26 @@ template <int ROWS, int KMODE> struct KrowTr {
     }
 };
 
+// Workgroup -> (n tile, m tile, k split).  The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs,
+// each with its own L2.  Remapped, XCD x owns the x-th contiguous eighth of the (split, m tile, n tile) order, so the
+// A rows / K slices its blocks share are fetched into ONE L2 instead of all eight.
+struct TileId { int bx, by, bz; };
+__device__ __forceinline__ TileId tile_id(const GP& p) {
+    TileId t;
+    if (!p.xcd_remap) { t.bx = blockIdx.x; t.by = blockIdx.y; t.bz = blockIdx.z; return t; }
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned total = gx * gy * gridDim.z;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = lin & 7u, i = lin >> 3;
+    const unsigned q = total >> 3, r = total & 7u;
+    const unsigned l2 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    t.bx = (int)(l2 % gx);
+    const unsigned rest = l2 / gx;
+    t.by = (int)(rest % gy);
+    t.bz = (int)(rest / gy);
+    return t;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Epilogue of one 4-wide accumulator fragment (row m, columns nb..nb+3).
 // ---------------------------------------------------------------------------------------------
@@ -672,6 +693,89 @@ __device__ __forceinline__ void epilogue_elem(const GP& p, float x, int m, int64
     }
 }
 
+// 8 consecutive elements <-> float[8] (one 16-byte bf16 / two 16-byte fp32 accesses)
+__device__ __forceinline__ void load8(const float* q, float (&v)[8]) {
+    f32x4 a = load4(q), b = load4(q + 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v[r] = a[r]; v[4 + r] = b[r]; }
+}
+__device__ __forceinline__ void load8(const bf16* q, float (&v)[8]) {
+    bf16x8 x = *reinterpret_cast<const bf16x8*>(q);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = (float)x[r];
+}
+__device__ __forceinline__ void store8(float* q, const float (&v)[8]) {
+    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    store4(q, a); store4(q + 4, b);
+}
+__device__ __forceinline__ void store8(bf16* q, const float (&v)[8]) {
+    bf16x8 x;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[r] = (bf16)v[r];
+    *reinterpret_cast<bf16x8*>(q) = x;
+}
+
+// Epilogue of 8 consecutive columns n..n+7 of row m (row-contiguous: every global access is a full 16-byte lane
+// access and a wave touches whole cache lines).  sc/sh are the per-column scale/shift the thread loaded once.
+template <typename T>
+__device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const float (&sc)[8], const float (&sh)[8],
+                                          int m, int64_t orow, int n) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
+    if (p.scale) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= sc[r];
+    }
+    if (p.shift) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += sh[r];
+    }
+    if (p.C2) store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, v);
+    if (p.act != CB_ACT_NONE) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = apply_act(p.act, v[r]);
+    }
+    if (p.dropout_p > 0.f) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= dropout_mult(p.seed, (uint64_t)m * p.N + n + r, p.dropout_p);
+    }
+    if (p.residual) {
+        float t[8];
+        load8(reinterpret_cast<const T*>(p.residual) + orow * p.ldr + n, t);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += t[r];
+    }
+    if (p.relu_after) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+    }
+    if (p.mask) {
+        float t[8];
+        load8(reinterpret_cast<const T*>(p.mask) + orow * p.ldm + n, t);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = t[r] > 0.f ? v[r] : 0.f;
+    }
+    if (p.c_f32) {
+        float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + n;
+        if (p.accumulate) {
+            float t[8];
+            load8(c, t);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += t[r];
+        }
+        store8(c, v);
+    } else {
+        T* c = reinterpret_cast<T*>(p.C) + orow * p.ldc + n;
+        if (p.accumulate) {
+            float t[8];
+            load8(c, t);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += t[r];
+        }
+        store8(c, v);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Tile epilogue shared by both kernel structures.  acc[i][j] = 4 consecutive n of row m (swapped MFMA operands).
 // ---------------------------------------------------------------------------------------------
@@ -682,7 +786,74 @@ __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 
     const int wm = wave >> 1, wn = wave & 1;
     if (p.dropout_p > 0.f && p.seed_ptr) p.seed += *p.seed_ptr;
     const bool fast = p.c_vec && (n0 + BN <= p.N);      // block-uniform
-    if (fast) {
+    if (p.c_vec8) {
+        // Row-contiguous epilogue: the fp32 accumulators go through LDS (free after the main loop), half the tile
+        // rows at a time, so that each thread then owns 8 consecutive columns of one row: residual / mask reads and
+        // the stores are 16-byte lane accesses over whole cache lines (the MFMA register layout would touch 16
+        // different lines per store instruction -- the dominant cost of the short-K convolutions).
+        constexpr int SROW = BN * 4 + 16;              // +16 B staggers consecutive rows across the banks
+        constexpr int CPR = BN / 8;                    // 8-column chunks per tile row
+        constexpr int ITER = WM * CPR / NTHREADS;
+        static_assert(WM * SROW <= SMEM_BYTES, "staging does not fit");
+        static_assert(WM * CPR % NTHREADS == 0 && NTHREADS % CPR == 0, "chunk map");
+        const int cc = tid % CPR, n = n0 + cc * 8;
+        const bool nok = n < p.N;                      // N % 8 == 0 (host-checked): chunks are all-in or all-out
+        float sc[8], sh[8];
+        if (p.scale && nok) load8(p.scale + n, sc);
+        if (p.shift && nok) load8(p.shift + n, sh);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();
+            if (wm == h) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        *reinterpret_cast<f32x4*>(smem + (i * 16 + (lane & 15)) * SROW + (wn * WN + j * 16 + 4 * (lane >> 4)) * 4) = acc[i][j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int rl = (tid + it * NTHREADS) / CPR;
+                const int m = m0 + h * WM + rl;
+                if (m < p.M && nok) {
+                    const int64_t orow = p.c_rowmap ? (int64_t)p.c_rowmap[m] : (int64_t)m;
+                    float v[8];
+                    load8(reinterpret_cast<const float*>(smem + rl * SROW + cc * 32), v);
+                    epilogue8<T>(p, v, sc, sh, m, orow, n);
+                }
+            }
+        }
+    } else if (p.split_k > 1 && p.c_vec) {
+        // split-K partial sums: fp32 atomics, issued so that a wave instruction covers 64 consecutive floats of one
+        // output row (whole cache lines per L2 atomic request instead of 16 rows x 16 B from the MFMA layout).
+        constexpr int SROW = BN * 4 + 16;
+        static_assert(WM * SROW <= SMEM_BYTES, "staging does not fit");
+        float* cbase = reinterpret_cast<float*>(p.C);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();
+            if (wm == h) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        *reinterpret_cast<f32x4*>(smem + (i * 16 + (lane & 15)) * SROW + (wn * WN + j * 16 + 4 * (lane >> 4)) * 4) = acc[i][j];
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int idx = tid; idx < WM * BN; idx += NTHREADS) {
+                const int rl = idx / BN, cl = idx % BN;
+                const int m = m0 + h * WM + rl, n = n0 + cl;
+                if (m < p.M && n < p.N) {
+                    const int64_t orow = p.c_rowmap ? (int64_t)p.c_rowmap[m] : (int64_t)m;
+                    float x = *reinterpret_cast<const float*>(smem + rl * SROW + cl * 4) * p.alpha;
+                    if (p.scale) x *= p.scale[n];
+                    atomicAdd(cbase + orow * p.ldc + n, x);
+                }
+            }
+        }
+    } else if (fast) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             const int m = m0 + wm * WM + i * 16 + (lane & 15);
@@ -734,9 +905,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const TileId bid = tile_id(p);
+    const int m0 = bid.by * BM, n0 = bid.bx * BN;
     const int kt_per = (p.ktiles + p.split_k - 1) / p.split_k;
-    const int kt0 = blockIdx.z * kt_per;
+    const int kt0 = bid.bz * kt_per;
     const int nt = ((kt0 + kt_per < p.ktiles) ? kt0 + kt_per : p.ktiles) - kt0;
     if (nt <= 0) return;
 
@@ -1004,9 +1176,10 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(GP p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const TileId bid = tile_id(p);
+    const int m0 = bid.by * BM, n0 = bid.bx * BN;
     const int kt_per = (p.ktiles + p.split_k - 1) / p.split_k;
-    const int kt0 = blockIdx.z * kt_per;
+    const int kt0 = bid.bz * kt_per;
     const int nt = ((kt0 + kt_per < p.ktiles) ? kt0 + kt_per : p.ktiles) - kt0;
     if (nt <= 0) return;
 
@@ -1244,6 +1417,15 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     if (d->scale) cv = cv && aligned16(d->scale);
     if (d->shift) cv = cv && aligned16(d->shift);
     p.c_vec = cv;
+    // row-contiguous epilogue: 8-wide chunks must be 16-byte aligned everywhere; atomics (split-K) keep the 4-wide path
+    bool cv8 = cv && p.split_k == 1 && (d->N % 8 == 0) && (d->ldc % 8 == 0) && aligned16(d->C);
+    if (d->C2) cv8 = cv8 && (d->ldc2 % 8 == 0) && aligned16(d->C2);
+    if (d->residual) cv8 = cv8 && (d->ldr % 8 == 0) && aligned16(d->residual);
+    if (d->mask) cv8 = cv8 && (d->ldm % 8 == 0) && aligned16(d->mask);
+    static const bool no_wide = getenv("CB_GEMM_NO_WIDE_EPILOGUE") != nullptr;
+    p.c_vec8 = cv8 && !no_wide;
+    static const bool no_remap = getenv("CB_GEMM_NO_XCD_REMAP") != nullptr;
+    p.xcd_remap = !no_remap && p.split_k > 1;   // measured: helps K-split grids (each XCD streams its own K slices), hurts plain M x N grids
 
     hipStream_t st = cb_stream(stream);
     if (d->dtype == CB_F32) return launch_gemm<float, 64, 64, 2>(p, fast, st);

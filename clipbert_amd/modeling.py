@@ -214,9 +214,10 @@ class Runtime:
 
 
 def _pick_split(mo, no, kred):
-    """(split_k, tile) for weight-gradient GEMMs (small outputs, long pixel/token reductions).  Split-K combines
-    through fp32 atomics, which the L2 serialises (measured: 768x768x1312 takes 11 us unsplit, 27 us split in 3), so it
-    is used only for long reductions (conv weight gradients over thousands of pixels)."""
+    """(split_k, tile) for weight-gradient GEMMs (small outputs, long pixel/token reductions).  Measured on MI355X
+    (tools/wgrad_probe2.py): one 64x64 block per CU is latency-bound (~0.3 us per 64-deep K tile), so long reductions
+    are split until ~400 blocks are in flight; the partial sums combine through row-coalesced fp32 atomics.  Short
+    reductions (transformer weights over 1312 tokens) lose more to the atomics than they gain."""
     ktiles = (kred + 63) // 64
     b64 = ((mo + 63) // 64) * ((no + 63) // 64)
     b128 = ((mo + 127) // 128) * ((no + 127) // 128)
@@ -224,7 +225,7 @@ def _pick_split(mo, no, kred):
         return 1, 1
     if b64 >= 200 or ktiles < 64:
         return 1, 2
-    split = max(1, min((320 + b64 - 1) // b64, ktiles // 16))
+    split = max(1, min(ktiles // 8, (400 + b64 // 2) // b64))
     return split, 2
 
 

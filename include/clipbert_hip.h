@@ -64,7 +64,7 @@ typedef struct {
     void* C; int64_t ldc;
     const int32_t* c_rowmap;  /* optional: output row m is written at row c_rowmap[m]                */
     int32_t c_f32;            /* 1: C is fp32 regardless of dtype (parameter gradients, logits)      */
-    int32_t accumulate;       /* 1: C += result (plain RMW; with split_k > 1: fp32 atomics)          */
+    int32_t accumulate;       /* 1: C += result (plain RMW; with split_k > 1: fp32 atomics, row-coalesced) */
     int32_t split_k;          /* >= 1; > 1 requires c_f32 && accumulate semantics (C pre-initialised) */
     int32_t act;              /* CB_ACT_* applied before the residual add                            */
     const float* scale;       /* optional per-n multiplier (FrozenBN scale)                          */

@@ -12,6 +12,8 @@
 //   bwd2: dK, dV                      (lane quad = key row; recomputes P from lse)
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int DH = 64;       // head size (hidden 768 / 12 heads, src/configs/base_model.json)
@@ -241,9 +243,19 @@ __global__ void __launch_bounds__(256) attention_bwd_kv_kernel(const T* qkv, con
 
 }  // namespace
 
+// attention_mfma.hip: one-wave-per-head MFMA kernels for short bf16 sequences
+bool cb_attention_mfma_ok(int32_t dtype, const void* qkv, const void* ctx, const void* other, int32_t L);
+int cb_attention_fwd_mfma(const void* qkv, const float* key_mask, void* ctx, float* lse, int32_t B, int32_t L, int32_t H, float p,
+                          uint64_t seed, const uint64_t* seed_ptr, hipStream_t st);
+int cb_attention_bwd_mfma(const void* qkv, const float* key_mask, const void* ctx, const void* dctx, const float* lse, void* dqkv,
+                          int32_t B, int32_t L, int32_t H, float p, uint64_t seed, const uint64_t* seed_ptr, hipStream_t st);
+static bool use_mfma() { static const bool off = getenv("CB_ATTENTION_NO_MFMA") != nullptr; return !off; }
+
 extern "C" int cb_attention_fwd(int32_t dtype, const void* qkv, const float* key_mask, void* ctx, float* lse, int32_t B, int32_t L,
                                 int32_t H, float dropout_p, uint64_t dropout_seed, const uint64_t* dropout_seed_ptr, void* stream) {
     CB_REQUIRE(qkv && key_mask && ctx && B > 0 && L > 0 && H > 0, "cb_attention_fwd: bad arguments");
+    if (use_mfma() && cb_attention_mfma_ok(dtype, qkv, ctx, nullptr, L))
+        return cb_attention_fwd_mfma(qkv, key_mask, ctx, lse, B, L, H, dropout_p, dropout_seed, dropout_seed_ptr, cb_stream(stream));
     dim3 g(B * H, (L + 63) / 64), b(256);
     if (dtype == CB_BF16) hipLaunchKernelGGL((attention_fwd_kernel<bf16>), g, b, 0, cb_stream(stream), (const bf16*)qkv, key_mask, (bf16*)ctx, lse, B, L, H, dropout_p, dropout_seed, dropout_seed_ptr);
     else if (dtype == CB_F32) hipLaunchKernelGGL((attention_fwd_kernel<float>), g, b, 0, cb_stream(stream), (const float*)qkv, key_mask, (float*)ctx, lse, B, L, H, dropout_p, dropout_seed, dropout_seed_ptr);
@@ -255,6 +267,8 @@ extern "C" int cb_attention_bwd(int32_t dtype, const void* qkv, const float* key
                                 const float* lse, float* dsum_ws, void* dqkv, int32_t B, int32_t L, int32_t H, float dropout_p,
                                 uint64_t dropout_seed, const uint64_t* dropout_seed_ptr, void* stream) {
     CB_REQUIRE(qkv && key_mask && ctx && dctx && lse && dsum_ws && dqkv && B > 0 && L > 0 && H > 0, "cb_attention_bwd: bad arguments");
+    if (use_mfma() && cb_attention_mfma_ok(dtype, qkv, ctx, dctx, L) && (reinterpret_cast<uintptr_t>(dqkv) & 15) == 0)
+        return cb_attention_bwd_mfma(qkv, key_mask, ctx, dctx, lse, dqkv, B, L, H, dropout_p, dropout_seed, dropout_seed_ptr, cb_stream(stream));
     dim3 g(B * H, (L + 63) / 64), b(256);
     hipStream_t st = cb_stream(stream);
     if (dtype == CB_BF16) {

@@ -136,6 +136,28 @@ def test_attention_fwd_bwd(hw, dt, L):
     torch.testing.assert_close(dqkv.float(), x.grad, **tol(dt, 1e-4, 3e-2))
 
 
+@pytest.mark.parametrize("L", [20, 41, 64])
+def test_attention_dropout_mfma_matches_generic(hw, L):
+    """bf16 one-wave MFMA kernels vs the generic fp32 kernels on the same (bf16-valued) inputs and the same dropout
+    stream: same mask indexing in forward and backward, P rounded to bf16 before P.V the only difference."""
+    B, H, p = 2, 3, 0.3
+    qkv16 = rnd(B * L, 3 * H * 64, seed=1).to(torch.bfloat16)
+    dctx16 = rnd(B * L, H * 64, seed=2).to(torch.bfloat16)
+    mask = ones(B, L)
+    mask[0, L - 5:] = 0
+    sp = torch.tensor([11], dtype=torch.int64, device=DEV[0])
+    ctx16, lse16 = ops.attention_fwd(qkv16, mask, B, L, H, save_lse=True, dropout_p=p, dropout_seed=5, seed_ptr=sp)
+    ctx32, lse32 = ops.attention_fwd(qkv16.float(), mask, B, L, H, save_lse=True, dropout_p=p, dropout_seed=5, seed_ptr=sp)
+    torch.testing.assert_close(lse16, lse32, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(ctx16.float(), ctx32, rtol=2e-2, atol=2e-2)
+    d16 = ops.attention_bwd(qkv16, mask, ctx16, dctx16, lse16, B, L, H, dropout_p=p, dropout_seed=5, seed_ptr=sp)
+    d32 = ops.attention_bwd(qkv16.float(), mask, ctx32, dctx16.float(), lse32, B, L, H, dropout_p=p, dropout_seed=5, seed_ptr=sp)
+    torch.testing.assert_close(d16.float(), d32, rtol=3e-2, atol=3e-2)
+    # a different replay seed gives a different mask
+    ctx_b, _ = ops.attention_fwd(qkv16, mask, B, L, H, dropout_p=p, dropout_seed=6, seed_ptr=sp)
+    assert (ctx_b.float() - ctx16.float()).abs().max() > 1e-2
+
+
 def test_cross_entropy_and_colsum_and_cast_and_act(hw):
     logits = rnd(9, 37, seed=1)
     labels = torch.randint(0, 37, (9,), generator=torch.Generator().manual_seed(2)).to(DEV[0])

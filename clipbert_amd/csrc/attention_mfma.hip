@@ -1,4 +1,5 @@
-// MFMA self-attention for short sequences (L <= 64, head size 64, bf16): ONE wave owns one (batch, head).
+// MFMA self-attention for short sequences (L <= 64, head size 64, bf16): one block of ceil(L/16) waves owns one
+// (batch, head); each wave owns 16 queries (and, in the backward's second half, 16 keys).
 //
 // The cross-modal encoder of the hot path sees L = Lt + Lv = 41 tokens (29..57 across the reference's tasks), so a
 // whole head is 3x3 (at most 4x4) MFMA tiles: Q, K, V, dO fragments are loaded straight from the fused QKV
@@ -35,9 +36,9 @@ __device__ __forceinline__ bf16x8 ld_frag(const bf16* base, int64_t stride, int 
     return z;
 }
 
-// natural [row][64] image of a strided matrix in LDS, rows [L, rows) zero-filled (one wave)
-__device__ __forceinline__ void stage(const bf16* base, int64_t stride, int L, int rows, unsigned char* dst, int lane) {
-    for (int idx = lane; idx < rows * 8; idx += 64) {
+// natural [row][64] image of a strided matrix in LDS, rows [L, rows) zero-filled (whole block)
+__device__ __forceinline__ void stage(const bf16* base, int64_t stride, int L, int rows, unsigned char* dst, int tid, int nthreads) {
+    for (int idx = tid; idx < rows * 8; idx += nthreads) {
         const int r = idx >> 3, seg = idx & 7;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (r < L) v = *reinterpret_cast<const u32x4*>(base + (int64_t)r * stride + seg * 8);
@@ -76,27 +77,27 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 template <int NT>
-__global__ void __launch_bounds__(64) attn_fwd_mfma_kernel(const bf16* qkv, const float* key_mask, bf16* ctx, float* lse, int B, int L,
+__global__ void __launch_bounds__(64 * NT) attn_fwd_mfma_kernel(const bf16* qkv, const float* key_mask, bf16* ctx, float* lse, int B, int L,
                                                            int H, float drop_p, uint64_t seed, const uint64_t* seed_ptr) {
     constexpr int NP = (NT + 1) / 2;
     __shared__ __attribute__((aligned(16))) unsigned char Vs[NP * 32 * RS];
     if (drop_p > 0.f && seed_ptr) seed += *seed_ptr;
-    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int it = threadIdx.x >> 6;                    // this wave's 16-query tile
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int64_t stride = 3 * H * DH;
     const bf16* qb = qkv + (int64_t)b * L * stride + h * DH;
     const bf16* kb = qb + H * DH;
     const bf16* vb = qb + 2 * H * DH;
-    stage(vb, stride, L, NP * 32, Vs, lane);
+    stage(vb, stride, L, NP * 32, Vs, threadIdx.x, 64 * NT);
 
-    bf16x8 qf[NT][2], kf[NT][2];
+    bf16x8 qf[2], kf[NT][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = ld_frag(qb, stride, 16 * it + c, L, 32 * ks + 8 * g);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            qf[t][ks] = ld_frag(qb, stride, 16 * t + c, L, 32 * ks + 8 * g);
-            kf[t][ks] = ld_frag(kb, stride, 16 * t + c, L, 32 * ks + 8 * g);
-        }
+        for (int ks = 0; ks < 2; ++ks) kf[t][ks] = ld_frag(kb, stride, 16 * t + c, L, 32 * ks + 8 * g);
     float madd[NT][4];
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt)
@@ -112,8 +113,7 @@ __global__ void __launch_bounds__(64) attn_fwd_mfma_kernel(const bf16* qkv, cons
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) vf[jp][dt] = tr_frag(Vs, jp, dt, lane);
 
-#pragma unroll
-    for (int it = 0; it < NT; ++it) {
+    {
         const int i = 16 * it + c;                      // this lane's query (accumulator column)
         f32x4 s[NP * 2];
         float m = NEG_BIG;
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(64) attn_fwd_mfma_kernel(const bf16* qkv, cons
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             if (jt < NT) {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt][ks], qf[it][ks], acc, 0, 0, 0);
+                for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt][ks], qf[ks], acc, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     acc[r] = acc[r] * 0.125f + madd[jt][r];
@@ -169,18 +169,28 @@ __global__ void __launch_bounds__(64) attn_fwd_mfma_kernel(const bf16* qkv, cons
     }
 }
 
+// Backward: a block of 2*NT waves per (batch, head).  Waves [0, NT) ("X") own 16 queries each and produce dQ; waves
+// [NT, 2NT) ("Y") own 16 keys each and produce dK, dV.  Both halves are the same computation with the roles of the
+// matrices swapped:  tiles(rows of PA) x own columns of OA,
+//   X: PA = K, PB = V, OA = Q, OB = dO  ->  S^T = K.Q^T,  dP^T = V.dO^T,  dQ^T = K^T.dS^T
+//   Y: PA = Q, PB = dO, OA = K, OB = V  ->  S   = Q.K^T,  dP   = dO.V^T,  dK^T = Q^T.dS,  dV^T = dO^T.P_drop
 template <int NT>
-__global__ void __launch_bounds__(64) attn_bwd_mfma_kernel(const bf16* qkv, const float* key_mask, const bf16* ctx, const bf16* dctx,
-                                                           const float* lse, bf16* dqkv, int B, int L, int H, float drop_p,
-                                                           uint64_t seed, const uint64_t* seed_ptr) {
+__global__ void __launch_bounds__(128 * NT) attn_bwd_mfma_kernel(const bf16* qkv, const float* key_mask, const bf16* ctx, const bf16* dctx,
+                                                            const float* lse, bf16* dqkv, int B, int L, int H, float drop_p,
+                                                            uint64_t seed, const uint64_t* seed_ptr) {
     constexpr int NP = (NT + 1) / 2;
+    constexpr int NTHR = 128 * NT;
+    constexpr float POS_BIG = 3.0e38f;
     __shared__ __attribute__((aligned(16))) unsigned char Ks[NP * 32 * RS];
     __shared__ __attribute__((aligned(16))) unsigned char Qs[NP * 32 * RS];
     __shared__ __attribute__((aligned(16))) unsigned char Gs[NP * 32 * RS];
-    __shared__ __attribute__((aligned(16))) float Dl[NP * 32];
-    __shared__ __attribute__((aligned(16))) float Ll[NP * 32];
+    __shared__ __attribute__((aligned(16))) float Dl[NP * 32];      // D_i = rowsum(dO * O)
+    __shared__ __attribute__((aligned(16))) float Ll[NP * 32];      // lse_i (+big past L: probabilities of padding rows = 0)
     if (drop_p > 0.f && seed_ptr) seed += *seed_ptr;
-    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int wave = threadIdx.x >> 6;
+    const bool yph = wave >= NT;
+    const int wt = yph ? wave - NT : wave;
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int64_t stride = 3 * H * DH, cstride = (int64_t)H * DH;
     const bf16* qb = qkv + (int64_t)b * L * stride + h * DH;
@@ -189,136 +199,105 @@ __global__ void __launch_bounds__(64) attn_bwd_mfma_kernel(const bf16* qkv, cons
     const bf16* ob = ctx + (int64_t)b * L * cstride + h * DH;
     const bf16* gb = dctx + (int64_t)b * L * cstride + h * DH;
     bf16* dqb = dqkv + (int64_t)b * L * stride + h * DH;
-    stage(kb, stride, L, NP * 32, Ks, lane);
-    stage(qb, stride, L, NP * 32, Qs, lane);
-    stage(gb, cstride, L, NP * 32, Gs, lane);
+    stage(kb, stride, L, NP * 32, Ks, threadIdx.x, NTHR);
+    stage(qb, stride, L, NP * 32, Qs, threadIdx.x, NTHR);
+    stage(gb, cstride, L, NP * 32, Gs, threadIdx.x, NTHR);
 
-    bf16x8 qf[NT][2], kf[NT][2], vf[NT][2], gf[NT][2];
-    float Dv[NT], Lv[NT];
+    const bf16* pa = yph ? qb : kb;
+    const bf16* pb = yph ? gb : vb;
+    const bf16* oa = yph ? kb : qb;
+    const bf16* oo = yph ? vb : gb;
+    const int64_t spb = yph ? cstride : stride, soo = yph ? stride : cstride;
+    const int col = 16 * wt + c;                                    // own query (X) / key (Y)
+    bf16x8 paf[NT][2], pbf[NT][2], oaf[2], oof[2];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int ks = 0; ks < 2; ++ks) {
+        const int d = 32 * ks + 8 * g;
+        oaf[ks] = ld_frag(oa, stride, col, L, d);
+        oof[ks] = ld_frag(oo, soo, col, L, d);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            paf[t][ks] = ld_frag(pa, stride, 16 * t + c, L, d);
+            pbf[t][ks] = ld_frag(pb, spb, 16 * t + c, L, d);
+        }
+    }
+    if (!yph) {
         float part = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int d = 32 * ks + 8 * g;
-            qf[t][ks] = ld_frag(qb, stride, 16 * t + c, L, d);
-            kf[t][ks] = ld_frag(kb, stride, 16 * t + c, L, d);
-            vf[t][ks] = ld_frag(vb, stride, 16 * t + c, L, d);
-            gf[t][ks] = ld_frag(gb, cstride, 16 * t + c, L, d);
-            const bf16x8 of = ld_frag(ob, cstride, 16 * t + c, L, d);
+            const bf16x8 of = ld_frag(ob, cstride, col, L, 32 * ks + 8 * g);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) part += (float)gf[t][ks][e] * (float)of[e];
+            for (int e = 0; e < 8; ++e) part += (float)oof[ks][e] * (float)of[e];
         }
-        Dv[t] = group_sum(part);                                        // D_i = rowsum(dO * O), i = 16t + c
-        Lv[t] = (16 * t + c < L) ? lse[(int64_t)bh * L + 16 * t + c] : 0.f;
-        if (g == 0) { Dl[16 * t + c] = Dv[t]; Ll[16 * t + c] = Lv[t]; }
-    }
-    if (NT & 1) {                                                       // zero the padding tile of the last pair
-        if (g == 0) { Dl[16 * NT + c] = 0.f; Ll[16 * NT + c] = 0.f; }
+        part = group_sum(part);
+        if (g == 0) {
+            Dl[col] = part;
+            Ll[col] = col < L ? lse[(int64_t)bh * L + col] : POS_BIG;
+        }
+        if ((NT & 1) && wt == 0 && g == 1) { Dl[16 * NT + c] = 0.f; Ll[16 * NT + c] = POS_BIG; }   // padding tile of the last pair
     }
     __syncthreads();
 
-    // ---- orientation X: lane = query i, k-slots = keys j  ->  dQ -----------------------------------------
-    {
-        float madd[NT][4];
+    const float cmadd = col < L ? (1.0f - key_mask[(int64_t)b * L + col]) * MASK_NEG : NEG_BIG;   // Y: own key
+    const float clse = Ll[col], cD = Dl[col];                                                        // X: own query
+    f32x4 pd[NP * 2], ds[NP * 2];
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt)
+    for (int t = 0; t < NP * 2; ++t) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f}, pdv = {0.f, 0.f, 0.f, 0.f};
+        if (t < NT) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(paf[t][ks], oaf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pbf[t][ks], oof[ks], dp, 0, 0, 0);
+            }
+            const int row0 = 16 * t + 4 * g;                        // rows row0..row0+3: keys (X) / queries (Y)
+            f32x4 rmadd, rlse, rD;
+            if (yph) {
+                rlse = *reinterpret_cast<const f32x4*>(&Ll[row0]);
+                rD = *reinterpret_cast<const f32x4*>(&Dl[row0]);
+                rmadd = f32x4{cmadd, cmadd, cmadd, cmadd};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rmadd[r] = row0 + r < L ? (1.0f - key_mask[(int64_t)b * L + row0 + r]) * MASK_NEG : NEG_BIG;
+                rlse = f32x4{clse, clse, clse, clse};
+                rD = f32x4{cD, cD, cD, cD};
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int j = 16 * jt + 4 * g + r;
-                madd[jt][r] = j < L ? (1.0f - key_mask[(int64_t)b * L + j]) * MASK_NEG : NEG_BIG;
+                const int qry = yph ? row0 + r : col, key = yph ? col : row0 + r;
+                const float p = __expf(s[r] * 0.125f + rmadd[r] - rlse[r]);
+                float mult = 1.0f;
+                if (drop_p > 0.f) mult = dropout_mult(seed, ((uint64_t)bh * L + qry) * L + key, drop_p);
+                pdv[r] = p * mult;
+                s[r] = p * (dp[r] * mult - rD[r]) * 0.125f;
             }
+        }
+        pd[t] = pdv;
+        ds[t] = s;
+    }
+    const unsigned char* tra = yph ? Qs : Ks;
+    f32x4 a1[4], a2[4];
 #pragma unroll
-        for (int it = 0; it < NT; ++it) {
-            const int i = 16 * it + c;
-            f32x4 ds[NP * 2];
+    for (int dt = 0; dt < 4; ++dt) { a1[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; a2[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-            for (int jt = 0; jt < NP * 2; ++jt) {
-                f32x4 sT = {0.f, 0.f, 0.f, 0.f}, dpT = {0.f, 0.f, 0.f, 0.f};
-                if (jt < NT) {
+    for (int pr = 0; pr < NP; ++pr) {
+        const bf16x8 dsf = pack_pair(ds[2 * pr], ds[2 * pr + 1]);
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        sT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt][ks], qf[it][ks], sT, 0, 0, 0);
-                        dpT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[jt][ks], gf[it][ks], dpT, 0, 0, 0);
-                    }
+        for (int dt = 0; dt < 4; ++dt) a1[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(tra, pr, dt, lane), dsf, a1[dt], 0, 0, 0);
+        if (yph) {
+            const bf16x8 pdf = pack_pair(pd[2 * pr], pd[2 * pr + 1]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = __expf(sT[r] * 0.125f + madd[jt][r] - Lv[it]);
-                        float dp = dpT[r];
-                        if (drop_p > 0.f) dp *= dropout_mult(seed, ((uint64_t)bh * L + i) * L + 16 * jt + 4 * g + r, drop_p);
-                        sT[r] = p * (dp - Dv[it]) * 0.125f;
-                    }
-                }
-                ds[jt] = sT;
-            }
-            f32x4 dq[4];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int jp = 0; jp < NP; ++jp) {
-                const bf16x8 dsf = pack_pair(ds[2 * jp], ds[2 * jp + 1]);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Ks, jp, dt, lane), dsf, dq[dt], 0, 0, 0);
-            }
-            if (i < L) {
-                bf16* dst = dqb + (int64_t)i * stride + 16 * g;
-                *reinterpret_cast<bf16x8*>(dst) = pack_pair(dq[0], dq[1]);
-                *reinterpret_cast<bf16x8*>(dst + 8) = pack_pair(dq[2], dq[3]);
-            }
+            for (int dt = 0; dt < 4; ++dt) a2[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Gs, pr, dt, lane), pdf, a2[dt], 0, 0, 0);
         }
     }
-
-    // ---- orientation Y: lane = key j, k-slots = queries i  ->  dK, dV -----------------------------------
-#pragma unroll
-    for (int jt = 0; jt < NT; ++jt) {
-        const int j = 16 * jt + c;
-        const float madd = j < L ? (1.0f - key_mask[(int64_t)b * L + j]) * MASK_NEG : NEG_BIG;
-        f32x4 pd[NP * 2], ds[NP * 2];
-#pragma unroll
-        for (int it = 0; it < NP * 2; ++it) {
-            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            f32x4 pdv = {0.f, 0.f, 0.f, 0.f};
-            if (it < NT) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[it][ks], kf[jt][ks], s, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[it][ks], vf[jt][ks], dp, 0, 0, 0);
-                }
-                const f32x4 li = *reinterpret_cast<const f32x4*>(&Ll[16 * it + 4 * g]);
-                const f32x4 di = *reinterpret_cast<const f32x4*>(&Dl[16 * it + 4 * g]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * it + 4 * g + r;
-                    const float p = i < L ? __expf(s[r] * 0.125f + madd - li[r]) : 0.f;
-                    float mult = 1.0f;
-                    if (drop_p > 0.f) mult = dropout_mult(seed, ((uint64_t)bh * L + i) * L + j, drop_p);
-                    pdv[r] = p * mult;
-                    s[r] = p * (dp[r] * mult - di[r]) * 0.125f;
-                }
-            }
-            pd[it] = pdv;
-            ds[it] = s;
-        }
-        f32x4 dk[4], dv[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-        for (int ip = 0; ip < NP; ++ip) {
-            const bf16x8 pdf = pack_pair(pd[2 * ip], pd[2 * ip + 1]);
-            const bf16x8 dsf = pack_pair(ds[2 * ip], ds[2 * ip + 1]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Gs, ip, dt, lane), pdf, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Qs, ip, dt, lane), dsf, dk[dt], 0, 0, 0);
-            }
-        }
-        if (j < L) {
-            bf16* dst = dqb + (int64_t)j * stride + H * DH + 16 * g;
-            *reinterpret_cast<bf16x8*>(dst) = pack_pair(dk[0], dk[1]);
-            *reinterpret_cast<bf16x8*>(dst + 8) = pack_pair(dk[2], dk[3]);
-            dst += H * DH;
-            *reinterpret_cast<bf16x8*>(dst) = pack_pair(dv[0], dv[1]);
-            *reinterpret_cast<bf16x8*>(dst + 8) = pack_pair(dv[2], dv[3]);
+    if (col < L) {
+        bf16* dst = dqb + (int64_t)col * stride + (yph ? H * DH : 0) + 16 * g;      // dQ third (X) / dK third (Y)
+        *reinterpret_cast<bf16x8*>(dst) = pack_pair(a1[0], a1[1]);
+        *reinterpret_cast<bf16x8*>(dst + 8) = pack_pair(a1[2], a1[3]);
+        if (yph) {
+            dst += H * DH;                                                          // dV third
+            *reinterpret_cast<bf16x8*>(dst) = pack_pair(a2[0], a2[1]);
+            *reinterpret_cast<bf16x8*>(dst + 8) = pack_pair(a2[2], a2[3]);
         }
     }
 }
@@ -334,7 +313,8 @@ bool cb_attention_mfma_ok(int32_t dtype, const void* qkv, const void* ctx, const
 
 int cb_attention_fwd_mfma(const void* qkv, const float* key_mask, void* ctx, float* lse, int32_t B, int32_t L, int32_t H,
                           float p, uint64_t seed, const uint64_t* seed_ptr, hipStream_t st) {
-    dim3 g(B * H), b(64);
+    const int nt = (L + 15) / 16;
+    dim3 g(B * H), b(64 * nt);
     const bf16* q = (const bf16*)qkv;
     bf16* c = (bf16*)ctx;
     switch ((L + 15) / 16) {
@@ -348,7 +328,8 @@ int cb_attention_fwd_mfma(const void* qkv, const float* key_mask, void* ctx, flo
 
 int cb_attention_bwd_mfma(const void* qkv, const float* key_mask, const void* ctx, const void* dctx, const float* lse, void* dqkv,
                           int32_t B, int32_t L, int32_t H, float p, uint64_t seed, const uint64_t* seed_ptr, hipStream_t st) {
-    dim3 g(B * H), b(64);
+    const int nt = (L + 15) / 16;
+    dim3 g(B * H), b(128 * nt);
     const bf16 *q = (const bf16*)qkv, *c = (const bf16*)ctx, *d = (const bf16*)dctx;
     bf16* o = (bf16*)dqkv;
     switch ((L + 15) / 16) {

@@ -39,6 +39,7 @@ template <> __device__ __forceinline__ int lds_off<float>(int row, int seg) { re
 
 struct GP {
     const void* A; const void* B; void* C; void* C2; const void* residual; const void* mask;
+    const void* dact_pre; float* a_rowsum; int64_t ldd;
     const float* scale; const float* shift;
     const cb_pixel* a_tab; const cb_pixel* b_tab; const int32_t* c_rowmap;
     int64_t lda, ldb, ldc, ldc2, ldr, ldm, sH, sW;
@@ -655,6 +656,11 @@ __device__ __forceinline__ void epilogue_vec(const GP& p, f32x4 v, int m, int64_
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
     }
+    if (p.dact_pre) {
+        f32x4 pr = load4(reinterpret_cast<const T*>(p.dact_pre) + orow * p.ldd + nb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(pr[r]);
+    }
     if (p.c_f32) {
         float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + nb;
         if (p.split_k > 1) {
@@ -683,6 +689,7 @@ __device__ __forceinline__ void epilogue_elem(const GP& p, float x, int m, int64
     if (p.residual) x += to_f32(reinterpret_cast<const T*>(p.residual)[orow * p.ldr + n]);
     if (p.relu_after) x = x > 0.f ? x : 0.f;
     if (p.mask) x = to_f32(reinterpret_cast<const T*>(p.mask)[orow * p.ldm + n]) > 0.f ? x : 0.f;
+    if (p.dact_pre) x *= gelu_erf_grad(to_f32(reinterpret_cast<const T*>(p.dact_pre)[orow * p.ldd + n]));
     if (p.c_f32) {
         float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + n;
         if (p.split_k > 1) atomicAdd(c, x);
@@ -754,6 +761,12 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
         load8(reinterpret_cast<const T*>(p.mask) + orow * p.ldm + n, t);
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = t[r] > 0.f ? v[r] : 0.f;
+    }
+    if (p.dact_pre) {
+        float t[8];
+        load8(reinterpret_cast<const T*>(p.dact_pre) + orow * p.ldd + n, t);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_grad(t[r]);
     }
     if (p.c_f32) {
         float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + n;
@@ -894,7 +907,7 @@ __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 
 }
 
 
-template <typename T, int BM, int BN, typename LA, typename LB, int PF>
+template <typename T, int BM, int BN, typename LA, typename LB, int PF, bool RS = false>
 __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
     using X = Tr<T>;
     constexpr int BK = X::BK;
@@ -943,6 +956,12 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
+    // RS: row sums of A over k (bias gradients of a weight-gradient GEMM) ride on the matrix core: one extra MFMA per A
+    // fragment against an all-ones B fragment, in the first column of blocks only
+    f32x4 accr[RS ? FM : 1];
+#pragma unroll
+    for (int i = 0; i < (RS ? FM : 1); ++i) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; accr[i] = z; }
+    const bool rs_on = RS && p.a_rowsum != nullptr && bid.bx == 0 && wn == 0;     // wave-uniform
 
     // prologue: K-tile j lives in register stage j % PF
 #pragma unroll
@@ -974,6 +993,15 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
 #pragma unroll
                     for (int j = 0; j < FN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                if constexpr (RS) {
+                    if (rs_on) {
+                        bf16x8 ones;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) accr[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accr[i], 0, 0, 0);
+                    }
+                }
             }
         } else {
 #pragma unroll
@@ -990,6 +1018,12 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
 #pragma unroll
                     for (int j = 0; j < FN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                if constexpr (RS) {
+                    if (rs_on) {
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) accr[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, af[i], accr[i], 0, 0, 0);
+                    }
+                }
             }
         }
     };
@@ -1025,6 +1059,15 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
         }
     }
 
+    if constexpr (RS) {
+        if (rs_on && (lane >> 4) == 0) {                 // every accumulator row holds the sum: take row 0 of lanes 0..15
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm * WM + i * 16 + lane;
+                if (m < p.M) atomicAdd(p.a_rowsum + m, accr[i][0]);
+            }
+        }
+    }
     tile_epilogue<T, BM, BN, SMEM_BYTES>(p, acc, smem, m0, n0, tid);
 }
 
@@ -1260,11 +1303,17 @@ __global__ void __launch_bounds__(256) pixel_table_kernel(cb_pixel* tab, int tot
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <typename T, int BM, int BN, int PF, typename LA, typename LB>
+template <typename T, int BM, int BN, int PF, typename LA, typename LB, bool RS = false>
 int launch_k(const GP& p, hipStream_t st) {
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.split_k);
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, LA, LB, PF>), grid, dim3(NTHREADS), 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, LA, LB, PF, RS>), grid, dim3(NTHREADS), 0, st, p);
     return cb_launch_status("cb_gemm");
+}
+// weight-gradient form (both operands KROW): with or without the fused row sums of A
+template <typename T, int BM, int BN, int PF, typename LA, typename LB>
+int launch_wgrad(const GP& p, hipStream_t st) {
+    if (p.a_rowsum) return launch_k<T, BM, BN, PF, LA, LB, true>(p, st);
+    return launch_k<T, BM, BN, PF, LA, LB, false>(p, st);
 }
 
 // addressing-mode dispatch: lean compile-time loaders on the fast path, the generic loaders otherwise
@@ -1300,7 +1349,7 @@ int launch_gemm(const GP& p, bool fast, hipStream_t st) {
                 if (dma_krow) {
                     if (p.a_mode == CB_ROWK && (p.b_mode == CB_KROW || (p.b_mode == CB_KROW_TAPS && taps == 1))) CB_LAUNCH_DMA(RA0, KB0);
                     if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_KROW_TAPS && ct_ok) CB_LAUNCH_DMA(RA1, KB1);
-                    if (p.a_mode == CB_KROW && p.b_mode == CB_KROW) CB_LAUNCH_DMA(KA0, KB0);
+                    if (p.a_mode == CB_KROW && p.b_mode == CB_KROW && !p.a_rowsum) CB_LAUNCH_DMA(KA0, KB0);
                 }
 #undef CB_LAUNCH_DMA
             }
@@ -1314,7 +1363,7 @@ int launch_gemm(const GP& p, bool fast, hipStream_t st) {
                     return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, KrowTr<BN, KM_TAPS>>(p, st);
             }
             if (p.a_mode == CB_KROW && p.b_mode == CB_KROW)
-                return launch_k<T, BM, BN, PF, KrowTr<BM, KM_PLAIN>, KrowTr<BN, KM_PLAIN>>(p, st);
+                return launch_wgrad<T, BM, BN, PF, KrowTr<BM, KM_PLAIN>, KrowTr<BN, KM_PLAIN>>(p, st);
             if (p.a_mode == CB_KROW && p.b_mode == CB_KROW_GATHER)
                 return launch_k<T, BM, BN, PF, KrowTr<BM, KM_PLAIN>, KrowTr<BN, KM_GATHER>>(p, st);
         }
@@ -1327,12 +1376,13 @@ int launch_gemm(const GP& p, bool fast, hipStream_t st) {
         if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_KROW_TAPS)
             return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, KrowFast<T, BN, KM_TAPS, KB1B, 0>>(p, st);
         if (p.a_mode == CB_KROW && p.b_mode == CB_KROW)
-            return launch_k<T, BM, BN, PF, KrowFast<T, BM, KM_PLAIN, KB2A, 0>, KrowFast<T, BN, KM_PLAIN, KB2B, 128>>(p, st);
+            return launch_wgrad<T, BM, BN, PF, KrowFast<T, BM, KM_PLAIN, KB2A, 0>, KrowFast<T, BN, KM_PLAIN, KB2B, 128>>(p, st);
         if (p.a_mode == CB_KROW && p.b_mode == CB_KROW_GATHER)
             return launch_k<T, BM, BN, PF, KrowFast<T, BM, KM_PLAIN, KB2A, 0>, KrowFast<T, BN, KM_GATHER, KB2B, 128>>(p, st);
     }
     if (!a_krow && !b_krow) return launch_k<T, BM, BN, PF, RowkLoader<T, BM, false>, RowkLoader<T, BN, false>>(p, st);
     if (!a_krow) return launch_k<T, BM, BN, PF, RowkLoader<T, BM, false>, KrowLoader<T, BN, false>>(p, st);
+    if (p.b_mode == CB_KROW) return launch_wgrad<T, BM, BN, PF, KrowLoader<T, BM, false>, KrowLoader<T, BN, false>>(p, st);
     return launch_k<T, BM, BN, PF, KrowLoader<T, BM, false>, KrowLoader<T, BN, false>>(p, st);
 }
 
@@ -1348,6 +1398,8 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     const int eps = 16 / esz;
     GP p{};
     p.A = d->A; p.B = d->B; p.C = d->C; p.C2 = d->C2; p.residual = d->residual; p.mask = d->mask;
+    p.dact_pre = d->gelu_grad_pre; p.ldd = d->ld_gelu; p.a_rowsum = d->a_rowsum;
+    CB_REQUIRE(!d->a_rowsum || (d->a_mode == CB_KROW && d->b_mode == CB_KROW), "cb_gemm: a_rowsum needs the weight-gradient form (A and B both CB_KROW)");
     p.scale = d->scale; p.shift = d->shift; p.a_tab = d->a_tab; p.b_tab = d->b_tab; p.c_rowmap = d->c_rowmap;
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldc2 = d->ldc2; p.ldr = d->ldr; p.ldm = d->ldm;
     p.sH = d->sH; p.sW = d->sW;
@@ -1403,7 +1455,7 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     p.b_bytes = (uint32_t)(fast ? d->b_bytes : 0);
     if (p.split_k > 1) {
         CB_REQUIRE(d->c_f32, "cb_gemm: split_k > 1 needs an fp32 output");
-        CB_REQUIRE(!d->C2 && !d->residual && !d->mask && d->act == CB_ACT_NONE && !d->relu_after && !d->shift && d->dropout_p <= 0.f,
+        CB_REQUIRE(!d->C2 && !d->residual && !d->mask && !d->gelu_grad_pre && d->act == CB_ACT_NONE && !d->relu_after && !d->shift && d->dropout_p <= 0.f,
                    "cb_gemm: split_k > 1 supports only scale/alpha in the epilogue");
         if (p.split_k > p.ktiles) p.split_k = p.ktiles;
     }
@@ -1414,6 +1466,7 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     if (d->C2) cv = cv && (d->ldc2 % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->C2) % (4 * esz)) == 0);
     if (d->residual) cv = cv && (d->ldr % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->residual) % (4 * esz)) == 0);
     if (d->mask) cv = cv && (d->ldm % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->mask) % (4 * esz)) == 0);
+    if (d->gelu_grad_pre) cv = cv && (d->ld_gelu % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->gelu_grad_pre) % (4 * esz)) == 0);
     if (d->scale) cv = cv && aligned16(d->scale);
     if (d->shift) cv = cv && aligned16(d->shift);
     p.c_vec = cv;
@@ -1422,6 +1475,7 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     if (d->C2) cv8 = cv8 && (d->ldc2 % 8 == 0) && aligned16(d->C2);
     if (d->residual) cv8 = cv8 && (d->ldr % 8 == 0) && aligned16(d->residual);
     if (d->mask) cv8 = cv8 && (d->ldm % 8 == 0) && aligned16(d->mask);
+    if (d->gelu_grad_pre) cv8 = cv8 && (d->ld_gelu % 8 == 0) && aligned16(d->gelu_grad_pre);
     static const bool no_wide = getenv("CB_GEMM_NO_WIDE_EPILOGUE") != nullptr;
     p.c_vec8 = cv8 && !no_wide;
     static const bool no_remap = getenv("CB_GEMM_NO_XCD_REMAP") != nullptr;

@@ -644,12 +644,12 @@ def encoder_forward(model: ClipBertBaseModel, grid, ids, mask, src_row, pooled_d
 def _linear_wgrad(rt: Runtime, g, x, lin_weight, lin_bias, m, n, k, ldx=None, grad_w=None, grad_b=None):
     """dW[n,k] += g[m,n]^T x[m,k];  db[n] += colsum(g)."""
     gw = grad_w if grad_w is not None else rt.bank.grad_image(lin_weight)
+    gb = grad_b if grad_b is not None else (rt.bank.grad_image(lin_bias) if lin_bias is not None else None)
     if gw is not None:
         split, tile = _pick_split(n, k, m)
         ops.gemm(g, x, n, k, m, out=gw, a_mode=KROW, lda=g.stride(0), b_mode=KROW, ldb=ldx if ldx is not None else x.stride(0),
-                 accumulate=True, split_k=split, tile=tile)
-    gb = grad_b if grad_b is not None else (rt.bank.grad_image(lin_bias) if lin_bias is not None else None)
-    if gb is not None:
+                 accumulate=True, split_k=split, tile=tile, a_rowsum=gb)       # db rides on the same kernel
+    elif gb is not None:
         ops.colsum(g, gb, m, n)
 
 
@@ -687,9 +687,8 @@ def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
         g = d_o_drop if d_o_drop is not None else d_o_pre
         with rt.side(g, hact):
             _linear_wgrad(rt, g, hact, ou.dense.weight, ou.dense.bias, M, d, ff)
-        dh = torch.empty(M, ff, dtype=dt, device=dev)
-        ops.gemm(g, bank.compute(ou.dense.weight), M, ff, d, out=dh, b_mode=KROW)
-        dhp = ops.act_bwd(ACT_GELU, dh, hpre)
+        dhp = torch.empty(M, ff, dtype=dt, device=dev)
+        ops.gemm(g, bank.compute(ou.dense.weight), M, ff, d, out=dhp, b_mode=KROW, gelu_grad_pre=hpre)   # dgrad + GELU'
         with rt.side(dhp, a):
             _linear_wgrad(rt, dhp, a, it.dense.weight, it.dense.bias, M, ff, d)
         da = torch.empty(M, d, dtype=dt, device=dev)

@@ -51,7 +51,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch
          b_mode=ROWK, lda=None, ldb=None, ldc=None, a_tab=None, b_tab=None, R=1, S=1, Cin=0, H=0, W=0,
          sH=0, sW=0, flip_taps=False, c_rowmap=None, accumulate=False, split_k=1, act=ACT_NONE,
          scale=None, shift=None, residual=None, ldr=None, relu_after=False, mask=None, ldm=None,
-         out2=None, ldc2=None, alpha=1.0, dropout_p=0.0, dropout_seed=0, seed_ptr=None, tile=0):
+         out2=None, ldc2=None, alpha=1.0, dropout_p=0.0, dropout_seed=0, seed_ptr=None, tile=0, gelu_grad_pre=None, a_rowsum=None):
     """C[M,N] (op)= epilogue(sum_k A(m,k) B(n,k)); see include/clipbert_hip.h cb_gemm_desc."""
     d = GemmDesc()
     d.dtype = dtype_code(a.dtype)
@@ -86,6 +86,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch
     d.tile = tile
     d.a_bytes = _extent_bytes(a)
     d.b_bytes = _extent_bytes(b)
+    if gelu_grad_pre is not None:
+        d.gelu_grad_pre, d.ld_gelu = _ptr(gelu_grad_pre), gelu_grad_pre.stride(0)
+    if a_rowsum is not None:
+        assert a_rowsum.dtype == torch.float32
+        d.a_rowsum = _ptr(a_rowsum)
     _chk(_lib.get().cb_gemm(C.byref(d), _stream(a)), "cb_gemm")
     return out
 

@@ -83,6 +83,10 @@ typedef struct {
     int64_t a_bytes, b_bytes; /* sizes of the A / B buffers in bytes (0 = unknown).  When both are known, < 2 GiB
                                  and every row / tap start is 16-byte aligned the kernel uses range-checked
                                  buffer loads (fast path); otherwise element-wise guarded loads.           */
+    const void* gelu_grad_pre; int64_t ld_gelu;  /* optional: result *= gelu'(pre[m,n]) (last step before the store):
+                                 the GELU backward of BertIntermediate fused into the dgrad of BertOutput.dense  */
+    float* a_rowsum;          /* optional, weight-gradient form only (A and B CB_KROW): a_rowsum[m] += sum_k A(m,k),
+                                 i.e. the bias gradient colsum(dY), computed on the matrix core next to dW (atomics) */
 } cb_gemm_desc;
 
 /* GEMM / implicit-GEMM convolution, all forms.  Replaces torch.nn.Linear / F.conv2d (+ apex-amp

@@ -58,6 +58,37 @@ def test_linear_dgrad_wgrad(hw, dt, tile):
     torch.testing.assert_close(dw2, g2.float().t() @ x.float(), **tol(dt))
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("tile", [2, 1])
+def test_fused_bias_grad_and_gelu_grad(hw, dt, tile):
+    """wgrad with the bias gradient on the matrix core (a_rowsum) and dgrad with GELU' in the epilogue."""
+    if dt == torch.float32 and tile == 1:
+        pytest.skip("fp32 parity mode has one tile size")
+    M, N, K = 150, 72, 136                               # tokens, out features, in features
+    x, g = hw(rnd(M, K, seed=1).to(dt)), hw(rnd(M, N, seed=3).to(dt))
+    for split in (1, 2):
+        dw = torch.zeros(N, K, dtype=torch.float32, device=hw.dev)
+        db = torch.ones(N, dtype=torch.float32, device=hw.dev)
+        ops.gemm(g, x, N, K, M, out=dw, a_mode=ops.KROW, b_mode=ops.KROW, accumulate=True, split_k=split, tile=tile, a_rowsum=db)
+        torch.testing.assert_close(dw, g.float().t() @ x.float(), **tol(dt))
+        torch.testing.assert_close(db, 1.0 + g.float().sum(0), **tol(dt))
+    # unaligned shapes take the generic loaders: same contract
+    g2 = hw(rnd(M, 3, seed=5).to(dt))
+    dw2 = torch.zeros(3, K, dtype=torch.float32, device=hw.dev)
+    db2 = torch.zeros(3, dtype=torch.float32, device=hw.dev)
+    ops.gemm(g2, x, 3, K, M, out=dw2, a_mode=ops.KROW, b_mode=ops.KROW, accumulate=True, a_rowsum=db2)
+    torch.testing.assert_close(dw2, g2.float().t() @ x.float(), **tol(dt))
+    torch.testing.assert_close(db2, g2.float().sum(0), **tol(dt))
+    # dX = (g W) * gelu'(pre)
+    w = hw(rnd(N, K, seed=2, scale=0.2).to(dt))
+    pre = hw(rnd(M, K, seed=7).to(dt))
+    dx = torch.empty(M, K, dtype=dt, device=hw.dev)
+    ops.gemm(g, w, M, K, N, out=dx, b_mode=ops.KROW, tile=tile, gelu_grad_pre=pre)
+    pr = pre.float().requires_grad_(True)
+    F.gelu(pr).backward(g.float() @ w.float())
+    torch.testing.assert_close(dx.float(), pr.grad, **tol(dt))
+
+
 def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 

@@ -92,10 +92,20 @@ def test_forward_backward_matches_oracle_fp32(hw, head, extra, repeat):
         if g_ref is None:
             g_ref = torch.zeros_like(p, device="cpu")
         scale = max(g_ref.abs().max().item(), 1e-5)   # key.bias has an exactly-zero gradient (softmax shift invariance)
-        err = (p.grad.cpu() - g_ref).abs().max().item() / scale
+        diff = p.grad.cpu() - g_ref
+        err = diff.abs().max().item() / scale
         if err > worst[0]:
             worst = (err, name)
-        assert err < gt, f"{name}: relative grad error {err:.3e} (|g|max {scale:.3e})"
+        if hw.name == "emul":
+            assert err < gt, f"{name}: relative grad error {err:.3e} (|g|max {scale:.3e})"
+        else:
+            # On the GPU exp/erf/tanh and the summation orders differ from the host in the last ulps; a pre-activation
+            # within that distance of zero flips its ReLU (or a max-pool tie) and changes a handful of gradient
+            # elements by a finite amount.  So: tight bound on the relative L2 error of the whole tensor, loose bound
+            # on the single worst element.
+            l2 = diff.norm().item() / max(g_ref.norm().item(), 1e-5 * g_ref.numel() ** 0.5)
+            assert l2 < gt, f"{name}: relative L2 grad error {l2:.3e} (|g| {g_ref.norm().item():.3e})"
+            assert err < 10 * gt, f"{name}: worst-element grad error {err:.3e} (|g|max {scale:.3e})"
         checked += 1
     assert checked > 40, checked
     # frozen stem / res2 must not have been touched

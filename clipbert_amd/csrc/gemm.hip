@@ -40,6 +40,7 @@ template <> __device__ __forceinline__ int lds_off<float>(int row, int seg) { re
 struct GP {
     const void* A; const void* B; void* C; void* C2; const void* residual; const void* mask;
     const void* dact_pre; float* a_rowsum; int64_t ldd;
+    int batch; int64_t bs_a, bs_b, bs_c, bs_r;      // strided-batched problems on gridDim.z (strides in BYTES; bs_r in floats)
     const float* scale; const float* shift;
     const cb_pixel* a_tab; const cb_pixel* b_tab; const int32_t* c_rowmap;
     int64_t lda, ldb, ldc, ldc2, ldr, ldm, sH, sW;
@@ -629,6 +630,20 @@ __device__ __forceinline__ TileId tile_id(const GP& p) {
     return t;
 }
 
+// strided-batched problems: grid z = batch * split_k + k split.  Rebases the operands of this block's problem.
+__device__ __forceinline__ void apply_batch(GP& p, TileId& t) {
+    if (p.batch <= 1) return;
+    const int b = t.bz / p.split_k;
+    t.bz -= b * p.split_k;
+    const int64_t oa = b * p.bs_a, ob = b * p.bs_b;
+    p.A = reinterpret_cast<const unsigned char*>(p.A) + oa;
+    p.B = reinterpret_cast<const unsigned char*>(p.B) + ob;
+    p.C = reinterpret_cast<unsigned char*>(p.C) + b * p.bs_c;
+    if (p.a_bytes) p.a_bytes -= (uint32_t)oa;              // the range check of the buffer descriptors keeps covering the
+    if (p.b_bytes) p.b_bytes -= (uint32_t)ob;              // rest of the stacked buffer
+    if (p.a_rowsum) p.a_rowsum += b * p.bs_r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Epilogue of one 4-wide accumulator fragment (row m, columns nb..nb+3).
 // ---------------------------------------------------------------------------------------------
@@ -918,7 +933,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(GP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const TileId bid = tile_id(p);
+    TileId bid = tile_id(p);
+    apply_batch(p, bid);
     const int m0 = bid.by * BM, n0 = bid.bx * BN;
     const int kt_per = (p.ktiles + p.split_k - 1) / p.split_k;
     const int kt0 = bid.bz * kt_per;
@@ -1219,7 +1235,8 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(GP p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const TileId bid = tile_id(p);
+    TileId bid = tile_id(p);
+    apply_batch(p, bid);
     const int m0 = bid.by * BM, n0 = bid.bx * BN;
     const int kt_per = (p.ktiles + p.split_k - 1) / p.split_k;
     const int kt0 = bid.bz * kt_per;
@@ -1305,7 +1322,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 template <typename T, int BM, int BN, int PF, typename LA, typename LB, bool RS = false>
 int launch_k(const GP& p, hipStream_t st) {
-    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.split_k);
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.split_k * (p.batch > 1 ? p.batch : 1));
     hipLaunchKernelGGL((gemm_kernel<T, BM, BN, LA, LB, PF, RS>), grid, dim3(NTHREADS), 0, st, p);
     return cb_launch_status("cb_gemm");
 }
@@ -1333,7 +1350,7 @@ int launch_gemm(const GP& p, bool fast, hipStream_t st) {
             constexpr int NST = (BM >= 128 && BN >= 128) ? 3 : 4;
             const bool ct_ok = p.Ct % Tr<bf16>::BK == 0;
             if (use_dma) {
-                dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.split_k);
+                dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.split_k * (p.batch > 1 ? p.batch : 1));
 #define CB_LAUNCH_DMA(LA_, LB_)                                                                               \
     do {                                                                                                      \
         hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, LA_, LB_, NST>), grid, dim3(NTHREADS), 0, st, p);         \
@@ -1399,6 +1416,15 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     GP p{};
     p.A = d->A; p.B = d->B; p.C = d->C; p.C2 = d->C2; p.residual = d->residual; p.mask = d->mask;
     p.dact_pre = d->gelu_grad_pre; p.ldd = d->ld_gelu; p.a_rowsum = d->a_rowsum;
+    p.batch = d->batch > 1 ? d->batch : 1;
+    p.bs_a = d->batch_stride_a * esz; p.bs_b = d->batch_stride_b * esz;
+    p.bs_c = d->batch_stride_c * (d->c_f32 ? 4 : esz); p.bs_r = d->batch_stride_rowsum;
+    if (p.batch > 1) {
+        CB_REQUIRE(!d->C2 && !d->residual && !d->mask && !d->gelu_grad_pre && !d->a_tab && !d->b_tab && !d->c_rowmap,
+                   "cb_gemm: batch > 1 supports plain operands only (no residual / mask / second output / gather / row map)");
+        CB_REQUIRE((d->batch_stride_a * esz) % 16 == 0 && (d->batch_stride_b * esz) % 16 == 0 && (p.bs_c % 16) == 0,
+                   "cb_gemm: batch strides must keep 16-byte alignment");
+    }
     CB_REQUIRE(!d->a_rowsum || (d->a_mode == CB_KROW && d->b_mode == CB_KROW), "cb_gemm: a_rowsum needs the weight-gradient form (A and B both CB_KROW)");
     p.scale = d->scale; p.shift = d->shift; p.a_tab = d->a_tab; p.b_tab = d->b_tab; p.c_rowmap = d->c_rowmap;
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldc2 = d->ldc2; p.ldr = d->ldr; p.ldm = d->ldm;
@@ -1485,9 +1511,10 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     if (d->dtype == CB_F32) return launch_gemm<float, 64, 64, 2>(p, fast, st);
     int tile = d->tile;
     if (tile == 0) {
-        int64_t blocks128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * p.split_k;
+        int64_t blocks128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * p.split_k * p.batch;
         tile = blocks128 >= 448 ? 1 : 2;               // below ~2 blocks per CU the 64x64 tile fills the chip better
-        if (d->N <= 64 && (int64_t)((d->M + 127) / 128) * p.split_k >= 448) tile = 3;
+        if (d->a_mode == CB_KROW) tile = 2;            // weight-gradient form: measured faster with 64x64 tiles at every size
+        if (d->N <= 64 && (int64_t)((d->M + 127) / 128) * p.split_k * p.batch >= 448) tile = 3;
     }
     if (tile == 1 && d->N <= 64) tile = 3;           // narrow outputs (stem / res2 convs): 128x64 tile
     if (tile == 1) return launch_gemm<bf16, 128, 128, 2>(p, fast, st);

@@ -220,9 +220,6 @@ def _pick_split(mo, no, kred):
     reductions (transformer weights over 1312 tokens) lose more to the atomics than they gain."""
     ktiles = (kred + 63) // 64
     b64 = ((mo + 63) // 64) * ((no + 63) // 64)
-    b128 = ((mo + 127) // 128) * ((no + 127) // 128)
-    if b128 >= 448:
-        return 1, 1
     if b64 >= 200 or ktiles < 64:
         return 1, 2
     split = max(1, min(ktiles // 8, (400 + b64 // 2) // b64))
@@ -584,7 +581,14 @@ def encoder_forward(model: ClipBertBaseModel, grid, ids, mask, src_row, pooled_d
         assert bv == bsz, "visual batch and text batch differ: pass src_row (n_examples_list)"
     key_mask = torch.ones(bsz, L, dtype=torch.float32, device=dev)
     key_mask[:, :lt] = mask.to(torch.float32)
-    x = torch.empty(M, d, dtype=dt, device=dev)
+    nl, ff = len(model.encoder.layer), cfg.intermediate_size
+    # The operands of the weight-gradient GEMMs are kept LAYER-STACKED ([layer, M, *]): the backward then computes the
+    # weight gradients of all layers of one kind in a single strided-batched launch (encoder_backward).
+    stk = None
+    if save:
+        stk = SimpleNamespace(x=torch.empty(nl, M, d, dtype=dt, device=dev), ctx=torch.empty(nl, M, d, dtype=dt, device=dev),
+                              a=torch.empty(nl, M, d, dtype=dt, device=dev), hact=torch.empty(nl, M, ff, dtype=dt, device=dev))
+    x = stk.x[0] if save else torch.empty(M, d, dtype=dt, device=dev)
     pre = torch.empty(M, d, dtype=dt, device=dev) if save else None
     mean0 = torch.empty(M, dtype=torch.float32, device=dev) if save else None
     rstd0 = torch.empty(M, dtype=torch.float32, device=dev) if save else None
@@ -607,19 +611,20 @@ def encoder_forward(model: ClipBertBaseModel, grid, ids, mask, src_row, pooled_d
         qkv = torch.empty(M, 3 * d, dtype=dt, device=dev)
         ops.gemm(x, wqkv, M, 3 * d, d, out=qkv, shift=bqkv)
         ctx, lse = ops.attention_fwd(qkv, key_mask, bsz, L, nh, save_lse=save, dropout_p=p_a,
-                                     dropout_seed=_seed(_SITE_ATTN, li), seed_ptr=rt.seed_dev)
+                                     dropout_seed=_seed(_SITE_ATTN, li), seed_ptr=rt.seed_dev, out=stk.ctx[li] if save else None)
         a_pre = torch.empty(M, d, dtype=dt, device=dev)
         ops.gemm(ctx, bank.compute(so.dense.weight), M, d, d, out=a_pre, shift=so.dense.bias, residual=x, dropout_p=p_h,
                  dropout_seed=_seed(_SITE_SELF_OUT, li), seed_ptr=rt.seed_dev)
-        a, mean1, rstd1 = ops.layernorm_fwd(a_pre, so.LayerNorm.weight, so.LayerNorm.bias, eps, save_stats=save)
-        ff = cfg.intermediate_size
-        hact = torch.empty(M, ff, dtype=dt, device=dev)
+        a, mean1, rstd1 = ops.layernorm_fwd(a_pre, so.LayerNorm.weight, so.LayerNorm.bias, eps, save_stats=save,
+                                            out=stk.a[li] if save else None)
+        hact = stk.hact[li] if save else torch.empty(M, ff, dtype=dt, device=dev)
         hpre = torch.empty(M, ff, dtype=dt, device=dev) if save else None
         ops.gemm(a, bank.compute(it.dense.weight), M, ff, d, out=hact, shift=it.dense.bias, act=ACT_GELU, out2=hpre)
         o_pre = torch.empty(M, d, dtype=dt, device=dev)
         ops.gemm(hact, bank.compute(ou.dense.weight), M, d, ff, out=o_pre, shift=ou.dense.bias, residual=a, dropout_p=p_h,
                  dropout_seed=_seed(_SITE_OUT, li), seed_ptr=rt.seed_dev)
-        out, mean2, rstd2 = ops.layernorm_fwd(o_pre, ou.LayerNorm.weight, ou.LayerNorm.bias, eps, save_stats=save)
+        out, mean2, rstd2 = ops.layernorm_fwd(o_pre, ou.LayerNorm.weight, ou.LayerNorm.bias, eps, save_stats=save,
+                                              out=stk.x[li + 1] if (save and li + 1 < nl) else None)
         if save:
             layers.append((x, qkv, ctx, lse, a_pre, mean1, rstd1, a, hpre, hact, o_pre, mean2, rstd2))
         x = out
@@ -637,13 +642,13 @@ def encoder_forward(model: ClipBertBaseModel, grid, ids, mask, src_row, pooled_d
     if save:
         pack = SimpleNamespace(layers=layers, x_final=x, pooled=pooled, pooled_raw=pooled_raw, p_pool=p_pool, pre=pre,
                                mean0=mean0, rstd0=rstd0, ids=ids_c, key_mask=key_mask, src_row=src_row, sel=sel, bsz=bsz,
-                               lt=lt, lv=lv, L=L, grid_shape=tuple(grid.shape), p_h=p_h, p_a=p_a)
+                               lt=lt, lv=lv, L=L, grid_shape=tuple(grid.shape), p_h=p_h, p_a=p_a, stk=stk)
     return x, pooled, pack
 
 
 def _linear_wgrad(rt: Runtime, g, x, lin_weight, lin_bias, m, n, k, ldx=None, grad_w=None, grad_b=None):
     """dW[n,k] += g[m,n]^T x[m,k];  db[n] += colsum(g)."""
-    gw = grad_w if grad_w is not None else rt.bank.grad_image(lin_weight)
+    gw = grad_w if grad_w is not None else (rt.bank.grad_image(lin_weight) if lin_weight is not None else None)
     gb = grad_b if grad_b is not None else (rt.bank.grad_image(lin_bias) if lin_bias is not None else None)
     if gw is not None:
         split, tile = _pick_split(n, k, m)
@@ -651,6 +656,56 @@ def _linear_wgrad(rt: Runtime, g, x, lin_weight, lin_bias, m, n, k, ldx=None, gr
                  accumulate=True, split_k=split, tile=tile, a_rowsum=gb)       # db rides on the same kernel
     elif gb is not None:
         ops.colsum(g, gb, m, n)
+
+
+def _uniform_stride(tensors):
+    """element stride between consecutive tensors of a list if they are equally spaced views of one buffer, else None"""
+    if any(t is None for t in tensors):
+        return None
+    if len(tensors) == 1:
+        return 0
+    esz = tensors[0].element_size()
+    step = tensors[1].data_ptr() - tensors[0].data_ptr()
+    if step <= 0 or step % esz:
+        return None
+    for i in range(2, len(tensors)):
+        if tensors[i].data_ptr() - tensors[i - 1].data_ptr() != step:
+            return None
+    return step // esz
+
+
+def _encoder_wgrads(model, pk, gs, M):
+    """Weight and bias gradients of every encoder layer: one strided-batched weight-gradient GEMM per kind when the
+    layers' gradient images are equally spaced in the flat gradient buffer (they are: same parameter order in every
+    layer), per-layer launches otherwise (frozen layers)."""
+    rt, cfg = model.rt, model.config
+    bank = rt.bank
+    d, ff = cfg.hidden_size, cfg.intermediate_size
+    layers = list(model.encoder.layer)
+    nl, stk = len(layers), pk.stk
+
+    def qkv_w(l):
+        return bank.grad_span(l.attention.self.query.weight, l.attention.self.value.weight, (3 * d, d)) \
+            if bank.is_trainable(l.attention.self.query.weight) else None
+
+    def qkv_b(l):
+        return bank.grad_span(l.attention.self.query.bias, l.attention.self.value.bias, (3 * d,)) \
+            if bank.is_trainable(l.attention.self.query.bias) else None
+
+    kinds = [  # (upstream gradient stack, input stack, out features, in features, dW images, db images)
+        (gs.out, stk.hact, d, ff, [bank.grad_image(l.output.dense.weight) for l in layers], [bank.grad_image(l.output.dense.bias) for l in layers]),
+        (gs.hp, stk.a, ff, d, [bank.grad_image(l.intermediate.dense.weight) for l in layers], [bank.grad_image(l.intermediate.dense.bias) for l in layers]),
+        (gs.att, stk.ctx, d, d, [bank.grad_image(l.attention.output.dense.weight) for l in layers], [bank.grad_image(l.attention.output.dense.bias) for l in layers]),
+        (gs.qkv, stk.x, 3 * d, d, [qkv_w(l) for l in layers], [qkv_b(l) for l in layers]),
+    ]
+    for g, x, n, k, gws, gbs in kinds:
+        sw, sb = _uniform_stride(gws), _uniform_stride(gbs)
+        if sw is not None and sb is not None and n % 8 == 0 and k % 8 == 0:
+            ops.gemm(g, x, n, k, M, out=gws[0], a_mode=KROW, lda=n, b_mode=KROW, ldb=k, ldc=k, accumulate=True, a_rowsum=gbs[0],
+                     batch=nl, batch_strides=(M * n, M * k, sw, sb))
+        else:
+            for li in range(nl):
+                _linear_wgrad(rt, g[li], x[li], None, None, M, n, k, grad_w=gws[li], grad_b=gbs[li])
 
 
 def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
@@ -678,37 +733,36 @@ def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
         _linear_wgrad(rt, g, pk.x_final, pw.weight, pw.bias, bsz, d, d, ldx=L * d)
         ops.gemm(g, bank.compute(pw.weight), bsz, d, d, out=dx, b_mode=KROW, ldc=L * d, accumulate=True)
     # ---- encoder layers, last to first -----------------------------------------------------------------
-    for li in range(len(pk.layers) - 1, -1, -1):
+    # The dgrad chain runs layer by layer; the upstream gradients that the weight gradients need are written into
+    # layer-stacked buffers and ALL layers' weight (+ bias) gradients of one kind follow in one strided-batched GEMM
+    # each (4 launches instead of 4 per layer: 12x the blocks per launch, 128x128 tiles, no launch tails).
+    nl, stk = len(pk.layers), pk.stk
+    gs = SimpleNamespace(out=torch.empty(nl, M, d, dtype=dt, device=dev), hp=torch.empty(nl, M, ff, dtype=dt, device=dev),
+                         att=torch.empty(nl, M, d, dtype=dt, device=dev), qkv=torch.empty(nl, M, 3 * d, dtype=dt, device=dev))
+    for li in range(nl - 1, -1, -1):
         layer = model.encoder.layer[li]
         att, so, it, ou = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
         x, qkv, ctx, lse, a_pre, mean1, rstd1, a, hpre, hact, o_pre, mean2, rstd2 = pk.layers[li]
+        keep = dict(dx2=gs.out[li]) if pk.p_h > 0 else dict(dx=gs.out[li])
         d_o_pre, d_o_drop = ops.layernorm_bwd(dx, o_pre, ou.LayerNorm.weight, mean2, rstd2, bank.grad_image(ou.LayerNorm.weight),
-                                              bank.grad_image(ou.LayerNorm.bias), pk.p_h, _seed(_SITE_OUT, li), rt.seed_dev)
+                                              bank.grad_image(ou.LayerNorm.bias), pk.p_h, _seed(_SITE_OUT, li), rt.seed_dev, **keep)
         g = d_o_drop if d_o_drop is not None else d_o_pre
-        with rt.side(g, hact):
-            _linear_wgrad(rt, g, hact, ou.dense.weight, ou.dense.bias, M, d, ff)
-        dhp = torch.empty(M, ff, dtype=dt, device=dev)
+        dhp = gs.hp[li]
         ops.gemm(g, bank.compute(ou.dense.weight), M, ff, d, out=dhp, b_mode=KROW, gelu_grad_pre=hpre)   # dgrad + GELU'
-        with rt.side(dhp, a):
-            _linear_wgrad(rt, dhp, a, it.dense.weight, it.dense.bias, M, ff, d)
         da = torch.empty(M, d, dtype=dt, device=dev)
         ops.gemm(dhp, bank.compute(it.dense.weight), M, d, ff, out=da, b_mode=KROW, residual=d_o_pre)
+        keep = dict(dx2=gs.att[li]) if pk.p_h > 0 else dict(dx=gs.att[li])
         d_a_pre, d_a_drop = ops.layernorm_bwd(da, a_pre, so.LayerNorm.weight, mean1, rstd1, bank.grad_image(so.LayerNorm.weight),
-                                              bank.grad_image(so.LayerNorm.bias), pk.p_h, _seed(_SITE_SELF_OUT, li), rt.seed_dev)
+                                              bank.grad_image(so.LayerNorm.bias), pk.p_h, _seed(_SITE_SELF_OUT, li), rt.seed_dev, **keep)
         g = d_a_drop if d_a_drop is not None else d_a_pre
-        with rt.side(g, ctx):
-            _linear_wgrad(rt, g, ctx, so.dense.weight, so.dense.bias, M, d, d)
         dctx = torch.empty(M, d, dtype=dt, device=dev)
         ops.gemm(g, bank.compute(so.dense.weight), M, d, d, out=dctx, b_mode=KROW)
-        dqkv = ops.attention_bwd(qkv, pk.key_mask, ctx, dctx, lse, bsz, L, nh, pk.p_a, _seed(_SITE_ATTN, li), rt.seed_dev)
-        gw = bank.grad_span(att.query.weight, att.value.weight, (3 * d, d)) if bank.is_trainable(att.query.weight) else None
-        gb = bank.grad_span(att.query.bias, att.value.bias, (3 * d,)) if bank.is_trainable(att.query.bias) else None
-        if gw is not None:
-            with rt.side(dqkv, x):
-                _linear_wgrad(rt, dqkv, x, None, None, M, 3 * d, d, grad_w=gw, grad_b=gb)
+        dqkv = ops.attention_bwd(qkv, pk.key_mask, ctx, dctx, lse, bsz, L, nh, pk.p_a, _seed(_SITE_ATTN, li), rt.seed_dev,
+                                 out=gs.qkv[li])
         wqkv = bank.compute_span(att.query.weight, att.value.weight, (3 * d, d))
         dx = torch.empty(M, d, dtype=dt, device=dev)
         ops.gemm(dqkv, wqkv, M, d, 3 * d, out=dx, b_mode=KROW, residual=d_a_pre)
+    _encoder_wgrads(model, pk, gs, M)
     # ---- embeddings -----------------------------------------------------------------------------------
     rt.join()
     if pk.p_h > 0:
@@ -1038,7 +1092,7 @@ class ClipBert(nn.Module):
 
     # ---- MI355X runtime --------------------------------------------------------------------------------
     def prepare(self, dtype=torch.bfloat16, device=None, transformer_lr_mul_prefix="", cnn_lr_mul_prefix="grid_encoder",
-                overlap_wgrad=True):
+                overlap_wgrad=False):
         """Move parameters into the flat HBM buffers and build compute copies.  Call after loading
         weights / changing requires_grad (freeze_cnn_backbone) and before the first forward."""
         device = torch.device(device) if device is not None else next(self.parameters()).device

@@ -51,7 +51,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch
          b_mode=ROWK, lda=None, ldb=None, ldc=None, a_tab=None, b_tab=None, R=1, S=1, Cin=0, H=0, W=0,
          sH=0, sW=0, flip_taps=False, c_rowmap=None, accumulate=False, split_k=1, act=ACT_NONE,
          scale=None, shift=None, residual=None, ldr=None, relu_after=False, mask=None, ldm=None,
-         out2=None, ldc2=None, alpha=1.0, dropout_p=0.0, dropout_seed=0, seed_ptr=None, tile=0, gelu_grad_pre=None, a_rowsum=None):
+         out2=None, ldc2=None, alpha=1.0, dropout_p=0.0, dropout_seed=0, seed_ptr=None, tile=0, gelu_grad_pre=None, a_rowsum=None, batch=1, batch_strides=None):
     """C[M,N] (op)= epilogue(sum_k A(m,k) B(n,k)); see include/clipbert_hip.h cb_gemm_desc."""
     d = GemmDesc()
     d.dtype = dtype_code(a.dtype)
@@ -91,6 +91,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch
     if a_rowsum is not None:
         assert a_rowsum.dtype == torch.float32
         d.a_rowsum = _ptr(a_rowsum)
+    if batch > 1:
+        d.batch = batch
+        d.batch_stride_a, d.batch_stride_b, d.batch_stride_c, d.batch_stride_rowsum = batch_strides
     _chk(_lib.get().cb_gemm(C.byref(d), _stream(a)), "cb_gemm")
     return out
 
@@ -177,13 +180,13 @@ def layernorm_fwd(x, gamma, beta, eps, save_stats=False, out=None):
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dropout_p=0.0, dropout_seed=0, seed_ptr=None,
-                  dx=None, rows=None, seg=(0, 0, 0)):
+                  dx=None, rows=None, seg=(0, 0, 0), dx2=None):
     """returns (dx, dx_dropped|None); dgamma/dbeta (fp32) are accumulated in place.
     seg = (seg_len, seg_stride, seg_off) addresses a strided subset of rows (see the header)."""
     d = x.shape[-1]
     rows = x.numel() // d if rows is None else rows
     dx = torch.empty_like(x) if dx is None else dx
-    dx2 = torch.empty_like(x) if dropout_p > 0 else None
+    dx2 = (dx2 if dx2 is not None else torch.empty_like(x)) if dropout_p > 0 else None
     _chk(_lib.get().cb_layernorm_bwd(dtype_code(x.dtype), _ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd),
                                      _ptr(dx), _ptr(dgamma), _ptr(dbeta), rows, d, _ptr(dx2), dropout_p,
                                      dropout_seed, _ptr(seed_ptr), seg[0], seg[1], seg[2], _stream(x)),
@@ -222,16 +225,16 @@ def visual_embed_bwd(dpre, src_row, sel, dgrid, drow, dcol, dtype0, b, lv, lt, l
                                         _stream(dpre)), "cb_visual_embed_bwd")
 
 
-def attention_fwd(qkv, key_mask, b, l, h, save_lse=False, dropout_p=0.0, dropout_seed=0, seed_ptr=None):
-    ctx = torch.empty(b * l, h * 64, dtype=qkv.dtype, device=qkv.device)
+def attention_fwd(qkv, key_mask, b, l, h, save_lse=False, dropout_p=0.0, dropout_seed=0, seed_ptr=None, out=None):
+    ctx = out if out is not None else torch.empty(b * l, h * 64, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(b * h * l, dtype=torch.float32, device=qkv.device) if save_lse else None
     _chk(_lib.get().cb_attention_fwd(dtype_code(qkv.dtype), _ptr(qkv), _ptr(key_mask), _ptr(ctx), _ptr(lse), b, l, h,
                                      dropout_p, dropout_seed, _ptr(seed_ptr), _stream(qkv)), "cb_attention_fwd")
     return ctx, lse
 
 
-def attention_bwd(qkv, key_mask, ctx, dctx, lse, b, l, h, dropout_p=0.0, dropout_seed=0, seed_ptr=None):
-    dqkv = torch.empty_like(qkv)
+def attention_bwd(qkv, key_mask, ctx, dctx, lse, b, l, h, dropout_p=0.0, dropout_seed=0, seed_ptr=None, out=None):
+    dqkv = out if out is not None else torch.empty_like(qkv)
     ws = torch.empty(b * h * l, dtype=torch.float32, device=qkv.device)
     _chk(_lib.get().cb_attention_bwd(dtype_code(qkv.dtype), _ptr(qkv), _ptr(key_mask), _ptr(ctx), _ptr(dctx),
                                      _ptr(lse), _ptr(ws), _ptr(dqkv), b, l, h, dropout_p, dropout_seed, _ptr(seed_ptr),

@@ -87,6 +87,12 @@ typedef struct {
                                  the GELU backward of BertIntermediate fused into the dgrad of BertOutput.dense  */
     float* a_rowsum;          /* optional, weight-gradient form only (A and B CB_KROW): a_rowsum[m] += sum_k A(m,k),
                                  i.e. the bias gradient colsum(dY), computed on the matrix core next to dW (atomics) */
+    int32_t batch;            /* > 1: `batch` independent problems of this shape in ONE launch (grid z); problem b uses
+                                 A + b*batch_stride_a, B + b*batch_stride_b, C + b*batch_stride_c (elements of their
+                                 types) and a_rowsum + b*batch_stride_rowsum.  Plain operands only.  Used for the weight
+                                 gradients of all encoder layers at once (same shapes, layer-strided buffers).       */
+    int32_t reserved3;
+    int64_t batch_stride_a, batch_stride_b, batch_stride_c, batch_stride_rowsum;
 } cb_gemm_desc;
 
 /* GEMM / implicit-GEMM convolution, all forms.  Replaces torch.nn.Linear / F.conv2d (+ apex-amp

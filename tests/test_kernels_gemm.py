@@ -89,6 +89,27 @@ def test_fused_bias_grad_and_gelu_grad(hw, dt, tile):
     torch.testing.assert_close(dx.float(), pr.grad, **tol(dt))
 
 
+@pytest.mark.parametrize("dt", DT)
+def test_strided_batched_wgrad(hw, dt):
+    """weight gradients (+ bias row sums) of several layers in one launch: grid z = layer * split_k + split."""
+    nb, M, N, K = 3, 90, 72, 40
+    x, g = hw(rnd(nb, M, K, seed=1).to(dt)), hw(rnd(nb, M, N, seed=3).to(dt))
+    for split in (1, 2):
+        dw = torch.zeros(nb, N * K + 16, dtype=torch.float32, device=hw.dev)     # layer-strided gradient buffer with a gap
+        db = torch.zeros(nb, N + 8, dtype=torch.float32, device=hw.dev)
+        ops.gemm(g, x, N, K, M, out=dw, ldc=K, lda=N, ldb=K, a_mode=ops.KROW, b_mode=ops.KROW, accumulate=True, split_k=split,
+                 a_rowsum=db, batch=nb, batch_strides=(M * N, M * K, dw.stride(0), db.stride(0)))
+        for b in range(nb):
+            torch.testing.assert_close(dw[b, :N * K].view(N, K), g[b].float().t() @ x[b].float(), **tol(dt))
+            torch.testing.assert_close(db[b, :N], g[b].float().sum(0), **tol(dt))
+        assert dw[:, N * K:].abs().max() == 0 and db[:, N:].abs().max() == 0
+    # batched forward form
+    w = hw(rnd(nb, N, K, seed=5, scale=0.2).to(dt))
+    y = torch.empty(nb, M, N, dtype=dt, device=hw.dev)
+    ops.gemm(x, w, M, N, K, out=y, lda=K, ldb=K, ldc=N, batch=nb, batch_strides=(M * K, N * K, M * N, 0))
+    torch.testing.assert_close(y.float(), torch.einsum("bmk,bnk->bmn", x.float(), w.float()), **tol(dt))
+
+
 def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 

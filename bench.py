@@ -221,7 +221,7 @@ def measure_roofline(step_fn):
         e1.record()
         form = ("wgrad" if kw.get("a_mode", 0) == ops.KROW else ("dgrad" if kw.get("b_mode", 0) in (ops.KROW, ops.KROW_TAPS) else "fwd"))
         conv = kw.get("a_mode", 0) == ops.ROWK_GATHER or kw.get("b_mode", 0) == ops.KROW_GATHER
-        records.append((form, conv, 2.0 * M * N * K, e0, e1))
+        records.append((form, conv, 2.0 * M * N * K * kw.get("batch", 1), e0, e1))
         return r
 
     ops.gemm = timed

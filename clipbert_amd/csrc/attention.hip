@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) attention_fwd_kernel(const T* qkv, const 
             if (j < nk) {
                 float pj = __expf(s[j] - mn);
                 l += pj;
-                if (drop_p > 0.f) pj *= dropout_mult(seed, ((uint64_t)bh * L + qi) * L + j0 + j, drop_p);
+                if (drop_p > 0.f) pj *= dropout_mult1(seed, ((uint64_t)bh * L + qi) * ((L + 3) >> 2) + ((j0 + j) >> 2), (j0 + j) & 3, drop_p);
 #pragma unroll
                 for (int d = 0; d < PD; ++d) o[d] += pj * Vs[j][part * PD + d];
             }
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256) attention_bwd_q_kernel(const T* qkv, cons
             dp = quad_sum(dp);
             if (j < nk) {
                 float p = __expf(sc * 0.125f + Ms[j] - lse_i);
-                if (drop_p > 0.f) dp *= dropout_mult(seed, ((uint64_t)bh * L + qi) * L + j0 + j, drop_p);
+                if (drop_p > 0.f) dp *= dropout_mult1(seed, ((uint64_t)bh * L + qi) * ((L + 3) >> 2) + ((j0 + j) >> 2), (j0 + j) & 3, drop_p);
                 float ds = p * (dp - Di) * 0.125f;
 #pragma unroll
                 for (int d = 0; d < PD; ++d) dq[d] += ds * Ks[j][part * PD + d];
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256) attention_bwd_kv_kernel(const T* qkv, con
             if (i < nq) {
                 float p = __expf(sc * 0.125f + madd - Ls[i]);
                 float mult = 1.0f;
-                if (drop_p > 0.f) mult = dropout_mult(seed, ((uint64_t)bh * L + i0 + i) * L + kj, drop_p);
+                if (drop_p > 0.f) mult = dropout_mult1(seed, ((uint64_t)bh * L + i0 + i) * ((L + 3) >> 2) + (kj >> 2), kj & 3, drop_p);
                 float pd = p * mult;
                 float ds = p * (dp * mult - Ds[i]) * 0.125f;
 #pragma unroll

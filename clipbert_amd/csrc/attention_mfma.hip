@@ -12,7 +12,7 @@
 // ~45 / ~150 MFMAs per head.
 //
 // Semantics = attention.hip (BertSelfAttention, src/modeling/transformers.py:257-282 of the reference): scores/8 +
-// (1-mask)*-10000, softmax, inverted dropout on the probabilities (same hash stream, index ((b*H+h)*L+i)*L+j).
+// (1-mask)*-10000, softmax, inverted dropout on the probabilities (same mask stream: row (b*H+h)*L+i, column j; common.h).
 #include "common.h"
 
 namespace {
@@ -143,13 +143,11 @@ __global__ void __launch_bounds__(64 * NT) attn_fwd_mfma_kernel(const bf16* qkv,
         l = group_sum(l);
         const float inv = 1.0f / l;
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float p = s[jt][r] * inv;
-                if (drop_p > 0.f) p *= dropout_mult(seed, ((uint64_t)bh * L + i) * L + 16 * jt + 4 * g + r, drop_p);
-                s[jt][r] = p;
-            }
+        for (int jt = 0; jt < NT; ++jt) {
+            s[jt] = s[jt] * inv;
+            // keys 16jt + 4g + 0..3 are one 4-element group of the row's mask: one hash per accumulator register quad
+            if (drop_p > 0.f) s[jt] = s[jt] * dropout_mult4(seed, ((uint64_t)bh * L + i) * ((L + 3) >> 2) + 4 * jt + g, drop_p);
+        }
         if (lse && g == 0 && i < L) lse[(int64_t)bh * L + i] = m + __logf(l);
         f32x4 o[4];
 #pragma unroll
@@ -262,14 +260,21 @@ __global__ void __launch_bounds__(128 * NT) attn_bwd_mfma_kernel(const bf16* qkv
                 rlse = f32x4{clse, clse, clse, clse};
                 rD = f32x4{cD, cD, cD, cD};
             }
+            f32x4 mult = {1.0f, 1.0f, 1.0f, 1.0f};
+            if (drop_p > 0.f) {
+                const uint64_t ng = (uint64_t)((L + 3) >> 2);
+                if (yph) {                                   // 4 queries x own key: 4 rows of the mask, one element each
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mult[r] = dropout_mult1(seed, ((uint64_t)bh * L + row0 + r) * ng + (col >> 2), col & 3, drop_p);
+                } else {                                     // own query x keys row0..row0+3: one group of the mask row
+                    mult = dropout_mult4(seed, ((uint64_t)bh * L + col) * ng + (row0 >> 2), drop_p);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int qry = yph ? row0 + r : col, key = yph ? col : row0 + r;
                 const float p = __expf(s[r] * 0.125f + rmadd[r] - rlse[r]);
-                float mult = 1.0f;
-                if (drop_p > 0.f) mult = dropout_mult(seed, ((uint64_t)bh * L + qry) * L + key, drop_p);
-                pdv[r] = p * mult;
-                s[r] = p * (dp[r] * mult - rD[r]) * 0.125f;
+                pdv[r] = p * mult[r];
+                s[r] = p * (dp[r] * mult[r] - rD[r]) * 0.125f;
             }
         }
         pd[t] = pdv;

@@ -70,18 +70,35 @@ __device__ __forceinline__ float apply_act(int act, float v) {
     }
 }
 
-// ---- stateless dropout mask: keep(seed, index) -------------------------------------------------
-__device__ __forceinline__ uint32_t cb_hash(uint64_t seed, uint64_t idx) {
+// ---- stateless dropout mask ------------------------------------------------------------------------
+// One 64-bit hash (splitmix64 finaliser) decides FOUR consecutive elements, 16 bits each (the 64-bit multiplies are the
+// expensive part on the VALU; p is resolved to 1/65536).  Elements are addressed as (group, e): element 4*group + e of
+// the site's stream; a 2-D site (rows x cols) uses group = row * ceil(cols/4) + col/4, e = col%4, so every producer
+// and consumer of one mask (GEMM epilogue <-> LayerNorm backward, attention forward <-> backward, cb_dropout forward
+// <-> backward) agrees whatever its own vector width is.
+__device__ __forceinline__ uint64_t cb_hash64(uint64_t seed, uint64_t idx) {
     uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (uint32_t)(z >> 32);
+    return z ^ (z >> 31);
 }
-// returns the multiplier: 0 (dropped) or 1/(1-p) (kept)
-__device__ __forceinline__ float dropout_mult(uint64_t seed, uint64_t idx, float p) {
-    float u = (float)(cb_hash(seed, idx) >> 8) * (1.0f / 16777216.0f);
-    return u < p ? 0.f : 1.0f / (1.0f - p);
+__device__ __forceinline__ uint32_t dropout_threshold(float p) { return (uint32_t)(p * 65536.0f); }
+// multipliers of the 4 elements of `group`: 0 (dropped) or 1/(1-p) (kept)
+__device__ __forceinline__ f32x4 dropout_mult4(uint64_t seed, uint64_t group, float p) {
+    const uint64_t z = cb_hash64(seed, group);
+    const uint32_t thr = dropout_threshold(p), lo = (uint32_t)z, hi = (uint32_t)(z >> 32);
+    const float keep = 1.0f / (1.0f - p);
+    f32x4 m;
+    m[0] = (lo & 0xffffu) < thr ? 0.f : keep;
+    m[1] = (lo >> 16) < thr ? 0.f : keep;
+    m[2] = (hi & 0xffffu) < thr ? 0.f : keep;
+    m[3] = (hi >> 16) < thr ? 0.f : keep;
+    return m;
+}
+// multiplier of element e (0..3) of `group`
+__device__ __forceinline__ float dropout_mult1(uint64_t seed, uint64_t group, int e, float p) {
+    const uint64_t z = cb_hash64(seed, group);
+    return (uint32_t)((z >> (16 * e)) & 0xffffu) < dropout_threshold(p) ? 0.f : 1.0f / (1.0f - p);
 }
 
 // ---- wave reductions (64 lanes) -----------------------------------------------------------------

@@ -658,8 +658,7 @@ __device__ __forceinline__ void epilogue_vec(const GP& p, f32x4 v, int m, int64_
         for (int r = 0; r < 4; ++r) v[r] = apply_act(p.act, v[r]);
     }
     if (p.dropout_p > 0.f) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= dropout_mult(p.seed, (uint64_t)m * p.N + nb + r, p.dropout_p);
+        v = v * dropout_mult4(p.seed, (uint64_t)m * ((p.N + 3) >> 2) + (nb >> 2), p.dropout_p);
     }
     if (p.residual) v = v + load4(reinterpret_cast<const T*>(p.residual) + orow * p.ldr + nb);
     if (p.relu_after) {
@@ -700,7 +699,7 @@ __device__ __forceinline__ void epilogue_elem(const GP& p, float x, int m, int64
     if (p.shift) x += p.shift[n];
     if (p.C2) reinterpret_cast<T*>(p.C2)[orow * p.ldc2 + n] = from_f32<T>(x);
     x = apply_act(p.act, x);
-    if (p.dropout_p > 0.f) x *= dropout_mult(p.seed, (uint64_t)m * p.N + n, p.dropout_p);
+    if (p.dropout_p > 0.f) x *= dropout_mult1(p.seed, (uint64_t)m * ((p.N + 3) >> 2) + (n >> 2), n & 3, p.dropout_p);
     if (p.residual) x += to_f32(reinterpret_cast<const T*>(p.residual)[orow * p.ldr + n]);
     if (p.relu_after) x = x > 0.f ? x : 0.f;
     if (p.mask) x = to_f32(reinterpret_cast<const T*>(p.mask)[orow * p.ldm + n]) > 0.f ? x : 0.f;
@@ -758,8 +757,10 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
         for (int r = 0; r < 8; ++r) v[r] = apply_act(p.act, v[r]);
     }
     if (p.dropout_p > 0.f) {
+        const uint64_t grp = (uint64_t)m * ((p.N + 3) >> 2) + (n >> 2);
+        const f32x4 d0 = dropout_mult4(p.seed, grp, p.dropout_p), d1 = dropout_mult4(p.seed, grp + 1, p.dropout_p);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] *= dropout_mult(p.seed, (uint64_t)m * p.N + n + r, p.dropout_p);
+        for (int r = 0; r < 4; ++r) { v[r] *= d0[r]; v[4 + r] *= d1[r]; }
     }
     if (p.residual) {
         float t[8];

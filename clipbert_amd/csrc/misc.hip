@@ -116,12 +116,11 @@ __global__ void __launch_bounds__(256) dropout_kernel(const T* x, T* y, int64_t 
     int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
     if (i + 3 < n) {
-        f32x4 v = load4(x + i);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= dropout_mult(seed, (uint64_t)(i + e), p);
+        f32x4 v = load4(x + i) * dropout_mult4(seed, (uint64_t)(i >> 2), p);      // i % 4 == 0
         store4(y + i, v);
     } else {
-        for (; i < n; ++i) y[i] = from_f32<T>(to_f32(x[i]) * dropout_mult(seed, (uint64_t)i, p));
+        const uint64_t grp = (uint64_t)(i >> 2);
+        for (int e = 0; i < n; ++i, ++e) y[i] = from_f32<T>(to_f32(x[i]) * dropout_mult1(seed, grp, e, p));
     }
 }
 

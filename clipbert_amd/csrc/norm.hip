@@ -119,8 +119,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* dy, const T
                 for (int i = 0; i < 4; ++i) o[i] = rs * (g[c][i] - c1 - xv[c][i] * c2);
                 store4(dx + row * D + e, o);
                 if (dx2) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] *= dropout_mult(seed, (uint64_t)row * D + e + i, drop_p);
+                    o = o * dropout_mult4(seed, ((uint64_t)row * D + e) >> 2, drop_p);            // D % 4 == 0, e % 4 == 0
                     store4(dx2 + row * D + e, o);
                 }
             }

@@ -251,6 +251,31 @@ def test_dropout_kernel_and_seed_pointer(hw):
     assert not torch.equal(a, c)
 
 
+@pytest.mark.parametrize("N", [72, 68, 200])
+def test_dropout_masks_agree_across_kernels(hw, N):
+    """One mask stream per site whatever kernel draws it: the GEMM epilogue (8-wide, 4-wide and element paths), the
+    LayerNorm backward (which re-applies the forward's mask to the gradient) and cb_dropout must drop the same elements."""
+    M, K, p, seed = 150, 32, 0.3, 9
+    sp = torch.tensor([5], dtype=torch.int64, device=DEV[0])
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    plain = torch.empty(M, N, device=DEV[0])
+    ops.gemm(x, w, M, N, K, out=plain)
+    ref = ops.dropout(plain.view(-1), p, seed=seed, seed_ptr=sp).view(M, N)
+    for tile in (1, 2):
+        got = torch.empty(M, N, device=DEV[0])
+        ops.gemm(x, w, M, N, K, out=got, dropout_p=p, dropout_seed=seed, seed_ptr=sp, tile=tile)
+        torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
+    if N % 8 == 0:
+        D = N
+        xx, dy = rnd(M, D, seed=3), rnd(M, D, seed=4)
+        g = 1 + rnd(D, seed=5, scale=0.1)
+        mean, var = xx.mean(-1), xx.var(-1, unbiased=False)
+        rstd = (var + 1e-12).rsqrt()
+        dg, db = zeros(D), zeros(D)
+        dx, dx2 = ops.layernorm_bwd(dy, xx, g, mean, rstd, dg, db, dropout_p=p, dropout_seed=seed, seed_ptr=sp)
+        torch.testing.assert_close(dx2, ops.dropout(dx.view(-1), p, seed=seed, seed_ptr=sp).view(M, D), rtol=1e-6, atol=1e-6)
+
+
 def test_layernorm_bwd_row_segments(hw):
     B, L, Lt, D = 3, 7, 4, 64
     x, dy = rnd(B * L, D, seed=1), rnd(B * L, D, seed=2)

@@ -37,7 +37,8 @@ orig = ops.gemm
 def logged(a, b, Mm, N, K, **kw):
     form = "wgrad" if kw.get("a_mode", 0) == ops.KROW else ("dgrad" if kw.get("b_mode", 0) in (ops.KROW, ops.KROW_TAPS) else "fwd")
     conv = kw.get("a_mode", 0) == ops.ROWK_GATHER or kw.get("b_mode", 0) == ops.KROW_GATHER
-    calls.append(dict(M=Mm, N=N, K=K, form=form, conv=bool(conv), split=kw.get("split_k", 1), R=kw.get("R", 1)))
+    calls.append(dict(M=Mm, N=N, K=K, form=form, conv=bool(conv), split=kw.get("split_k", 1), R=kw.get("R", 1), batch=kw.get("batch", 1),
+                      esz=a.element_size(), c_esz=kw["out"].element_size()))
     return orig(a, b, Mm, N, K, **kw)
 ops.gemm = logged
 step()

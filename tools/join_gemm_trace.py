@@ -7,7 +7,7 @@ agg = collections.defaultdict(lambda: [0.0, 0.0, 0])
 for c, r in zip(calls, g):
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     key = (c["form"], c["conv"], c["M"], c["N"], c["K"], c["split"])
-    a = agg[key]; a[0] += d; a[1] += 2.0 * c["M"] * c["N"] * c["K"]; a[2] += 1
+    a = agg[key]; a[0] += d; a[1] += 2.0 * c["M"] * c["N"] * c["K"] * c.get("batch", 1); a[2] += 1
 tot = sum(a[0] for a in agg.values())
 print(f"total gemm time {tot/1e3:.3f} ms over {len(calls)} launches")
 print(f"{'form':6s} {'conv':5s} {'M':>7s} {'N':>6s} {'K':>6s} {'spl':>3s} {'n':>3s} {'us/launch':>9s} {'TF/s':>7s} {'ms tot':>7s}")

@@ -208,34 +208,57 @@ def ops_image_norm_host(frames_u8):
 
 
 def measure_roofline(step_fn):
-    """Per-launch HIP-event timing of every cb_gemm launch of ONE eager step; the dominant kernel variant
-    (by total time) is reported against the dense bf16 MFMA peak with its ALGORITHMIC flops 2*M*N*K."""
+    """Durations of the cb_gemm kernels of the step, by kernel family, against the dense bf16 MFMA peak with their
+    ALGORITHMIC flops (2*M*N*K per problem).
+
+    HIP events cost several microseconds each on this stack, so bracketing every ~20 us launch individually would
+    measure the markers.  Instead one eager step is recorded (every cb_gemm call with its live operands), then each
+    family's calls are replayed back to back -- captured in a hipGraph, `reps` times -- between ONE pair of HIP events
+    on the launch stream: avg launch duration = elapsed / (reps * launches), which is what rocprofv3's kernel trace of
+    the same command reports (profiles/)."""
     from clipbert_amd import ops
-    records = []
+    calls = []
     orig = ops.gemm
 
-    def timed(a, b, M, N, K, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = orig(a, b, M, N, K, **kw)
-        e1.record()
+    def logged(a, b, M, N, K, **kw):
         form = ("wgrad" if kw.get("a_mode", 0) == ops.KROW else ("dgrad" if kw.get("b_mode", 0) in (ops.KROW, ops.KROW_TAPS) else "fwd"))
         conv = kw.get("a_mode", 0) == ops.ROWK_GATHER or kw.get("b_mode", 0) == ops.KROW_GATHER
-        records.append((form, conv, 2.0 * M * N * K * kw.get("batch", 1), e0, e1))
-        return r
+        key = f"gemm_kernel<bf16> {form}{' (implicit-GEMM conv)' if conv else ''}"
+        calls.append((key, 2.0 * M * N * K * kw.get("batch", 1), (a, b, M, N, K), kw))
+        return orig(a, b, M, N, K, **kw)
 
-    ops.gemm = timed
+    ops.gemm = logged
     try:
         step_fn()
         torch.cuda.synchronize()
     finally:
         ops.gemm = orig
+    fams = {}
+    for key, fl, pos, kw in calls:
+        fams.setdefault(key, []).append((fl, pos, kw))
+    reps, outer = 3, 5
     agg = {}
-    for form, conv, fl, e0, e1 in records:
-        key = f"gemm_kernel<bf16> {form}{' (implicit-GEMM conv)' if conv else ''}"
-        t = e0.elapsed_time(e1) * 1e-3
-        a = agg.setdefault(key, [0.0, 0.0, 0])
-        a[0] += fl; a[1] += t; a[2] += 1
+    for key, lst in fams.items():
+        def replay():
+            for _ in range(reps):
+                for fl, pos, kw in lst:
+                    orig(*pos, **kw)
+        replay()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            replay()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(outer):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / (reps * outer)             # seconds for one pass over the family's launches
+        agg[key] = [sum(x[0] for x in lst), t, len(lst)]
+        del g
     tot_fl = sum(a[0] for a in agg.values())
     tot_t = sum(a[1] for a in agg.values())
     dom = max(agg.items(), key=lambda kv: kv[1][1])

@@ -1342,18 +1342,27 @@ int launch_gemm(const GP& p, bool fast, hipStream_t st) {
     if (a_krow && !b_krow) return cb_fail("cb_gemm: unsupported operand mode combination (A KROW with B ROWK)");
     if (fast) {
         const int taps = p.R * p.S;
-        if (p.a_mode == CB_ROWK && p.b_mode == CB_ROWK)
-            return launch_k<T, BM, BN, PF, RowkFast<T, BM, false>, RowkFast<T, BN, false>>(p, st);
-        if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_ROWK)
-            return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, RowkFast<T, BN, false>>(p, st);
         if constexpr (sizeof(T) == 2) {
-            static const bool use_dma = getenv("CB_GEMM_NO_DMA") == nullptr;
+            // The LDS-DMA ring kernel is OPT-IN (CB_GEMM_DMA=1).  Measured on MI355X against the register-staged kernel
+            // below for every GEMM of the step: equal where K is long (both run into the L2->LDS bandwidth of the 64x64
+            // tile, profiles/r01_gemm_l2_analysis.md; an 8-stage ring, CB_GEMM_DMA_DEEP=1, changes nothing either) and
+            // 10-20 % slower for short-K convolutions (its 64 KiB ring halves the blocks per CU).
+            static const bool use_dma = getenv("CB_GEMM_DMA") != nullptr;
             constexpr int NST = (BM >= 128 && BN >= 128) ? 3 : 4;
             const bool ct_ok = p.Ct % Tr<bf16>::BK == 0;
             if (use_dma) {
                 dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.split_k * (p.batch > 1 ? p.batch : 1));
+                static const int deep_env = getenv("CB_GEMM_DMA_DEEP") ? atoi(getenv("CB_GEMM_DMA_DEEP")) : 0;
+                const int64_t nblk = (int64_t)grid.x * grid.y * grid.z;
+                const bool deep = (BM == 64 && BN == 64) && deep_env != 0 && nblk <= 320 && p.ktiles / p.split_k >= 8;
 #define CB_LAUNCH_DMA(LA_, LB_)                                                                               \
     do {                                                                                                      \
+        if constexpr (BM == 64 && BN == 64) {                                                                 \
+            if (deep) {                                                                                       \
+                hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, LA_, LB_, 8>), grid, dim3(NTHREADS), 0, st, p);   \
+                return cb_launch_status("cb_gemm");                                                           \
+            }                                                                                                 \
+        }                                                                                                     \
         hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, LA_, LB_, NST>), grid, dim3(NTHREADS), 0, st, p);         \
         return cb_launch_status("cb_gemm");                                                                   \
     } while (0)
@@ -1385,6 +1394,10 @@ int launch_gemm(const GP& p, bool fast, hipStream_t st) {
             if (p.a_mode == CB_KROW && p.b_mode == CB_KROW_GATHER)
                 return launch_k<T, BM, BN, PF, KrowTr<BM, KM_PLAIN>, KrowTr<BN, KM_GATHER>>(p, st);
         }
+        if (p.a_mode == CB_ROWK && p.b_mode == CB_ROWK)
+            return launch_k<T, BM, BN, PF, RowkFast<T, BM, false>, RowkFast<T, BN, false>>(p, st);
+        if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_ROWK)
+            return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, RowkFast<T, BN, false>>(p, st);
         // fp32 parity mode (and odd channel counts): register-transposing loaders.  One KROW operand next to a ROWK
         // one is spread over all 256 threads; two KROW operands take half the threads each (B shifted by 128)
         constexpr int KB1B = BN >= 128 ? 4 : 2;

@@ -1,0 +1,1391 @@
+// Templates of the cb_gemm kernels (included by gemm.hip and by the per-tile instantiation units gemm_inst_*.hip, so that
+// the tile sizes compile in parallel).  See gemm.hip for the description of the kernel.
+#pragma once
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace cbgemm {
+
+
+constexpr int NTHREADS = 256;
+
+// EPS elements per 16-byte segment; BK = K step; SEGS segments per LDS row; ROWB bytes per LDS row;
+// RB rows per transposing block
+template <typename T> struct Tr;
+template <> struct Tr<bf16> { static constexpr int EPS = 8, BK = 64, SEGS = 8, ROWB = 128, RB = 8; };
+template <> struct Tr<float> { static constexpr int EPS = 4, BK = 32, SEGS = 8, ROWB = 144, RB = 4; };
+
+template <typename T> __device__ __forceinline__ int lds_off(int row, int seg);
+template <> __device__ __forceinline__ int lds_off<bf16>(int row, int seg) { return row * 128 + ((seg ^ (row & 7)) << 4); }
+template <> __device__ __forceinline__ int lds_off<float>(int row, int seg) { return row * 144 + (seg << 4); }
+
+struct GP {
+    const void* A; const void* B; void* C; void* C2; const void* residual; const void* mask;
+    const void* dact_pre; float* a_rowsum; int64_t ldd;
+    int batch; int64_t bs_a, bs_b, bs_c, bs_r;      // strided-batched problems on gridDim.z (strides in BYTES; bs_r in floats)
+    const float* scale; const float* shift;
+    const cb_pixel* a_tab; const cb_pixel* b_tab; const int32_t* c_rowmap;
+    int64_t lda, ldb, ldc, ldc2, ldr, ldm, sH, sW;
+    int M, N, K;
+    int a_mode, b_mode;
+    int R, S, Ct, H, W, flip;
+    int c_f32, accumulate, split_k, act, relu_after;
+    float alpha, dropout_p;
+    uint64_t seed;
+    const uint64_t* seed_ptr;
+    int c_vec, c_vec8;
+    int xcd_remap;              // 1: remap workgroup ids so that each XCD (own L2) owns a contiguous chunk of tiles
+    uint32_t a_bytes, b_bytes;
+    int ktiles;
+};
+
+template <typename T> __device__ __forceinline__ u32x4 load_guarded(const T* src, int nvalid) {
+    constexpr int EPS = Tr<T>::EPS;
+    union { u32x4 v; T e[EPS]; } u;
+#pragma unroll
+    for (int i = 0; i < EPS; ++i) u.e[i] = (i < nvalid) ? src[i] : (T)0.f;
+    return u.v;
+}
+
+// Buffer-descriptor loads: the hardware range check returns zeros for any byte offset >= num_records, so
+// predication (rows past M, taps in the padding, K tails) is ONE select of the offset to OOB -- no branches,
+// no 64-bit address arithmetic in the K loop.  Operands must be < 2 GiB (else the generic loaders run).
+constexpr uint32_t OOB = 0x80000000u;
+typedef decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0)) rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 bload16(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
+
+// one operand of the GEMM as the loaders see it
+struct Opnd {
+    const void* base; const cb_pixel* tab; int64_t ld; int mode; uint32_t bytes;
+};
+
+// ---------------------------------------------------------------------------------------------
+// ROWK loaders: tile rows are GEMM rows, 16-byte segments run along k.  Per-row state is fixed for the
+// whole K loop; `Stage` holds one K-tile of loaded registers; load() must be called for consecutive
+// K-tiles (it advances the thread's k -> (tap, channel) position incrementally: no divisions).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int ROWS, bool FAST> struct RowkLoader {
+    using X = Tr<T>;
+    static constexpr bool TR = false;
+    static constexpr int NS = ROWS * X::SEGS / NTHREADS;
+    static constexpr int ESZ = (int)sizeof(T);
+    static_assert(ROWS * X::SEGS % NTHREADS == 0, "tile/threads mismatch");
+    struct Stage { u32x4 r[NS]; };
+    int64_t off[NS];            // element offset of (row, k=0)        (generic path)
+    uint32_t boff[NS];          // byte offset of (row, k=0), or OOB   (fast path)
+    int ih[NS], iw[NS];
+    bool ok[NS];
+    int c, rr, ss;              // this thread's segment: channel within the tap, tap = (rr, ss)
+    bool gather;
+    rsrc_t rs;
+    const T* base;
+
+    __device__ __forceinline__ void init(const GP& p, const Opnd& o, int row0, int bound, int kt0, int tid) {
+        gather = o.mode == CB_ROWK_GATHER;
+        base = reinterpret_cast<const T*>(o.base);
+        if constexpr (FAST) rs = make_rsrc(o.base, o.bytes);
+        int k = kt0 * X::BK + (tid % X::SEGS) * X::EPS;
+        c = k; rr = 0; ss = 0;
+        if (gather) {
+            int tap = k / p.Ct;
+            c = k - tap * p.Ct;
+            rr = tap / p.S; ss = tap - rr * p.S;
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            int idx = tid + i * NTHREADS;
+            int row = row0 + idx / X::SEGS;
+            ok[i] = row < bound;
+            ih[i] = 0; iw[i] = 0;
+            int64_t e = (int64_t)row * o.ld;
+            if (gather) {
+                cb_pixel px = {0, 0, 0};
+                if (ok[i]) px = o.tab[row];
+                e = px.off; ih[i] = px.ih0; iw[i] = px.iw0;
+            }
+            off[i] = e;
+            boff[i] = ok[i] ? (uint32_t)e * (uint32_t)ESZ : OOB;
+        }
+    }
+    template <bool CHECK> __device__ __forceinline__ void load(Stage& st, const GP& p) {
+        const bool kv = gather ? (rr < p.R) : (c < p.K);
+        const int klim = gather ? p.Ct : p.K;
+        const int64_t tapoff = gather ? (rr * p.sH + ss * p.sW) : 0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            bool v = kv && ok[i];
+            if (gather) v = v && (unsigned)(ih[i] + rr) < (unsigned)p.H && (unsigned)(iw[i] + ss) < (unsigned)p.W;
+            if constexpr (FAST) {
+                uint32_t o32 = boff[i] + (uint32_t)(tapoff + c) * (uint32_t)ESZ;
+                st.r[i] = bload16(rs, v ? o32 : OOB);
+            } else {
+                u32x4 z = {0u, 0u, 0u, 0u};
+                st.r[i] = v ? load_guarded<T>(base + off[i] + tapoff + c, klim - c) : z;
+            }
+        }
+        c += X::BK;
+        if (gather) {
+            while (c >= p.Ct) { c -= p.Ct; if (++ss == p.S) { ss = 0; ++rr; } }
+        }
+    }
+    __device__ __forceinline__ void store(const Stage& st, unsigned char* tile, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            int idx = tid + i * NTHREADS;
+            *reinterpret_cast<u32x4*>(tile + lds_off<T>(idx / X::SEGS, idx % X::SEGS)) = st.r[i];
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// KROW loaders: memory has the reduction index outermost; each thread moves a (4 k) x (RB rows) block
+// and transposes it in registers on its way into the [row][k] LDS tile.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int ROWS, bool FAST> struct KrowLoader {
+    using X = Tr<T>;
+    static constexpr bool TR = false;
+    static constexpr int RBLK = ROWS / X::RB;              // row blocks per tile
+    static constexpr int CNT = RBLK * (X::BK / 4);         // thread-blocks per tile
+    static constexpr int NI = (CNT + NTHREADS - 1) / NTHREADS;
+    static constexpr int ESZ = (int)sizeof(T);
+    struct Stage { u32x4 r[NI][4]; };
+    int mode, bound;
+    int64_t ld;
+    const cb_pixel* tab;
+    const T* base;
+    rsrc_t rs;
+    int kb0[NI];        // k of the block's first row (advances by BK per tile)
+    int co[NI], tap[NI];// CB_KROW_TAPS: k -> (tap, co)
+    int row[NI];        // global row of the block's first element
+    int rr[NI], ss[NI]; // CB_KROW_GATHER: tap of this row block
+    int64_t rowoff[NI]; // element offset contributed by the row (and its tap for GATHER)
+    bool act[NI];
+
+    __device__ __forceinline__ void init(const GP& p, const Opnd& o, int row0, int bnd, int kt0, int tid) {
+        mode = o.mode; bound = bnd; ld = o.ld; tab = o.tab;
+        base = reinterpret_cast<const T*>(o.base);
+        if constexpr (FAST) rs = make_rsrc(o.base, o.bytes);
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            int b = tid + it * NTHREADS;
+            act[it] = b < CNT;
+            int rb = b % RBLK, kb = b / RBLK;
+            row[it] = row0 + rb * X::RB;
+            kb0[it] = kt0 * X::BK + kb * 4;        // the 4 k of a block never straddle a tap (Ct % 4 == 0)
+            rowoff[it] = row[it];
+            co[it] = kb0[it]; tap[it] = 0; rr[it] = 0; ss[it] = 0;
+            if (mode == CB_KROW_TAPS) {            // weights [Ct][taps][bound] read for a transposed conv
+                tap[it] = kb0[it] / p.Ct;
+                co[it] = kb0[it] - tap[it] * p.Ct;
+            } else if (mode == CB_KROW_GATHER) {   // row = (tap, channel) of the gathered image
+                int tp = row[it] / p.Ct;
+                int ch = row[it] - tp * p.Ct;
+                rr[it] = tp / p.S; ss[it] = tp - rr[it] * p.S;
+                rowoff[it] = rr[it] * p.sH + ss[it] * p.sW + ch;
+            }
+        }
+    }
+    template <bool CHECK> __device__ __forceinline__ void load(Stage& st, const GP& p) {
+        u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            if (!act[it]) { st.r[it][0] = z; st.r[it][1] = z; st.r[it][2] = z; st.r[it][3] = z; continue; }
+            const int nvalid = bound - row[it];
+            int64_t ro = rowoff[it];
+            if (mode == CB_KROW_TAPS) {
+                int tapw = p.flip ? (p.R * p.S - 1 - tap[it]) : tap[it];
+                ro = (int64_t)tapw * bound + row[it];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kb0[it] + j;
+                bool v = k < p.K && nvalid > 0;
+                int64_t e;
+                if (mode == CB_KROW_GATHER) {
+                    cb_pixel px = {0, 0, 0};
+                    if (v) px = tab[k];
+                    v = v && (unsigned)(px.ih0 + rr[it]) < (unsigned)p.H && (unsigned)(px.iw0 + ss[it]) < (unsigned)p.W;
+                    e = px.off + ro;
+                } else if (mode == CB_KROW_TAPS) {
+                    e = (int64_t)(co[it] + j) * ld + ro;
+                } else {
+                    e = (int64_t)k * ld + ro;
+                }
+                if constexpr (FAST) {
+                    // rows past `bound` inside a block read neighbouring (in-buffer) data: those tile rows only feed
+                    // outputs the epilogue discards; past the buffer end the descriptor returns zeros
+                    st.r[it][j] = bload16(rs, v ? (uint32_t)e * (uint32_t)ESZ : OOB);
+                } else {
+                    st.r[it][j] = v ? load_guarded<T>(base + e, nvalid) : z;
+                }
+            }
+            kb0[it] += X::BK;
+            if (mode == CB_KROW_TAPS) {
+                co[it] += X::BK;
+                while (co[it] >= p.Ct) { co[it] -= p.Ct; ++tap[it]; }
+            }
+        }
+    }
+    __device__ __forceinline__ void store(const Stage& st, unsigned char* tile, int tid) const {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            int b = tid + it * NTHREADS;
+            if (b >= CNT) continue;
+            int rb = b % RBLK, kb = b / RBLK;
+            int r0 = rb * X::RB;
+            if constexpr (sizeof(T) == 2) {
+                // st.r[it][j][d] holds rows (2d, 2d+1) at k = kb*4 + j
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    uint32_t a0 = st.r[it][0][d], a1 = st.r[it][1][d], a2 = st.r[it][2][d], a3 = st.r[it][3][d];
+                    u32x2 even = {(a0 & 0xffffu) | (a1 << 16), (a2 & 0xffffu) | (a3 << 16)};
+                    u32x2 odd = {(a0 >> 16) | (a1 & 0xffff0000u), (a2 >> 16) | (a3 & 0xffff0000u)};
+                    *reinterpret_cast<u32x2*>(tile + lds_off<T>(r0 + 2 * d, kb >> 1) + (kb & 1) * 8) = even;
+                    *reinterpret_cast<u32x2*>(tile + lds_off<T>(r0 + 2 * d + 1, kb >> 1) + (kb & 1) * 8) = odd;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u32x4 o = {st.r[it][0][e], st.r[it][1][e], st.r[it][2][e], st.r[it][3][e]};
+                    *reinterpret_cast<u32x4*>(tile + lds_off<T>(r0 + e, kb)) = o;
+                }
+            }
+        }
+    }
+};
+
+// =============================================================================================
+// FAST loaders (compile-time addressing mode, range-checked buffer loads): the steady-state K loop costs
+// one v_add + one buffer_load per 16 bytes (plus two compares per load for convolution gathers).
+// =============================================================================================
+enum { KM_PLAIN = 0, KM_TAPS = 1, KM_GATHER = 2 };
+
+template <typename T, int ROWS, bool GATHER> struct RowkFast {
+    using X = Tr<T>;
+    static constexpr bool TR = false;
+    static constexpr int NS = ROWS * X::SEGS / NTHREADS;
+    static constexpr uint32_t ESZ = (uint32_t)sizeof(T);
+    struct Stage { u32x4 r[NS]; };
+    rsrc_t rs;
+    uint32_t voff[NS];          // byte offset of this thread's segment (k position included unless GATHER), or OOB
+    int ih[NS], iw[NS];         // GATHER: top-left input pixel of the row's receptive field
+    int c, rr, ss;              // GATHER: channel within the tap, tap = (rr, ss)
+    int krem;                   // !GATHER: K - (k of this thread's segment)
+
+    __device__ __forceinline__ void init(const GP& p, const Opnd& o, int row0, int bound, int kt0, int tid) {
+        rs = make_rsrc(o.base, o.bytes);
+        const int k = kt0 * X::BK + (tid % X::SEGS) * X::EPS;
+        c = k; rr = 0; ss = 0; krem = p.K - k;
+        if constexpr (GATHER) {
+            int tap = k / p.Ct;
+            c = k - tap * p.Ct;
+            rr = tap / p.S; ss = tap - rr * p.S;
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int row = row0 + (tid + i * NTHREADS) / X::SEGS;
+            const bool ok = row < bound;
+            ih[i] = 0; iw[i] = 0;
+            if constexpr (GATHER) {
+                cb_pixel px = {0, 0, 0};
+                if (ok) px = o.tab[row];
+                ih[i] = px.ih0; iw[i] = px.iw0;
+                voff[i] = ok ? (uint32_t)px.off * ESZ : OOB;
+            } else {
+                voff[i] = ok ? ((uint32_t)row * (uint32_t)o.ld + (uint32_t)k) * ESZ : OOB;
+            }
+        }
+    }
+    template <bool CHECK> __device__ __forceinline__ void load(Stage& st, const GP& p) {
+        if constexpr (GATHER) {
+            const bool kv = rr < p.R;
+            const uint32_t koff = (uint32_t)(rr * (int)p.sH + ss * (int)p.sW + c) * ESZ;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const bool v = kv && (unsigned)(ih[i] + rr) < (unsigned)p.H && (unsigned)(iw[i] + ss) < (unsigned)p.W;
+                st.r[i] = bload16(rs, v ? voff[i] + koff : OOB);
+            }
+            if (p.Ct >= X::BK) {
+                c += X::BK;
+                if (c >= p.Ct) { c -= p.Ct; if (++ss == p.S) { ss = 0; ++rr; } }
+            } else {                                   // several taps per K step (stem: 32 channels per tap)
+                ss += X::BK / p.Ct;
+                while (ss >= p.S) { ss -= p.S; ++rr; }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                uint32_t o32 = voff[i];
+                if (CHECK && krem <= 0) o32 = OOB;
+                st.r[i] = bload16(rs, o32);
+                voff[i] += X::BK * ESZ;
+            }
+            krem -= X::BK;
+        }
+    }
+    __device__ __forceinline__ void store(const Stage& st, unsigned char* tile, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            int idx = tid + i * NTHREADS;
+            *reinterpret_cast<u32x4*>(tile + lds_off<T>(idx / X::SEGS, idx % X::SEGS)) = st.r[i];
+        }
+    }
+};
+
+// KB = k-lines per thread block (8: 8x8 transpose -> ds_write_b128; 4: ds_write_b64; 2: ds_write_b32), chosen so
+// that the tile's blocks cover all 256 threads; SHIFT rotates the thread -> block map so that two half-occupancy
+// operands (A and B both KROW) land on different waves.
+// Lane mapping: the k-block index varies fastest, so the lanes of one LDS write group fill ONE tile row
+// (all 32 banks, conflict-free) while lanes NKB apart read adjacent 16-byte chunks of the same k-line.
+template <typename T, int ROWS, int KMODE, int KB_ = 4, int SHIFT = 0> struct KrowFast {
+    using X = Tr<T>;
+    static constexpr bool TR = false;
+    static constexpr int KB = sizeof(T) == 2 ? KB_ : 4;
+    static constexpr int NKB = X::BK / KB;
+    static constexpr int RBLK = ROWS / X::RB;
+    static constexpr int CNT = RBLK * NKB;
+    static constexpr int NI = (CNT + NTHREADS - 1) / NTHREADS;
+    static constexpr uint32_t ESZ = (uint32_t)sizeof(T);
+    struct Stage { u32x4 r[NI][KB]; };
+    rsrc_t rs;
+    const cb_pixel* tab;
+    uint32_t ldb;               // bytes between consecutive reduction indices
+    uint32_t voff[NI];          // PLAIN: byte offset of (k = kb0, row) | TAPS/GATHER: byte offset contributed by the row
+    int kb0[NI];                // k of the block's first line
+    int co[NI], tap[NI];        // TAPS
+    int rr[NI], ss[NI];         // GATHER
+    cb_pixel px[NI][KB];        // GATHER: table entries of the NEXT tile (prefetched one call ahead)
+    bool act[NI];
+    uint32_t bound;
+
+    __device__ __forceinline__ void init(const GP& p, const Opnd& o, int row0, int bnd, int kt0, int tid) {
+        rs = make_rsrc(o.base, o.bytes);
+        tab = o.tab; ldb = (uint32_t)o.ld * ESZ; bound = (uint32_t)bnd;
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int b = ((tid + SHIFT) % NTHREADS) + it * NTHREADS;
+            const int kb = b % NKB, rb = b / NKB;
+            const int row = row0 + rb * X::RB;
+            act[it] = (b < CNT) && (row < bnd);
+            kb0[it] = kt0 * X::BK + kb * KB;
+            co[it] = kb0[it]; tap[it] = 0; rr[it] = 0; ss[it] = 0;
+            if constexpr (KMODE == KM_PLAIN) {
+                voff[it] = ((uint32_t)kb0[it] * (uint32_t)o.ld + (uint32_t)row) * ESZ;
+            } else if constexpr (KMODE == KM_TAPS) {        // weights [Ct][taps][bound] of a transposed conv
+                tap[it] = kb0[it] / p.Ct;
+                co[it] = kb0[it] - tap[it] * p.Ct;
+                voff[it] = (uint32_t)row * ESZ;
+            } else {                                        // row = (tap, channel) of the gathered image
+                const int tp = row / p.Ct, ch = row - tp * p.Ct;
+                rr[it] = tp / p.S; ss[it] = tp - rr[it] * p.S;
+                voff[it] = (uint32_t)(rr[it] * (int)p.sH + ss[it] * (int)p.sW + ch) * ESZ;
+#pragma unroll
+                for (int j = 0; j < KB; ++j) {
+                    cb_pixel e = {0, (int16_t)-30000, (int16_t)-30000};
+                    if (act[it] && kb0[it] + j < p.K) e = tab[kb0[it] + j];
+                    px[it][j] = e;
+                }
+            }
+        }
+    }
+    template <bool CHECK> __device__ __forceinline__ void load(Stage& st, const GP& p) {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            if constexpr (KMODE == KM_PLAIN) {
+#pragma unroll
+                for (int j = 0; j < KB; ++j) {
+                    bool v = act[it];
+                    if (CHECK) v = v && (kb0[it] + j < p.K);
+                    st.r[it][j] = bload16(rs, v ? voff[it] + (uint32_t)j * ldb : OOB);
+                }
+                voff[it] += X::BK * ldb;
+                kb0[it] += X::BK;
+            } else if constexpr (KMODE == KM_TAPS) {        // (Ct % 8 == 0: a block never straddles a tap)
+                const int tapw = p.flip ? (p.R * p.S - 1 - tap[it]) : tap[it];
+                const bool v = act[it] && tap[it] < p.R * p.S;
+                const uint32_t base = (uint32_t)co[it] * ldb + (uint32_t)tapw * bound * ESZ + voff[it];
+#pragma unroll
+                for (int j = 0; j < KB; ++j) st.r[it][j] = bload16(rs, v ? base + (uint32_t)j * ldb : OOB);
+                co[it] += X::BK;
+                while (co[it] >= p.Ct) { co[it] -= p.Ct; ++tap[it]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < KB; ++j) {
+                    const cb_pixel e = px[it][j];
+                    const bool v = (unsigned)(e.ih0 + rr[it]) < (unsigned)p.H && (unsigned)(e.iw0 + ss[it]) < (unsigned)p.W;
+                    st.r[it][j] = bload16(rs, v ? (uint32_t)e.off * ESZ + voff[it] : OOB);
+                }
+                kb0[it] += X::BK;
+#pragma unroll
+                for (int j = 0; j < KB; ++j) {              // table entries of the next K tile
+                    cb_pixel e = {0, (int16_t)-30000, (int16_t)-30000};
+                    if (act[it] && kb0[it] + j < p.K) e = tab[kb0[it] + j];
+                    px[it][j] = e;
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void store(const Stage& st, unsigned char* tile, int tid) const {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int b = ((tid + SHIFT) % NTHREADS) + it * NTHREADS;
+            if (b >= CNT) continue;
+            const int kb = b % NKB, rb = b / NKB;
+            const int r0 = rb * X::RB;
+            if constexpr (sizeof(T) == 2 && KB == 8) {
+                // 8x8 16-bit transpose: st.r[it][j][d] holds rows (2d, 2d+1) at k = kb*8 + j; one 16-byte store per row
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    u32x4 even, odd;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        even[q] = __builtin_amdgcn_perm(st.r[it][2 * q + 1][d], st.r[it][2 * q][d], 0x05040100u);
+                        odd[q] = __builtin_amdgcn_perm(st.r[it][2 * q + 1][d], st.r[it][2 * q][d], 0x07060302u);
+                    }
+                    *reinterpret_cast<u32x4*>(tile + lds_off<T>(r0 + 2 * d, kb)) = even;
+                    *reinterpret_cast<u32x4*>(tile + lds_off<T>(r0 + 2 * d + 1, kb)) = odd;
+                }
+            } else if constexpr (sizeof(T) == 2 && KB == 2) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const uint32_t even = __builtin_amdgcn_perm(st.r[it][1][d], st.r[it][0][d], 0x05040100u);
+                    const uint32_t odd = __builtin_amdgcn_perm(st.r[it][1][d], st.r[it][0][d], 0x07060302u);
+                    *reinterpret_cast<uint32_t*>(tile + lds_off<T>(r0 + 2 * d, kb >> 2) + (kb & 3) * 4) = even;
+                    *reinterpret_cast<uint32_t*>(tile + lds_off<T>(r0 + 2 * d + 1, kb >> 2) + (kb & 3) * 4) = odd;
+                }
+            } else if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    u32x2 even = {__builtin_amdgcn_perm(st.r[it][1][d], st.r[it][0][d], 0x05040100u),
+                                  __builtin_amdgcn_perm(st.r[it][3][d], st.r[it][2][d], 0x05040100u)};
+                    u32x2 odd = {__builtin_amdgcn_perm(st.r[it][1][d], st.r[it][0][d], 0x07060302u),
+                                 __builtin_amdgcn_perm(st.r[it][3][d], st.r[it][2][d], 0x07060302u)};
+                    *reinterpret_cast<u32x2*>(tile + lds_off<T>(r0 + 2 * d, kb >> 1) + (kb & 1) * 8) = even;
+                    *reinterpret_cast<u32x2*>(tile + lds_off<T>(r0 + 2 * d + 1, kb >> 1) + (kb & 1) * 8) = odd;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u32x4 o = {st.r[it][0][e], st.r[it][1][e], st.r[it][2][e], st.r[it][3][e]};
+                    *reinterpret_cast<u32x4*>(tile + lds_off<T>(r0 + e, kb)) = o;
+                }
+            }
+        }
+    }
+};
+
+// =============================================================================================
+// KROW operands, bf16: no register transpose at all.  The tile is stored in LDS in its NATURAL image
+// [k][rows] (each k-line = ROWS contiguous elements = what a fully coalesced global read delivers) and the MFMA
+// fragments are produced by the LDS transpose-read ds_read_b64_tr_b16: per 16-lane group, lane p supplies the
+// address of 4 consecutive rows of line (kbase + p/4) and lane i receives column i of that 4 x 16 block
+// (semantics verified on gfx950 by tools/tr_probe.hip).  16-byte chunks of a line are XOR-swizzled with the
+// line index so that the 8 lines read by one 32-lane bank group fall into 8 distinct 32-byte windows.
+// =============================================================================================
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ s16x4 lds_read_tr(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+
+template <int ROWS> __device__ __forceinline__ int tr_chunk_swz(int kline) {
+    if constexpr (ROWS >= 128) return (((kline & 3) | (((kline >> 3) & 1) << 2)) << 1);          // 8 windows per line
+    else return ((((kline >> 1) & 1) | (((kline >> 3) & 1) << 1)) << 1);                        // 4 windows, 2 lines per bank row
+}
+// byte offset of rows [r, r+4) of line k in a KROW tile
+template <int ROWS> __device__ __forceinline__ int tr_off(int kline, int r) {
+    const int chunk = (r >> 3) ^ tr_chunk_swz<ROWS>(kline);
+    return kline * (ROWS * 2) + (chunk << 4) + ((r & 7) << 1);
+}
+
+// MFMA fragment (rows r0..r0+15, k = kk*32 + 8*(lane>>4) .. +7) of a natural-image KROW tile
+template <int ROWS> __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int r0, int kk, int lane) {
+    const int p = lane & 15, kbase = kk * 32 + 8 * (lane >> 4) + (p >> 2);
+    const int r = r0 + 4 * (p & 3);
+    union { struct { s16x4 lo, hi; } h; bf16x8 v; } u;
+    u.h.lo = lds_read_tr(tile + tr_off<ROWS>(kbase, r));
+    u.h.hi = lds_read_tr(tile + tr_off<ROWS>(kbase + 4, r));
+    return u.v;
+}
+
+template <int ROWS, int KMODE> struct KrowTr {
+    using X = Tr<bf16>;
+    static constexpr bool TR = true;
+    static constexpr int CH = ROWS / 8;                           // 16-byte chunks per k-line
+    static constexpr int NS = CH * X::BK / NTHREADS;
+    static_assert(CH * X::BK % NTHREADS == 0, "tile/threads mismatch");
+    static constexpr uint32_t ESZ = 2;
+    struct Stage { u32x4 r[NS]; };
+    rsrc_t rs;
+    const cb_pixel* tab;
+    uint32_t ldb, bound;
+    uint32_t voff[NS];          // PLAIN: byte offset of (k-line, chunk) | TAPS / GATHER: the part contributed by the rows
+    int kl[NS];                 // global k of the slot's line
+    int co[NS], tap[NS];        // TAPS
+    int rr, ss;                 // GATHER (the 8 rows of a chunk share a tap)
+    cb_pixel px[NS];            // GATHER: table entries of the NEXT tile
+    bool act[NS];
+
+    __device__ __forceinline__ void init(const GP& p, const Opnd& o, int row0, int bnd, int kt0, int tid) {
+        rs = make_rsrc(o.base, o.bytes);
+        tab = o.tab; ldb = (uint32_t)o.ld * ESZ; bound = (uint32_t)bnd;
+        rr = 0; ss = 0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int idx = tid + i * NTHREADS;
+            const int chunk = idx % CH, kline = idx / CH;
+            const int row = row0 + chunk * 8;
+            act[i] = row < bnd;
+            kl[i] = kt0 * X::BK + kline;
+            co[i] = kl[i]; tap[i] = 0;
+            if constexpr (KMODE == KM_PLAIN) {
+                voff[i] = ((uint32_t)kl[i] * (uint32_t)o.ld + (uint32_t)row) * ESZ;
+            } else if constexpr (KMODE == KM_TAPS) {
+                tap[i] = kl[i] / p.Ct;
+                co[i] = kl[i] - tap[i] * p.Ct;
+                voff[i] = (uint32_t)row * ESZ;
+            } else {
+                const int tp = row / p.Ct, ch = row - tp * p.Ct;        // chunk is the same for all slots of a thread
+                rr = tp / p.S; ss = tp - rr * p.S;
+                voff[i] = (uint32_t)(rr * (int)p.sH + ss * (int)p.sW + ch) * ESZ;
+                cb_pixel e = {0, (int16_t)-30000, (int16_t)-30000};
+                if (act[i] && kl[i] < p.K) e = tab[kl[i]];
+                px[i] = e;
+            }
+        }
+    }
+    template <bool CHECK> __device__ __forceinline__ void load(Stage& st, const GP& p) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            if constexpr (KMODE == KM_PLAIN) {
+                bool v = act[i];
+                if (CHECK) v = v && (kl[i] < p.K);
+                st.r[i] = bload16(rs, v ? voff[i] : OOB);
+                voff[i] += X::BK * ldb;
+                kl[i] += X::BK;
+            } else if constexpr (KMODE == KM_TAPS) {
+                const int tapw = p.flip ? (p.R * p.S - 1 - tap[i]) : tap[i];
+                const bool v = act[i] && tap[i] < p.R * p.S;
+                st.r[i] = bload16(rs, v ? (uint32_t)co[i] * ldb + (uint32_t)tapw * bound * ESZ + voff[i] : OOB);
+                co[i] += X::BK;
+                while (co[i] >= p.Ct) { co[i] -= p.Ct; ++tap[i]; }
+            } else {
+                const cb_pixel e = px[i];
+                const bool v = (unsigned)(e.ih0 + rr) < (unsigned)p.H && (unsigned)(e.iw0 + ss) < (unsigned)p.W;
+                st.r[i] = bload16(rs, v ? (uint32_t)e.off * ESZ + voff[i] : OOB);
+                kl[i] += X::BK;
+                cb_pixel nx = {0, (int16_t)-30000, (int16_t)-30000};
+                if (act[i] && kl[i] < p.K) nx = tab[kl[i]];
+                px[i] = nx;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(const Stage& st, unsigned char* tile, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int idx = tid + i * NTHREADS;
+            const int chunk = idx % CH, kline = idx / CH;
+            *reinterpret_cast<u32x4*>(tile + kline * (ROWS * 2) + ((chunk ^ tr_chunk_swz<ROWS>(kline)) << 4)) = st.r[i];
+        }
+    }
+};
+
+// Workgroup -> (n tile, m tile, k split).  The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs,
+// each with its own L2.  Remapped, XCD x owns the x-th contiguous eighth of the (split, m tile, n tile) order, so the
+// A rows / K slices its blocks share are fetched into ONE L2 instead of all eight.
+struct TileId { int bx, by, bz; };
+__device__ __forceinline__ TileId tile_id(const GP& p) {
+    TileId t;
+    if (!p.xcd_remap) { t.bx = blockIdx.x; t.by = blockIdx.y; t.bz = blockIdx.z; return t; }
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned total = gx * gy * gridDim.z;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = lin & 7u, i = lin >> 3;
+    const unsigned q = total >> 3, r = total & 7u;
+    const unsigned l2 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    t.bx = (int)(l2 % gx);
+    const unsigned rest = l2 / gx;
+    t.by = (int)(rest % gy);
+    t.bz = (int)(rest / gy);
+    return t;
+}
+
+// strided-batched problems: grid z = batch * split_k + k split.  Rebases the operands of this block's problem.
+__device__ __forceinline__ void apply_batch(GP& p, TileId& t) {
+    if (p.batch <= 1) return;
+    const int b = t.bz / p.split_k;
+    t.bz -= b * p.split_k;
+    const int64_t oa = b * p.bs_a, ob = b * p.bs_b;
+    p.A = reinterpret_cast<const unsigned char*>(p.A) + oa;
+    p.B = reinterpret_cast<const unsigned char*>(p.B) + ob;
+    p.C = reinterpret_cast<unsigned char*>(p.C) + b * p.bs_c;
+    if (p.a_bytes) p.a_bytes -= (uint32_t)oa;              // the range check of the buffer descriptors keeps covering the
+    if (p.b_bytes) p.b_bytes -= (uint32_t)ob;              // rest of the stacked buffer
+    if (p.a_rowsum) p.a_rowsum += b * p.bs_r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Epilogue of one 4-wide accumulator fragment (row m, columns nb..nb+3).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void epilogue_vec(const GP& p, f32x4 v, int m, int64_t orow, int nb) {
+    v = v * p.alpha;
+    if (p.scale) v = v * load4(p.scale + nb);
+    if (p.shift) v = v + load4(p.shift + nb);
+    if (p.C2) store4(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + nb, v);
+    if (p.act != CB_ACT_NONE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act(p.act, v[r]);
+    }
+    if (p.dropout_p > 0.f) {
+        v = v * dropout_mult4(p.seed, (uint64_t)m * ((p.N + 3) >> 2) + (nb >> 2), p.dropout_p);
+    }
+    if (p.residual) v = v + load4(reinterpret_cast<const T*>(p.residual) + orow * p.ldr + nb);
+    if (p.relu_after) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+    }
+    if (p.mask) {
+        f32x4 mk = load4(reinterpret_cast<const T*>(p.mask) + orow * p.ldm + nb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
+    }
+    if (p.dact_pre) {
+        f32x4 pr = load4(reinterpret_cast<const T*>(p.dact_pre) + orow * p.ldd + nb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(pr[r]);
+    }
+    if (p.c_f32) {
+        float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + nb;
+        if (p.split_k > 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(c + r, v[r]);
+        } else {
+            if (p.accumulate) v = v + load4(c);
+            store4(c, v);
+        }
+    } else {
+        T* c = reinterpret_cast<T*>(p.C) + orow * p.ldc + nb;
+        if (p.accumulate) v = v + load4(c);
+        store4(c, v);
+    }
+}
+
+// one element (ragged / unaligned edge path; reached through the LDS-staged slow epilogue below)
+template <typename T>
+__device__ __forceinline__ void epilogue_elem(const GP& p, float x, int m, int64_t orow, int n) {
+    x *= p.alpha;
+    if (p.scale) x *= p.scale[n];
+    if (p.shift) x += p.shift[n];
+    if (p.C2) reinterpret_cast<T*>(p.C2)[orow * p.ldc2 + n] = from_f32<T>(x);
+    x = apply_act(p.act, x);
+    if (p.dropout_p > 0.f) x *= dropout_mult1(p.seed, (uint64_t)m * ((p.N + 3) >> 2) + (n >> 2), n & 3, p.dropout_p);
+    if (p.residual) x += to_f32(reinterpret_cast<const T*>(p.residual)[orow * p.ldr + n]);
+    if (p.relu_after) x = x > 0.f ? x : 0.f;
+    if (p.mask) x = to_f32(reinterpret_cast<const T*>(p.mask)[orow * p.ldm + n]) > 0.f ? x : 0.f;
+    if (p.dact_pre) x *= gelu_erf_grad(to_f32(reinterpret_cast<const T*>(p.dact_pre)[orow * p.ldd + n]));
+    if (p.c_f32) {
+        float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + n;
+        if (p.split_k > 1) atomicAdd(c, x);
+        else *c = p.accumulate ? (*c + x) : x;
+    } else {
+        T* c = reinterpret_cast<T*>(p.C) + orow * p.ldc + n;
+        *c = from_f32<T>(p.accumulate ? (to_f32(*c) + x) : x);
+    }
+}
+
+// 8 consecutive elements <-> float[8] (one 16-byte bf16 / two 16-byte fp32 accesses)
+__device__ __forceinline__ void load8(const float* q, float (&v)[8]) {
+    f32x4 a = load4(q), b = load4(q + 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v[r] = a[r]; v[4 + r] = b[r]; }
+}
+__device__ __forceinline__ void load8(const bf16* q, float (&v)[8]) {
+    bf16x8 x = *reinterpret_cast<const bf16x8*>(q);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = (float)x[r];
+}
+__device__ __forceinline__ void store8(float* q, const float (&v)[8]) {
+    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    store4(q, a); store4(q + 4, b);
+}
+__device__ __forceinline__ void store8(bf16* q, const float (&v)[8]) {
+    bf16x8 x;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[r] = (bf16)v[r];
+    *reinterpret_cast<bf16x8*>(q) = x;
+}
+
+// Epilogue of 8 consecutive columns n..n+7 of row m (row-contiguous: every global access is a full 16-byte lane
+// access and a wave touches whole cache lines).  sc/sh are the per-column scale/shift the thread loaded once.
+template <typename T>
+__device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const float (&sc)[8], const float (&sh)[8],
+                                          int m, int64_t orow, int n) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
+    if (p.scale) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= sc[r];
+    }
+    if (p.shift) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += sh[r];
+    }
+    if (p.C2) store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, v);
+    if (p.act != CB_ACT_NONE) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = apply_act(p.act, v[r]);
+    }
+    if (p.dropout_p > 0.f) {
+        const uint64_t grp = (uint64_t)m * ((p.N + 3) >> 2) + (n >> 2);
+        const f32x4 d0 = dropout_mult4(p.seed, grp, p.dropout_p), d1 = dropout_mult4(p.seed, grp + 1, p.dropout_p);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] *= d0[r]; v[4 + r] *= d1[r]; }
+    }
+    if (p.residual) {
+        float t[8];
+        load8(reinterpret_cast<const T*>(p.residual) + orow * p.ldr + n, t);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += t[r];
+    }
+    if (p.relu_after) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+    }
+    if (p.mask) {
+        float t[8];
+        load8(reinterpret_cast<const T*>(p.mask) + orow * p.ldm + n, t);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = t[r] > 0.f ? v[r] : 0.f;
+    }
+    if (p.dact_pre) {
+        float t[8];
+        load8(reinterpret_cast<const T*>(p.dact_pre) + orow * p.ldd + n, t);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_grad(t[r]);
+    }
+    if (p.c_f32) {
+        float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + n;
+        if (p.accumulate) {
+            float t[8];
+            load8(c, t);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += t[r];
+        }
+        store8(c, v);
+    } else {
+        T* c = reinterpret_cast<T*>(p.C) + orow * p.ldc + n;
+        if (p.accumulate) {
+            float t[8];
+            load8(c, t);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += t[r];
+        }
+        store8(c, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tile epilogue shared by both kernel structures.  acc[i][j] = 4 consecutive n of row m (swapped MFMA operands).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int SMEM_BYTES>
+__device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 32], unsigned char* smem, int m0, int n0, int tid) {
+    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    if (p.dropout_p > 0.f && p.seed_ptr) p.seed += *p.seed_ptr;
+    const bool fast = p.c_vec && (n0 + BN <= p.N);      // block-uniform
+    if (p.c_vec8) {
+        // Row-contiguous epilogue: the fp32 accumulators go through LDS (free after the main loop), half the tile
+        // rows at a time, so that each thread then owns 8 consecutive columns of one row: residual / mask reads and
+        // the stores are 16-byte lane accesses over whole cache lines (the MFMA register layout would touch 16
+        // different lines per store instruction -- the dominant cost of the short-K convolutions).
+        constexpr int SROW = BN * 4 + 16;              // +16 B staggers consecutive rows across the banks
+        constexpr int CPR = BN / 8;                    // 8-column chunks per tile row
+        constexpr int ITER = WM * CPR / NTHREADS;
+        static_assert(WM * SROW <= SMEM_BYTES, "staging does not fit");
+        static_assert(WM * CPR % NTHREADS == 0 && NTHREADS % CPR == 0, "chunk map");
+        const int cc = tid % CPR, n = n0 + cc * 8;
+        const bool nok = n < p.N;                      // N % 8 == 0 (host-checked): chunks are all-in or all-out
+        float sc[8], sh[8];
+        if (p.scale && nok) load8(p.scale + n, sc);
+        if (p.shift && nok) load8(p.shift + n, sh);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();
+            if (wm == h) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        *reinterpret_cast<f32x4*>(smem + (i * 16 + (lane & 15)) * SROW + (wn * WN + j * 16 + 4 * (lane >> 4)) * 4) = acc[i][j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int rl = (tid + it * NTHREADS) / CPR;
+                const int m = m0 + h * WM + rl;
+                if (m < p.M && nok) {
+                    const int64_t orow = p.c_rowmap ? (int64_t)p.c_rowmap[m] : (int64_t)m;
+                    float v[8];
+                    load8(reinterpret_cast<const float*>(smem + rl * SROW + cc * 32), v);
+                    epilogue8<T>(p, v, sc, sh, m, orow, n);
+                }
+            }
+        }
+    } else if (p.split_k > 1 && p.c_vec) {
+        // split-K partial sums: fp32 atomics, issued so that a wave instruction covers 64 consecutive floats of one
+        // output row (whole cache lines per L2 atomic request instead of 16 rows x 16 B from the MFMA layout).
+        constexpr int SROW = BN * 4 + 16;
+        static_assert(WM * SROW <= SMEM_BYTES, "staging does not fit");
+        float* cbase = reinterpret_cast<float*>(p.C);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();
+            if (wm == h) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        *reinterpret_cast<f32x4*>(smem + (i * 16 + (lane & 15)) * SROW + (wn * WN + j * 16 + 4 * (lane >> 4)) * 4) = acc[i][j];
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int idx = tid; idx < WM * BN; idx += NTHREADS) {
+                const int rl = idx / BN, cl = idx % BN;
+                const int m = m0 + h * WM + rl, n = n0 + cl;
+                if (m < p.M && n < p.N) {
+                    const int64_t orow = p.c_rowmap ? (int64_t)p.c_rowmap[m] : (int64_t)m;
+                    float x = *reinterpret_cast<const float*>(smem + rl * SROW + cl * 4) * p.alpha;
+                    if (p.scale) x *= p.scale[n];
+                    atomicAdd(cbase + orow * p.ldc + n, x);
+                }
+            }
+        }
+    } else if (fast) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * WM + i * 16 + (lane & 15);
+            const bool mok = m < p.M;
+            const int64_t orow = (mok && p.c_rowmap) ? (int64_t)p.c_rowmap[m] : (int64_t)m;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int nb = n0 + wn * WN + j * 16 + 4 * (lane >> 4);
+                if (mok) epilogue_vec<T>(p, acc[i][j], m, orow, nb);
+            }
+        }
+    } else {
+        // ragged N edge or unaligned output: stage the accumulators through LDS (free after the main
+        // loop), half the tile rows at a time, then run a plain bounds-checked per-element loop.
+        float* stage = reinterpret_cast<float*>(smem);
+        static_assert(WM * BN * 4 <= SMEM_BYTES, "staging does not fit");
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();
+            if (wm == h) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        *reinterpret_cast<f32x4*>(stage + (i * 16 + (lane & 15)) * BN + wn * WN + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+            }
+            __syncthreads();
+            for (int idx = tid; idx < WM * BN; idx += NTHREADS) {
+                const int rl = idx / BN, cl = idx % BN;
+                const int m = m0 + h * WM + rl, n = n0 + cl;
+                if (m < p.M && n < p.N) {
+                    const int64_t orow = p.c_rowmap ? (int64_t)p.c_rowmap[m] : (int64_t)m;
+                    epilogue_elem<T>(p, stage[idx], m, orow, n);
+                }
+            }
+        }
+    }
+}
+
+
+template <typename T, int BM, int BN, typename LA, typename LB, int PF, bool RS = false>
+__global__ void __launch_bounds__(256) gemm_kernel(GP p) {
+    using X = Tr<T>;
+    constexpr int BK = X::BK;
+    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+    constexpr int TILE_A = BM * X::ROWB, TILE_B = BN * X::ROWB;
+    constexpr int SMEM_BYTES = 2 * (TILE_A + TILE_B);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    TileId bid = tile_id(p);
+    apply_batch(p, bid);
+    const int m0 = bid.by * BM, n0 = bid.bx * BN;
+    const int kt_per = (p.ktiles + p.split_k - 1) / p.split_k;
+    const int kt0 = bid.bz * kt_per;
+    const int nt = ((kt0 + kt_per < p.ktiles) ? kt0 + kt_per : p.ktiles) - kt0;
+    if (nt <= 0) return;
+
+    LA la;
+    LB lb;
+    {
+        Opnd oa = {p.A, p.a_tab, p.lda, p.a_mode, p.a_bytes};
+        Opnd ob = {p.B, p.b_tab, p.ldb, p.b_mode, p.b_bytes};
+        la.init(p, oa, m0, p.M, kt0, tid);
+        lb.init(p, ob, n0, p.N, kt0, tid);
+    }
+    typename LA::Stage sa[PF];
+    typename LB::Stage sb[PF];
+
+    // tiles are loaded strictly in order (the loaders advance their k position on every call)
+    auto load_tiles = [&](typename LA::Stage& xa, typename LB::Stage& xb) {      // steady state: full K tiles only
+        la.template load<false>(xa, p);
+        lb.template load<false>(xb, p);
+    };
+    auto load_tiles_checked = [&](typename LA::Stage& xa, typename LB::Stage& xb) {
+        la.template load<true>(xa, p);
+        lb.template load<true>(xb, p);
+    };
+    auto store_tiles = [&](const typename LA::Stage& xa, const typename LB::Stage& xb, int buf) {
+        unsigned char* As = smem + buf * (TILE_A + TILE_B);
+        la.store(xa, As, tid);
+        lb.store(xb, As + TILE_A, tid);
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
+    // RS: row sums of A over k (bias gradients of a weight-gradient GEMM) ride on the matrix core: one extra MFMA per A
+    // fragment against an all-ones B fragment, in the first column of blocks only
+    f32x4 accr[RS ? FM : 1];
+#pragma unroll
+    for (int i = 0; i < (RS ? FM : 1); ++i) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; accr[i] = z; }
+    const bool rs_on = RS && p.a_rowsum != nullptr && bid.bx == 0 && wn == 0;     // wave-uniform
+
+    // prologue: K-tile j lives in register stage j % PF
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+        if (s < nt) load_tiles_checked(sa[s], sb[s]);
+    store_tiles(sa[0], sb[0], 0);
+    if (PF < nt) load_tiles_checked(sa[0], sb[0]);
+    __syncthreads();
+
+    auto compute_tile = [&](int buf) {
+        const unsigned char* As = smem + buf * (TILE_A + TILE_B);
+        const unsigned char* Bs = As + TILE_A;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int kk = 0; kk < BK / 32; ++kk) {
+                bf16x8 af[FM], bfr[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    if constexpr (LA::TR) af[i] = tr_frag<BM>(As, wm * WM + i * 16, kk, lane);
+                    else af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off<T>(wm * WM + i * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    if constexpr (LB::TR) bfr[j] = tr_frag<BN>(Bs, wn * WN + j * 16, kk, lane);
+                    else bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<T>(wn * WN + j * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                if constexpr (RS) {
+                    if (rs_on) {
+                        bf16x8 ones;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) accr[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accr[i], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                float af[FM], bfr[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    af[i] = *reinterpret_cast<const float*>(As + lds_off<T>(wm * WM + i * 16 + (lane & 15), kk) + (lane >> 4) * 4);
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    bfr[j] = *reinterpret_cast<const float*>(Bs + lds_off<T>(wn * WN + j * 16 + (lane & 15), kk) + (lane >> 4) * 4);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                if constexpr (RS) {
+                    if (rs_on) {
+#pragma unroll
+                        for (int i = 0; i < FM; ++i) accr[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, af[i], accr[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+
+    int t = 0;
+    // steady state: branch-free body (compute tile t, stage tile t+1 into LDS, issue the loads of tile t+1+PF),
+    // so the PF register stages really stay in flight across iterations
+    while (t + 2 * PF < nt - 1) {                 // ... and never the last (possibly partial) K tile
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {            // t % PF == s: static register-stage indices
+            const int S1 = (s + 1) % PF;
+            compute_tile(t & 1);
+            store_tiles(sa[S1], sb[S1], (t + 1) & 1);
+            load_tiles(sa[S1], sb[S1]);
+            __syncthreads();
+            ++t;
+        }
+    }
+    // tail: at most 2*PF+1 tiles, guarded (K tail handled by the checked loads)
+    while (t < nt) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            if (t < nt) {
+                const int S1 = (s + 1) % PF;
+                compute_tile(t & 1);
+                if (t + 1 < nt) {
+                    store_tiles(sa[S1], sb[S1], (t + 1) & 1);
+                    if (t + 1 + PF < nt) load_tiles_checked(sa[S1], sb[S1]);
+                }
+                __syncthreads();
+                ++t;
+            }
+        }
+    }
+
+    if constexpr (RS) {
+        if (rs_on && (lane >> 4) == 0) {                 // every accumulator row holds the sum: take row 0 of lanes 0..15
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm * WM + i * 16 + lane;
+                if (m < p.M) atomicAdd(p.a_rowsum + m, accr[i][0]);
+            }
+        }
+    }
+    tile_epilogue<T, BM, BN, SMEM_BYTES>(p, acc, smem, m0, n0, tid);
+}
+
+// =============================================================================================
+// v6 structure (bf16 fast path without convolution-gathered KROW operands): operands go global -> LDS by
+// LDS-DMA (buffer_load_dwordx4 ... lds): no VGPR staging, no ds_write, and an NST-deep LDS ring whose depth is
+// spent with counted s_waitcnt vmcnt(N) + one raw s_barrier per K step.  The LDS destination of an LDS-DMA is
+// wave-uniform base + lane*16, so the XOR swizzles of the tile images are applied to each lane's SOURCE address.
+// =============================================================================================
+__device__ __forceinline__ void dma16(rsrc_t rs, unsigned char* lds_wave_base, uint32_t voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
+}
+// s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields left at "no wait")
+#define CB_WAIT_VMCNT(N) __builtin_amdgcn_s_waitcnt((((N) & 15) | (7 << 4) | (15 << 8) | ((((N) >> 4) & 3) << 14)))
+
+// ROWK image [rows][128 B], 16-byte segment s of row r stored at segment s ^ (r & 7)  (same image as RowkFast)
+template <int ROWS, bool GATHER> struct RowkDma {
+    using X = Tr<bf16>;
+    static constexpr bool TR = false;
+    static constexpr int NI = ROWS / 8 / 4;            // 1-KiB DMA instructions per wave per tile
+    rsrc_t rs;
+    uint32_t voff[NI];
+    int ih[NI], iw[NI];
+    int c, rr, ss, krem;
+
+    __device__ __forceinline__ void init(const GP& p, const Opnd& o, int row0, int bound, int kt0, int tid) {
+        rs = make_rsrc(o.base, o.bytes);
+        const int lane = tid & 63, wave = tid >> 6;
+        const int rin = lane >> 3;                                   // row within the 8-row group (= row & 7)
+        const int lseg = (lane & 7) ^ rin;                           // logical segment this lane fetches
+        const int k = kt0 * X::BK + lseg * 8;
+        c = k; rr = 0; ss = 0; krem = p.K - k;
+        if constexpr (GATHER) {
+            int tap = k / p.Ct;
+            c = k - tap * p.Ct;
+            rr = tap / p.S; ss = tap - rr * p.S;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row = row0 + (i * 4 + wave) * 8 + rin;
+            const bool ok = row < bound;
+            ih[i] = 0; iw[i] = 0;
+            if constexpr (GATHER) {
+                cb_pixel px = {0, 0, 0};
+                if (ok) px = o.tab[row];
+                ih[i] = px.ih0; iw[i] = px.iw0;
+                voff[i] = ok ? (uint32_t)px.off * 2u : OOB;
+            } else {
+                voff[i] = ok ? ((uint32_t)row * (uint32_t)o.ld + (uint32_t)k) * 2u : OOB;
+            }
+        }
+    }
+    template <bool CHECK> __device__ __forceinline__ void issue(const GP& p, unsigned char* tile, int wave) {
+        if constexpr (GATHER) {
+            const bool kv = rr < p.R;
+            const uint32_t koff = (uint32_t)(rr * (int)p.sH + ss * (int)p.sW + c) * 2u;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const bool v = kv && (unsigned)(ih[i] + rr) < (unsigned)p.H && (unsigned)(iw[i] + ss) < (unsigned)p.W;
+                dma16(rs, tile + (i * 4 + wave) * 1024, v ? voff[i] + koff : OOB);
+            }
+            if (p.Ct >= X::BK) {
+                c += X::BK;
+                if (c >= p.Ct) { c -= p.Ct; if (++ss == p.S) { ss = 0; ++rr; } }
+            } else {
+                ss += X::BK / p.Ct;
+                while (ss >= p.S) { ss -= p.S; ++rr; }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                uint32_t o32 = voff[i];
+                if (CHECK && krem <= 0) o32 = OOB;
+                dma16(rs, tile + (i * 4 + wave) * 1024, o32);
+                voff[i] += X::BK * 2u;
+            }
+            krem -= X::BK;
+        }
+    }
+};
+
+// KROW natural image [64 k-lines][ROWS*2 B], 16-byte chunk c of line k stored at chunk c ^ tr_chunk_swz(k)
+template <int ROWS, int KMODE> struct KrowDma {
+    using X = Tr<bf16>;
+    static constexpr bool TR = true;
+    static constexpr int CH = ROWS / 8;                 // chunks per k-line
+    static constexpr int LPI = 64 / CH;                 // k-lines per DMA instruction
+    static constexpr int NI = X::BK / LPI / 4;          // DMA instructions per wave per tile
+    static_assert(KMODE != KM_GATHER, "gathered KROW operands use the register path");
+    rsrc_t rs;
+    uint32_t ldb, bound;
+    uint32_t voff[NI];
+    int kl[NI], co[NI], tap[NI];
+    bool act;
+
+    __device__ __forceinline__ void init(const GP& p, const Opnd& o, int row0, int bnd, int kt0, int tid) {
+        rs = make_rsrc(o.base, o.bytes);
+        ldb = (uint32_t)o.ld * 2u; bound = (uint32_t)bnd;
+        const int lane = tid & 63, wave = tid >> 6;
+        act = false;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int kline = (i * 4 + wave) * LPI + lane / CH;
+            const int lchunk = (lane % CH) ^ tr_chunk_swz<ROWS>(kline);
+            const int row = row0 + lchunk * 8;
+            act = row < bnd;                                        // (lchunk depends on kline only through the swizzle:
+            kl[i] = kt0 * X::BK + kline;                            //  validity is tracked per instruction below)
+            co[i] = kl[i]; tap[i] = 0;
+            if constexpr (KMODE == KM_PLAIN) {
+                voff[i] = (row < bnd) ? ((uint32_t)kl[i] * (uint32_t)o.ld + (uint32_t)row) * 2u : OOB;
+            } else {
+                tap[i] = kl[i] / p.Ct;
+                co[i] = kl[i] - tap[i] * p.Ct;
+                voff[i] = (row < bnd) ? (uint32_t)row * 2u : OOB;
+            }
+        }
+    }
+    template <bool CHECK> __device__ __forceinline__ void issue(const GP& p, unsigned char* tile, int wave) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if constexpr (KMODE == KM_PLAIN) {
+                uint32_t o32 = voff[i];
+                if (CHECK && kl[i] >= p.K) o32 = OOB;
+                dma16(rs, tile + (i * 4 + wave) * 1024, o32);
+                voff[i] += X::BK * ldb;                             // (OOB + n * BK * ld stays >= 2 GiB: K * ld < 2 GiB)
+                kl[i] += X::BK;
+            } else {
+                const int tapw = p.flip ? (p.R * p.S - 1 - tap[i]) : tap[i];
+                const bool v = tap[i] < p.R * p.S;
+                dma16(rs, tile + (i * 4 + wave) * 1024, v ? (uint32_t)co[i] * ldb + (uint32_t)tapw * bound * 2u + voff[i] : OOB);
+                co[i] += X::BK;
+                while (co[i] >= p.Ct) { co[i] -= p.Ct; ++tap[i]; }
+            }
+        }
+    }
+};
+
+template <int BM, int BN, typename LA, typename LB, int NST>
+__global__ void __launch_bounds__(256) gemm_dma_kernel(GP p) {
+    using T = bf16;
+    using X = Tr<bf16>;
+    constexpr int BK = X::BK;
+    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+    constexpr int TILE_A = BM * 128, TILE_B = BN * 128, STAGE = TILE_A + TILE_B;
+    constexpr int SMEM_BYTES = NST * STAGE;
+    constexpr int LPT = LA::NI + LB::NI;                      // DMA instructions per wave per K tile
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    TileId bid = tile_id(p);
+    apply_batch(p, bid);
+    const int m0 = bid.by * BM, n0 = bid.bx * BN;
+    const int kt_per = (p.ktiles + p.split_k - 1) / p.split_k;
+    const int kt0 = bid.bz * kt_per;
+    const int nt = ((kt0 + kt_per < p.ktiles) ? kt0 + kt_per : p.ktiles) - kt0;
+    if (nt <= 0) return;
+
+    LA la;
+    LB lb;
+    {
+        Opnd oa = {p.A, p.a_tab, p.lda, p.a_mode, p.a_bytes};
+        Opnd ob = {p.B, p.b_tab, p.ldb, p.b_mode, p.b_bytes};
+        la.init(p, oa, m0, p.M, kt0, tid);
+        lb.init(p, ob, n0, p.N, kt0, tid);
+    }
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
+
+    auto issue = [&](int stage) {                     // (K tails and rows past M/N read zeros through the descriptor)
+        unsigned char* base = smem + stage * STAGE;
+        la.template issue<true>(p, base, wave);
+        lb.template issue<true>(p, base + TILE_A, wave);
+    };
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nt) issue(s);
+
+    int stage = 0;                                    // stage holding K tile t
+    for (int t = 0; t < nt; ++t) {
+        // this wave's share of tile t has landed when at most min(NST-2, tiles issued beyond t) tiles are in flight
+        if (nt - 1 - t >= NST - 2) { CB_WAIT_VMCNT(LPT * (NST - 2)); }
+        else { CB_WAIT_VMCNT(0); }
+        __builtin_amdgcn_s_barrier();                 // everyone's share landed; everyone is done reading stage (t-1)
+        if (t + NST - 1 < nt) {
+            int ns = stage + NST - 1;
+            if (ns >= NST) ns -= NST;
+            issue(ns);
+        }
+        const unsigned char* As = smem + stage * STAGE;
+        const unsigned char* Bs = As + TILE_A;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8 af[FM], bfr[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                if constexpr (LA::TR) af[i] = tr_frag<BM>(As, wm * WM + i * 16, kk, lane);
+                else af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off<T>(wm * WM + i * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                if constexpr (LB::TR) bfr[j] = tr_frag<BN>(Bs, wn * WN + j * 16, kk, lane);
+                else bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<T>(wn * WN + j * 16 + (lane & 15), kk * 4 + (lane >> 4)));
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (++stage == NST) stage = 0;
+    }
+    __syncthreads();
+    tile_epilogue<T, BM, BN, SMEM_BYTES>(p, acc, smem, m0, n0, tid);
+}
+
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename T, int BM, int BN, int PF, typename LA, typename LB, bool RS = false>
+int launch_k(const GP& p, hipStream_t st) {
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.split_k * (p.batch > 1 ? p.batch : 1));
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, LA, LB, PF, RS>), grid, dim3(NTHREADS), 0, st, p);
+    return cb_launch_status("cb_gemm");
+}
+// weight-gradient form (both operands KROW): with or without the fused row sums of A
+template <typename T, int BM, int BN, int PF, typename LA, typename LB>
+int launch_wgrad(const GP& p, hipStream_t st) {
+    if (p.a_rowsum) return launch_k<T, BM, BN, PF, LA, LB, true>(p, st);
+    return launch_k<T, BM, BN, PF, LA, LB, false>(p, st);
+}
+
+// addressing-mode dispatch: lean compile-time loaders on the fast path, the generic loaders otherwise
+template <typename T, int BM, int BN, int PF>
+int launch_gemm(const GP& p, bool fast, hipStream_t st) {
+    const bool a_krow = p.a_mode == CB_KROW;
+    const bool b_krow = p.b_mode != CB_ROWK;
+    if (a_krow && !b_krow) return cb_fail("cb_gemm: unsupported operand mode combination (A KROW with B ROWK)");
+    if (fast) {
+        const int taps = p.R * p.S;
+        if constexpr (sizeof(T) == 2) {
+            // The LDS-DMA ring kernel is OPT-IN (CB_GEMM_DMA=1).  Measured on MI355X against the register-staged kernel
+            // below for every GEMM of the step: equal where K is long (both run into the L2->LDS bandwidth of the 64x64
+            // tile, profiles/r01_gemm_l2_analysis.md; an 8-stage ring, CB_GEMM_DMA_DEEP=1, changes nothing either) and
+            // 10-20 % slower for short-K convolutions (its 64 KiB ring halves the blocks per CU).
+            static const bool use_dma = getenv("CB_GEMM_DMA") != nullptr;
+            constexpr int NST = (BM >= 128 && BN >= 128) ? 3 : 4;
+            const bool ct_ok = p.Ct % Tr<bf16>::BK == 0;
+            if (use_dma) {
+                dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.split_k * (p.batch > 1 ? p.batch : 1));
+                static const int deep_env = getenv("CB_GEMM_DMA_DEEP") ? atoi(getenv("CB_GEMM_DMA_DEEP")) : 0;
+                const int64_t nblk = (int64_t)grid.x * grid.y * grid.z;
+                const bool deep = (BM == 64 && BN == 64) && deep_env != 0 && nblk <= 320 && p.ktiles / p.split_k >= 8;
+#define CB_LAUNCH_DMA(LA_, LB_)                                                                               \
+    do {                                                                                                      \
+        if constexpr (BM == 64 && BN == 64) {                                                                 \
+            if (deep) {                                                                                       \
+                hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, LA_, LB_, 8>), grid, dim3(NTHREADS), 0, st, p);   \
+                return cb_launch_status("cb_gemm");                                                           \
+            }                                                                                                 \
+        }                                                                                                     \
+        hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, LA_, LB_, NST>), grid, dim3(NTHREADS), 0, st, p);         \
+        return cb_launch_status("cb_gemm");                                                                   \
+    } while (0)
+                using RA0 = RowkDma<BM, false>; using RA1 = RowkDma<BM, true>; using RB0 = RowkDma<BN, false>;
+                using KA0 = KrowDma<BM, KM_PLAIN>; using KB0 = KrowDma<BN, KM_PLAIN>; using KB1 = KrowDma<BN, KM_TAPS>;
+                if (p.a_mode == CB_ROWK && p.b_mode == CB_ROWK) CB_LAUNCH_DMA(RA0, RB0);
+                if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_ROWK) CB_LAUNCH_DMA(RA1, RB0);
+                // measured (profiles/r01_gemm_microbench.md): the DMA ring wins for k-contiguous operands only; with a
+                // transpose-read (KROW) operand the register-staged kernels below are faster, so those stay opt-in
+                static const bool dma_krow = getenv("CB_GEMM_DMA_KROW") != nullptr;
+                if (dma_krow) {
+                    if (p.a_mode == CB_ROWK && (p.b_mode == CB_KROW || (p.b_mode == CB_KROW_TAPS && taps == 1))) CB_LAUNCH_DMA(RA0, KB0);
+                    if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_KROW_TAPS && ct_ok) CB_LAUNCH_DMA(RA1, KB1);
+                    if (p.a_mode == CB_KROW && p.b_mode == CB_KROW && !p.a_rowsum) CB_LAUNCH_DMA(KA0, KB0);
+                }
+#undef CB_LAUNCH_DMA
+            }
+            // measured on MI355X: next to a ROWK operand the transpose-read image wins for 64-row tiles, the
+            // register transpose (KB = 4, all 256 threads) for 128-row tiles; with two KROW operands the
+            // transpose-read image wins for both tile sizes (profiles/r01_gemm_microbench.md)
+            if constexpr (BN < 128) {
+                if (p.a_mode == CB_ROWK && (p.b_mode == CB_KROW || (p.b_mode == CB_KROW_TAPS && taps == 1)))
+                    return launch_k<T, BM, BN, PF, RowkFast<T, BM, false>, KrowTr<BN, KM_PLAIN>>(p, st);
+                if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_KROW_TAPS && p.Ct % Tr<bf16>::BK == 0)
+                    return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, KrowTr<BN, KM_TAPS>>(p, st);
+            }
+            if (p.a_mode == CB_KROW && p.b_mode == CB_KROW)
+                return launch_wgrad<T, BM, BN, PF, KrowTr<BM, KM_PLAIN>, KrowTr<BN, KM_PLAIN>>(p, st);
+            if (p.a_mode == CB_KROW && p.b_mode == CB_KROW_GATHER)
+                return launch_k<T, BM, BN, PF, KrowTr<BM, KM_PLAIN>, KrowTr<BN, KM_GATHER>>(p, st);
+        }
+        if (p.a_mode == CB_ROWK && p.b_mode == CB_ROWK)
+            return launch_k<T, BM, BN, PF, RowkFast<T, BM, false>, RowkFast<T, BN, false>>(p, st);
+        if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_ROWK)
+            return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, RowkFast<T, BN, false>>(p, st);
+        // fp32 parity mode (and odd channel counts): register-transposing loaders.  One KROW operand next to a ROWK
+        // one is spread over all 256 threads; two KROW operands take half the threads each (B shifted by 128)
+        constexpr int KB1B = BN >= 128 ? 4 : 2;
+        constexpr int KB2A = BM >= 128 ? 8 : 4, KB2B = BN >= 128 ? 8 : 4;
+        if (p.a_mode == CB_ROWK && (p.b_mode == CB_KROW || (p.b_mode == CB_KROW_TAPS && taps == 1)))
+            return launch_k<T, BM, BN, PF, RowkFast<T, BM, false>, KrowFast<T, BN, KM_PLAIN, KB1B, 0>>(p, st);
+        if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_KROW_TAPS)
+            return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, KrowFast<T, BN, KM_TAPS, KB1B, 0>>(p, st);
+        if (p.a_mode == CB_KROW && p.b_mode == CB_KROW)
+            return launch_wgrad<T, BM, BN, PF, KrowFast<T, BM, KM_PLAIN, KB2A, 0>, KrowFast<T, BN, KM_PLAIN, KB2B, 128>>(p, st);
+        if (p.a_mode == CB_KROW && p.b_mode == CB_KROW_GATHER)
+            return launch_k<T, BM, BN, PF, KrowFast<T, BM, KM_PLAIN, KB2A, 0>, KrowFast<T, BN, KM_GATHER, KB2B, 128>>(p, st);
+    }
+    if (!a_krow && !b_krow) return launch_k<T, BM, BN, PF, RowkLoader<T, BM, false>, RowkLoader<T, BN, false>>(p, st);
+    if (!a_krow) return launch_k<T, BM, BN, PF, RowkLoader<T, BM, false>, KrowLoader<T, BN, false>>(p, st);
+    if (p.b_mode == CB_KROW) return launch_wgrad<T, BM, BN, PF, KrowLoader<T, BM, false>, KrowLoader<T, BN, false>>(p, st);
+    return launch_k<T, BM, BN, PF, KrowLoader<T, BM, false>, KrowLoader<T, BN, false>>(p, st);
+}
+
+
+}  // namespace cbgemm

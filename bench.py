@@ -90,7 +90,7 @@ def main():
     model.load_state_dict(S.full_state_dict(cfg, "retrieval", 42), strict=True)
     model.to(dev)
     model.train(not args.forward_only)
-    model.prepare(dtype=torch.bfloat16, device=dev, overlap_wgrad=os.environ.get("CB_OVERLAP_WGRAD", "1") != "0")
+    model.prepare(dtype=torch.bfloat16, device=dev, overlap_wgrad=os.environ.get("CB_OVERLAP_WGRAD", "0") != "0")
     log("model prepared")
     bank = model.rt.bank
     sync = GradSync(bank)

@@ -62,6 +62,16 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     GP p{};
     p.A = d->A; p.B = d->B; p.C = d->C; p.C2 = d->C2; p.residual = d->residual; p.mask = d->mask;
     p.dact_pre = d->gelu_grad_pre; p.ldd = d->ld_gelu; p.a_rowsum = d->a_rowsum;
+    p.relu_bwd = d->relu_bwd != 0; p.post_scale = d->post_scale; p.post_scale2 = d->post_scale2;
+    if (p.relu_bwd) {
+        CB_REQUIRE(d->mask && (!d->c_f32 || d->dtype == CB_F32) && !d->scale && !d->shift && d->act == CB_ACT_NONE && d->dropout_p <= 0.f && !d->relu_after &&
+                   !d->gelu_grad_pre && (d->split_k <= 1),
+                   "cb_gemm: relu_bwd needs a mask and excludes scale/shift/act/dropout/relu_after/gelu_grad_pre/split_k and an fp32 C next to bf16 operands");
+        CB_REQUIRE((!d->post_scale || aligned16(d->post_scale)) && (!d->post_scale2 || aligned16(d->post_scale2)),
+                   "cb_gemm: post_scale vectors must be 16-byte aligned");
+    } else {
+        CB_REQUIRE(!d->post_scale && !d->post_scale2, "cb_gemm: post_scale / post_scale2 need relu_bwd");
+    }
     p.batch = d->batch > 1 ? d->batch : 1;
     p.bs_a = d->batch_stride_a * esz; p.bs_b = d->batch_stride_b * esz;
     p.bs_c = d->batch_stride_c * (d->c_f32 ? 4 : esz); p.bs_r = d->batch_stride_rowsum;

@@ -23,6 +23,7 @@ template <> __device__ __forceinline__ int lds_off<float>(int row, int seg) { re
 struct GP {
     const void* A; const void* B; void* C; void* C2; const void* residual; const void* mask;
     const void* dact_pre; float* a_rowsum; int64_t ldd;
+    int relu_bwd; const float* post_scale; const float* post_scale2;   // ResNet-block ReLU x FrozenBN backward epilogue
     int batch; int64_t bs_a, bs_b, bs_c, bs_r;      // strided-batched problems on gridDim.z (strides in BYTES; bs_r in floats)
     const float* scale; const float* shift;
     const cb_pixel* a_tab; const cb_pixel* b_tab; const int32_t* c_rowmap;
@@ -633,6 +634,17 @@ __device__ __forceinline__ void apply_batch(GP& p, TileId& t) {
 template <typename T>
 __device__ __forceinline__ void epilogue_vec(const GP& p, f32x4 v, int m, int64_t orow, int nb) {
     v = v * p.alpha;
+    if (p.relu_bwd) {          // t = (acc [+ C] [+ residual]) where mask > 0;  C2 = t * post_scale2,  C = t * post_scale
+        T* c = reinterpret_cast<T*>(p.C) + orow * p.ldc + nb;
+        if (p.accumulate) v = v + load4(c);
+        if (p.residual) v = v + load4(reinterpret_cast<const T*>(p.residual) + orow * p.ldr + nb);
+        const f32x4 mk = load4(reinterpret_cast<const T*>(p.mask) + orow * p.ldm + nb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
+        if (p.C2) store4(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + nb, p.post_scale2 ? v * load4(p.post_scale2 + nb) : v);
+        store4(c, p.post_scale ? v * load4(p.post_scale + nb) : v);
+        return;
+    }
     if (p.scale) v = v * load4(p.scale + nb);
     if (p.shift) v = v + load4(p.shift + nb);
     if (p.C2) store4(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + nb, v);
@@ -678,6 +690,15 @@ __device__ __forceinline__ void epilogue_vec(const GP& p, f32x4 v, int m, int64_
 template <typename T>
 __device__ __forceinline__ void epilogue_elem(const GP& p, float x, int m, int64_t orow, int n) {
     x *= p.alpha;
+    if (p.relu_bwd) {
+        T* c = reinterpret_cast<T*>(p.C) + orow * p.ldc + n;
+        if (p.accumulate) x += to_f32(*c);
+        if (p.residual) x += to_f32(reinterpret_cast<const T*>(p.residual)[orow * p.ldr + n]);
+        x = to_f32(reinterpret_cast<const T*>(p.mask)[orow * p.ldm + n]) > 0.f ? x : 0.f;
+        if (p.C2) reinterpret_cast<T*>(p.C2)[orow * p.ldc2 + n] = from_f32<T>(p.post_scale2 ? x * p.post_scale2[n] : x);
+        *c = from_f32<T>(p.post_scale ? x * p.post_scale[n] : x);
+        return;
+    }
     if (p.scale) x *= p.scale[n];
     if (p.shift) x += p.shift[n];
     if (p.C2) reinterpret_cast<T*>(p.C2)[orow * p.ldc2 + n] = from_f32<T>(x);
@@ -726,6 +747,42 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
                                           int m, int64_t orow, int n) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
+    if (p.relu_bwd) {          // t = (acc [+ C] [+ residual]) where mask > 0;  C2 = t * post_scale2,  C = t * post_scale
+        T* c = reinterpret_cast<T*>(p.C) + orow * p.ldc + n;
+        float t[8];
+        if (p.accumulate) {
+            load8(c, t);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += t[r];
+        }
+        if (p.residual) {
+            load8(reinterpret_cast<const T*>(p.residual) + orow * p.ldr + n, t);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += t[r];
+        }
+        load8(reinterpret_cast<const T*>(p.mask) + orow * p.ldm + n, t);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = t[r] > 0.f ? v[r] : 0.f;
+        if (p.C2) {
+            float u[8];
+            if (p.post_scale2) {
+                load8(p.post_scale2 + n, t);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) u[r] = v[r] * t[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) u[r] = v[r];
+            }
+            store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, u);
+        }
+        if (p.post_scale) {
+            load8(p.post_scale + n, t);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] *= t[r];
+        }
+        store8(c, v);
+        return;
+    }
     if (p.scale) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] *= sc[r];

@@ -250,30 +250,41 @@ def _conv_fwd(rt: Runtime, x, conv, act=ACT_NONE, residual=None, relu_after=Fals
     return y
 
 
-def _conv_dgrad(rt: Runtime, g, conv, in_shape, scale=None, mask=None, residual=None, out=None, accumulate=False):
+def _conv_dgrad(rt: Runtime, g, conv, in_shape, scale=None, mask=None, residual=None, out=None, accumulate=False, fuse=None):
     """d(input) of a convolution given g = d(conv output) (already multiplied by the FrozenBN scale).
-    Epilogue options: per-channel ``scale`` and ReLU ``mask`` of the PRODUCER of the input, ``residual``."""
+    Epilogue options: per-channel ``scale`` and ReLU ``mask`` of the PRODUCER of the input, ``residual``.
+    ``fuse = (y, s_a, s_b)``: the input is the output y of a ResNet block; the launch also does that block's ReLU x
+    FrozenBN-scale backward and returns (t*s_a, t*s_b) with t = d(input) where y > 0 (s_b None -> t itself)."""
     n, h, w, cin = in_shape
     _, oh, ow, cout = g.shape
     k, s, p = conv.k, conv.stride, conv.pad
     wk = rt.bank.compute(conv.weight).view(cout, k * k * cin)
     mi = n * h * w
+    alloc = torch.zeros if s > 1 else torch.empty
     if out is None:
-        out = (torch.zeros if s > 1 else torch.empty)(n, h, w, cin, dtype=g.dtype, device=g.device)
+        out = alloc(n, h, w, cin, dtype=g.dtype, device=g.device)
     o2 = out.view(mi, cin)
     r2 = residual.view(mi, cin) if residual is not None else None
     k2 = mask.view(mi, cin) if mask is not None else None
+    extra = {}
+    second = None
+    if fuse is not None:
+        assert mask is None and scale is None
+        y, s_a, s_b = fuse
+        second = alloc(n, h, w, cin, dtype=g.dtype, device=g.device)
+        k2 = y.view(mi, cin)
+        extra = dict(relu_bwd=True, post_scale=s_a, post_scale2=s_b, out2=second.view(mi, cin))
     if k == 1:
         rowmap = rt.strided_rowmap(n, h, w, oh, ow, s, g.device) if s > 1 else None
         ops.gemm(g.view(n * oh * ow, cout), wk, n * oh * ow, cin, cout, out=o2, b_mode=KROW_TAPS, ldb=cin, R=1, S=1,
-                 Cin=cout, c_rowmap=rowmap, scale=scale, mask=k2, residual=r2, accumulate=accumulate)
+                 Cin=cout, c_rowmap=rowmap, scale=scale, mask=k2, residual=r2, accumulate=accumulate, **extra)
     else:
         assert s == 1
         tab = rt.table(n, h, w, 1, k - 1 - p, oh * ow * cout, ow * cout, cout, g.device)
         ops.gemm(g, wk, mi, cin, k * k * cout, out=o2, a_mode=ROWK_GATHER, a_tab=tab, lda=0, b_mode=KROW_TAPS,
                  ldb=k * k * cin, R=k, S=k, Cin=cout, H=oh, W=ow, sH=ow * cout, sW=cout, flip_taps=True, scale=scale,
-                 mask=k2, residual=r2, accumulate=accumulate)
-    return out
+                 mask=k2, residual=r2, accumulate=accumulate, **extra)
+    return (out, second) if fuse is not None else out
 
 
 def _conv_wgrad(rt: Runtime, g, x, conv):
@@ -361,20 +372,22 @@ def cnn_backward(bb: "GridFeatBackbone", saved_pack, dgrid: torch.Tensor):
     if not saved:
         rt.join()
         return
-    dout = _conv_dgrad(rt, dg, gconv, res5.shape)
+    def fuse_spec(i):
+        """the ReLU x FrozenBN-scale backward of block i, done by the launch that produces d(output of block i)"""
+        b, _x, _y1, _y2, o = saved[i]
+        s3_, _ = b.conv3.scale_shift()
+        ssc_ = b.shortcut.scale_shift()[0] if b.shortcut is not None else None
+        return (o, s3_, ssc_)
+
+    # (g3, sec): g3 = d(conv3 output of the block), sec = d(identity shortcut) or d(shortcut conv output)
+    g3, sec = _conv_dgrad(rt, dg, gconv, res5.shape, fuse=fuse_spec(len(saved) - 1))
     for idx in range(len(saved) - 1, -1, -1):
         blk, x, y1, y2, out = saved[idx]
         need_dx = idx > 0
-        s3, _ = blk.conv3.scale_shift()
         s2, _ = blk.conv2.scale_shift()
         s1, _ = blk.conv1.scale_shift()
-        if blk.shortcut is not None:
-            ssc, _ = blk.shortcut.scale_shift()
-            g3, _dz, gsc = ops.relu_scale_bwd(dout, out, s3, False, ssc)
-            dz = None
-        else:
-            g3, dz, gsc = ops.relu_scale_bwd(dout, out, s3, True, None)
-        with rt.side(g3, y2, gsc):
+        dz, gsc = (sec, None) if blk.shortcut is None else (None, sec)
+        with rt.side(g3, y2, sec):
             _conv_wgrad(rt, g3, y2, blk.conv3)
             if blk.shortcut is not None:
                 _conv_wgrad(rt, gsc, x, blk.shortcut)
@@ -385,11 +398,12 @@ def cnn_backward(bb: "GridFeatBackbone", saved_pack, dgrid: torch.Tensor):
         with rt.side(g1, x):
             _conv_wgrad(rt, g1, x, blk.conv1)
         if need_dx:
+            spec = fuse_spec(idx - 1)
             if blk.shortcut is None:
-                dout = _conv_dgrad(rt, g1, blk.conv1, x.shape, residual=dz)
+                g3, sec = _conv_dgrad(rt, g1, blk.conv1, x.shape, residual=dz, fuse=spec)
             else:
                 dout = _conv_dgrad(rt, g1, blk.conv1, x.shape)
-                _conv_dgrad(rt, gsc, blk.shortcut, x.shape, out=dout, accumulate=True)
+                g3, sec = _conv_dgrad(rt, gsc, blk.shortcut, x.shape, out=dout, accumulate=True, fuse=spec)
     rt.join()
 
 

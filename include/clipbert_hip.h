@@ -91,8 +91,13 @@ typedef struct {
                                  A + b*batch_stride_a, B + b*batch_stride_b, C + b*batch_stride_c (elements of their
                                  types) and a_rowsum + b*batch_stride_rowsum.  Plain operands only.  Used for the weight
                                  gradients of all encoder layers at once (same shapes, layer-strided buffers).       */
-    int32_t reserved3;
+    int32_t relu_bwd;         /* 1: ResNet-block backward epilogue (needs `mask` = the block's output y):
+                                 t = (acc [+ C if accumulate] [+ residual]) where mask > 0, else 0;
+                                 C2 = t * post_scale2[n] (t if null),  C = t * post_scale[n] (t if null).
+                                 One dgrad launch thereby also does the ReLU x FrozenBN-scale backward of the block
+                                 that consumes its result (F.relu_ + FrozenBatchNorm2d under autograd, grid_feat.py:95) */
     int64_t batch_stride_a, batch_stride_b, batch_stride_c, batch_stride_rowsum;
+    const float* post_scale; const float* post_scale2;
 } cb_gemm_desc;
 
 /* GEMM / implicit-GEMM convolution, all forms.  Replaces torch.nn.Linear / F.conv2d (+ apex-amp

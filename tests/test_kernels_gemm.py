@@ -110,6 +110,30 @@ def test_strided_batched_wgrad(hw, dt):
     torch.testing.assert_close(y.float(), torch.einsum("bmk,bnk->bmn", x.float(), w.float()), **tol(dt))
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("tile", [2, 1])
+def test_relu_bwd_epilogue(hw, dt, tile):
+    """dgrad launch that also does the consumer block's ReLU x FrozenBN-scale backward: C = t*s_a, C2 = t*s_b,
+    t = (acc [+ C] [+ residual]) where y > 0."""
+    if dt == torch.float32 and tile == 1:
+        pytest.skip("fp32 parity mode has one tile size")
+    M, N, K = 150, 72, 40
+    g, w = hw(rnd(M, K, seed=1).to(dt)), hw(rnd(K, N, seed=2, scale=0.2).to(dt))          # dX = g W  (W as [K][N], KROW)
+    y, res = hw(rnd(M, N, seed=3).to(dt)), hw(rnd(M, N, seed=4).to(dt))
+    sa, sb = hw(rnd(N, seed=5).abs() + 0.5), hw(rnd(N, seed=6).abs() + 0.5)
+    base = g.float() @ w.float()
+    for accumulate, residual, s2 in ((False, res, sb), (True, None, None)):
+        c0 = hw(rnd(M, N, seed=7).to(dt))
+        c = c0.clone()
+        c2 = torch.empty(M, N, dtype=dt, device=hw.dev)
+        ops.gemm(g, w, M, N, K, out=c, b_mode=ops.KROW, ldb=N, tile=tile, accumulate=accumulate, residual=residual, mask=y,
+                 relu_bwd=True, post_scale=sa, post_scale2=s2, out2=c2)
+        t = base + (c0.float() if accumulate else 0) + (residual.float() if residual is not None else 0)
+        t = torch.where(y.float() > 0, t, torch.zeros_like(t))
+        torch.testing.assert_close(c.float(), t * sa, **tol(dt))
+        torch.testing.assert_close(c2.float(), t * s2 if s2 is not None else t, **tol(dt))
+
+
 def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 

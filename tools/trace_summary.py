@@ -9,35 +9,44 @@ import sys
 
 
 def gemm_name(n):
+    """readable name of a cb_gemm instantiation from its (possibly half-demangled) symbol"""
+    if "gemm_kernel" not in n and "gemm_dma_kernel" not in n:
+        return None
     m = re.search(r"gemm_dma_kernelILi(\d+)ELi(\d+)E", n)
     if m:
         gather = "RowkDmaILi%sELb1" % m.group(1) in n
-        return f"cb_gemm {m.group(1)}x{m.group(2)} LDS-DMA ring: {'conv fwd (pixel gather)' if gather else 'linear / 1x1 fwd'}"
+        return f"cb_gemm {m.group(1)}x{m.group(2)} bf16 LDS-DMA ring: {'conv fwd (pixel gather)' if gather else 'linear / 1x1 fwd'}"
     m = re.search(r"gemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)E(.*)", n)
-    if not m:
-        m2 = re.search(r"gemm_kernel<([^,]+), (\d+), (\d+), (.*)", n)
-        if not m2:
-            return None
-        ty, bm, bn, rest = m2.group(1), m2.group(2), m2.group(3), m2.group(4)
-        a_g = "RowkFast<" in rest and ", true>" in rest.split("RowkFast<")[1][:40]
-        kinds = re.findall(r"KrowTr<\d+, (\d)>", rest)
+    if m:
+        dt, bm, bn, rest = ("bf16" if m.group(1) == "DF16b" else "fp32"), m.group(2), m.group(3), m.group(4)
+    else:                                               # rocprofv3 sometimes prints a half-demangled form
+        m = re.search(r"ELi(\d+)E(NS_.*)", n)
+        if not m:
+            return "cb_gemm (unparsed)"
+        dt, bm, bn, rest = "bf16", m.group(1), m.group(1), m.group(2)
+    # first loader
+    a = re.search(r"NS_\d+(RowkFast|KrowTr|KrowFast|RowkLoader|KrowLoader)I(?:DF16b|f)?(?:Li\d+E)?L([bi])(\d)", rest)
+    if not a:
+        return f"cb_gemm {bm}x{bn} {dt}: other"
+    a_kind, a_arg = a.group(1), a.group(3)
+    after = rest[a.end():]
+    if re.match(r"E*S2_", after) or re.match(r"[^N]*S2_", after[:12]):
+        b_kind, b_arg = a_kind, a_arg
     else:
-        ty, bm, bn, rest = m.group(1), m.group(2), m.group(3), m.group(4)
-        a_g = re.search(r"RowkFastI\w+Li\d+ELb1E", rest) is not None
-        kinds = re.findall(r"KrowTrILi\d+ELi(\d)E", rest)
-        if "KrowTr" in rest and "S2_" in rest and len(kinds) == 1:
-            kinds = kinds * 2
-    dt = "bf16" if ty in ("DF16b", "__bf16") else "fp32"
+        b = re.search(r"NS_\d+(RowkFast|KrowTr|KrowFast|RowkLoader|KrowLoader)I(?:DF16b|f)?(?:Li\d+E)?L([bi])(\d)", after)
+        if b:
+            b_kind, b_arg = b.group(1), b.group(3)
+        else:
+            b2 = re.search(r"NS1_I(?:DF16b|f)?(?:Li\d+E)?L([bi])(\d)", after)
+            b_kind, b_arg = a_kind, (b2.group(2) if b2 else "?")
     tile = f"cb_gemm {bm}x{bn} {dt}"
-    if "RowkFast" in rest and "KrowFast" in rest:
-        return f"{tile}: dgrad (register-transposed B)"
-    if "RowkFast" in rest and kinds:
-        return f"{tile}: dgrad {'3x3 conv (pixel gather x flipped taps)' if a_g else 'linear / 1x1'} (tr-read B)"
-    if len(kinds) == 2:
-        return f"{tile}: wgrad {'conv (pixel gather)' if kinds[1] == '2' else 'linear / 1x1 (+ bias row sums)'} (tr-read A, B)"
-    if "RowkFast" in rest:
-        return f"{tile}: fwd (register-staged)"
-    return f"{tile}: other"
+    if a_kind in ("RowkFast", "RowkLoader") and b_kind in ("RowkFast", "RowkLoader"):
+        return f"{tile}: fwd {'conv (pixel gather)' if a_arg == '1' else 'linear / 1x1 conv'}"
+    if a_kind in ("RowkFast", "RowkLoader"):
+        how = {"KrowTr": "tr-read B", "KrowFast": "register-transposed B", "KrowLoader": "guarded loads"}[b_kind]
+        return f"{tile}: dgrad {'3x3 conv (pixel gather x flipped taps)' if a_arg == '1' else 'linear / 1x1 conv'} ({how})"
+    how = {"KrowTr": "tr-read A, B", "KrowFast": "register-transposed", "KrowLoader": "guarded loads"}[a_kind]
+    return f"{tile}: wgrad {'conv (pixel gather)' if b_arg == '2' else 'linear / 1x1 conv (+ bias row sums)'} ({how})"
 
 
 def short(n):

@@ -56,6 +56,9 @@ _SIGNATURES = {
     "cb_act_bwd": [i32, i32, vp, vp, vp, i64, vp],
     "cb_adamw": [vp, vp, vp, vp, vp, i64, vp, vp, vp],
     "cb_dropout": [i32, vp, vp, i64, f32, u64, vp, vp],
+    "cb_clip_aggregate_fwd": [vp, i32, i64, i32, vp, vp, vp],
+    "cb_clip_aggregate_bwd": [vp, vp, vp, vp, i32, i64, i32, vp, vp],
+    "cb_lse_loss": [vp, vp, i32, i32, i32, vp, vp, vp, vp],
     "cb_sq_sum": [vp, i64, vp, vp],
 }
 

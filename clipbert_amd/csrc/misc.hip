@@ -124,9 +124,111 @@ __global__ void __launch_bounds__(256) dropout_kernel(const T* x, T* y, int64_t 
     }
 }
 
+// ---- clip aggregation (a20: run_video_retrieval.py:402-418 training, :664-682 inference) -------------------------
+// logits are clip-major [N][B*C] fp32 (the stack of the per-clip forward outputs); one thread per (pair, class).
+__global__ void __launch_bounds__(256) clip_agg_fwd_kernel(const float* x, int N, int64_t bc, int mode, float* out, int32_t* argmax) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= bc) return;
+    float m = x[i];
+    int am = 0;
+    for (int n = 1; n < N; ++n) {
+        const float v = x[(int64_t)n * bc + i];
+        if (v > m) { m = v; am = n; }
+    }
+    if (mode == CB_AGG_MEAN) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += x[(int64_t)n * bc + i];
+        out[i] = s / (float)N;
+    } else if (mode == CB_AGG_MAX) {
+        out[i] = m;
+        if (argmax) argmax[i] = am;
+    } else {                                   // log-sum-exp over the clips (max-shifted)
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += expf(x[(int64_t)n * bc + i] - m);
+        out[i] = m + logf(s);
+    }
+}
+
+__global__ void __launch_bounds__(256) clip_agg_bwd_kernel(const float* dout, const float* x, const float* out, const int32_t* argmax,
+                                                           int N, int64_t bc, int mode, float* dx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= bc) return;
+    const float g = dout[i];
+    for (int n = 0; n < N; ++n) {
+        float d;
+        if (mode == CB_AGG_MEAN) d = g / (float)N;
+        else if (mode == CB_AGG_MAX) d = argmax[i] == n ? g : 0.f;
+        else d = g * expf(x[(int64_t)n * bc + i] - out[i]);
+        dx[(int64_t)n * bc + i] = d;
+    }
+}
+
+// LSE training loss of one pair b: logsumexp over all (clip, class) - logsumexp over the clips of class label[b]
+// (run_video_retrieval.py:415-418); optional gradient dlogits = dloss[b] * (softmax_all - [c == label] softmax_clips).
+__global__ void __launch_bounds__(256) lse_loss_kernel(const float* x, const int64_t* labels, int N, int B, int C, float* loss,
+                                                       const float* dloss, float* dx) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const int64_t bc = (int64_t)B * C;
+    const int lab = (int)labels[b];
+    float ma = -3.0e38f, ml = -3.0e38f;
+    for (int n = 0; n < N; ++n)
+        for (int c = 0; c < C; ++c) {
+            const float v = x[(int64_t)n * bc + (int64_t)b * C + c];
+            ma = fmaxf(ma, v);
+            if (c == lab) ml = fmaxf(ml, v);
+        }
+    float sa = 0.f, sl = 0.f;
+    for (int n = 0; n < N; ++n)
+        for (int c = 0; c < C; ++c) {
+            const float v = x[(int64_t)n * bc + (int64_t)b * C + c];
+            sa += expf(v - ma);
+            if (c == lab) sl += expf(v - ml);
+        }
+    const float la = ma + logf(sa), ll = ml + logf(sl);
+    if (loss) loss[b] = la - ll;
+    if (dx) {
+        const float g = dloss ? dloss[b] : 1.0f;
+        for (int n = 0; n < N; ++n)
+            for (int c = 0; c < C; ++c) {
+                const int64_t idx = (int64_t)n * bc + (int64_t)b * C + c;
+                float d = expf(x[idx] - la);
+                if (c == lab) d -= expf(x[idx] - ll);
+                dx[idx] = g * d;
+            }
+    }
+}
+
 inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace
+
+extern "C" int cb_clip_aggregate_fwd(const float* logits, int32_t n_clips, int64_t bc, int32_t mode, float* out, int32_t* argmax,
+                                     void* stream) {
+    CB_REQUIRE(logits && out && n_clips > 0 && bc >= 0 && mode >= CB_AGG_MEAN && mode <= CB_AGG_LSE, "cb_clip_aggregate_fwd: bad arguments");
+    if (bc == 0) return 0;
+    hipLaunchKernelGGL(clip_agg_fwd_kernel, dim3(nblk(bc, 256)), dim3(256), 0, cb_stream(stream), logits, n_clips, bc, mode, out, argmax);
+    return cb_launch_status("cb_clip_aggregate_fwd");
+}
+
+extern "C" int cb_clip_aggregate_bwd(const float* dout, const float* logits, const float* out, const int32_t* argmax, int32_t n_clips,
+                                     int64_t bc, int32_t mode, float* dlogits, void* stream) {
+    CB_REQUIRE(dout && dlogits && n_clips > 0 && mode >= CB_AGG_MEAN && mode <= CB_AGG_LSE, "cb_clip_aggregate_bwd: bad arguments");
+    CB_REQUIRE(mode != CB_AGG_MAX || argmax, "cb_clip_aggregate_bwd: max needs the forward's argmax");
+    CB_REQUIRE(mode != CB_AGG_LSE || (logits && out), "cb_clip_aggregate_bwd: lse needs the forward's input and output");
+    if (bc == 0) return 0;
+    hipLaunchKernelGGL(clip_agg_bwd_kernel, dim3(nblk(bc, 256)), dim3(256), 0, cb_stream(stream), dout, logits, out, argmax, n_clips, bc,
+                       mode, dlogits);
+    return cb_launch_status("cb_clip_aggregate_bwd");
+}
+
+extern "C" int cb_lse_loss(const float* logits, const int64_t* labels, int32_t n_clips, int32_t B, int32_t C, float* loss,
+                           const float* dloss, float* dlogits, void* stream) {
+    CB_REQUIRE(logits && labels && n_clips > 0 && B >= 0 && C > 0 && (loss || dlogits), "cb_lse_loss: bad arguments");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(lse_loss_kernel, dim3(nblk(B, 256)), dim3(256), 0, cb_stream(stream), logits, labels, n_clips, B, C, loss, dloss, dlogits);
+    return cb_launch_status("cb_lse_loss");
+}
 
 extern "C" int cb_dropout(int32_t dtype, const void* x, void* y, int64_t n, float p, uint64_t seed, const uint64_t* seed_ptr,
                           void* stream) {

@@ -1131,13 +1131,24 @@ class ClipBert(nn.Module):
         if self.rt is None:
             self.prepare(device=device)
 
+    def grid_features(self, visual_inputs):
+        """(Bv, T, 3, H, W) frames -> (Bv, T, H', W', hidden) grid features: the CNN half of forward() on its own, so that
+        inference can compute each clip's features once and reuse them across text mini-batches (SURVEY 8f N1;
+        the reference recomputes them per mini-batch, run_video_retrieval.py:655-666)."""
+        self._ensure_prepared(visual_inputs.device)
+        return self.cnn(visual_inputs)
+
     def forward(self, batch):
+        vis = batch["visual_inputs"]
+        self._ensure_prepared(vis.device)
+        batch["visual_inputs"] = self.cnn(vis)
+        return self.forward_from_grid(batch)
+
+    def forward_from_grid(self, batch):
+        """forward() for a batch whose ``visual_inputs`` already are grid features (see grid_features)."""
         repeat_counts = batch["n_examples_list"]
         del batch["n_examples_list"]
         vis = batch["visual_inputs"]
-        self._ensure_prepared(vis.device)
-        visual_features = self.cnn(vis)
-        batch["visual_inputs"] = visual_features
         # repeat_tensor_rows (data_utils.py:344-357) is fused into the visual-embedding gather
         src_row = None
         if sum(repeat_counts) != len(repeat_counts):

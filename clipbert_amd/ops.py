@@ -303,3 +303,36 @@ def dropout(x, p, seed=0, seed_ptr=None, out=None):
     _chk(_lib.get().cb_dropout(dtype_code(x.dtype), _ptr(x), _ptr(y), x.numel(), p, seed, _ptr(seed_ptr), _stream(x)),
          "cb_dropout")
     return y
+
+
+AGG_MEAN, AGG_MAX, AGG_LSE = 0, 1, 2
+
+
+def clip_aggregate_fwd(stack: torch.Tensor, mode: int):
+    """stack: (n_clips, ...) fp32 contiguous -> (out (...), argmax int32 | None)."""
+    assert stack.dtype == torch.float32 and stack.is_contiguous()
+    n = stack.shape[0]
+    out = torch.empty(stack.shape[1:], dtype=torch.float32, device=stack.device)
+    am = torch.empty(stack.shape[1:], dtype=torch.int32, device=stack.device) if mode == AGG_MAX else None
+    _chk(_lib.get().cb_clip_aggregate_fwd(_ptr(stack), n, out.numel(), mode, _ptr(out), _ptr(am), _stream(stack)),
+         "cb_clip_aggregate_fwd")
+    return out, am
+
+
+def clip_aggregate_bwd(dout: torch.Tensor, stack, out, argmax, n_clips: int, mode: int):
+    dout = dout.contiguous()
+    dx = torch.empty((n_clips,) + tuple(dout.shape), dtype=torch.float32, device=dout.device)
+    _chk(_lib.get().cb_clip_aggregate_bwd(_ptr(dout), _ptr(stack), _ptr(out), _ptr(argmax), n_clips, dout.numel(), mode, _ptr(dx),
+                                          _stream(dout)), "cb_clip_aggregate_bwd")
+    return dx
+
+
+def lse_loss(stack: torch.Tensor, labels: torch.Tensor, want_loss=True, dloss=None, want_grad=False):
+    """stack: (n_clips, B, C) fp32 clip-major logits -> (loss (B,) | None, dlogits like stack | None)."""
+    assert stack.dtype == torch.float32 and stack.is_contiguous() and stack.dim() == 3
+    n, b, c = stack.shape
+    loss = torch.empty(b, dtype=torch.float32, device=stack.device) if want_loss else None
+    dx = torch.empty_like(stack) if want_grad else None
+    _chk(_lib.get().cb_lse_loss(_ptr(stack), _ptr(labels.contiguous()), n, b, c, _ptr(loss), _ptr(dloss), _ptr(dx), _stream(stack)),
+         "cb_lse_loss")
+    return loss, dx

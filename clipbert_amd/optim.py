@@ -22,8 +22,18 @@ def warmup_linear(step: int, warmup_step: int, tot_step: int) -> float:
     return max(0, (tot_step - step) / (tot_step - warmup_step))
 
 
-def get_lr_sched(global_step: int, decay: str, learning_rate: float, num_train_steps: int, warmup_ratio: float = 0.1) -> float:
-    """src/optimization/sched.py:28-47 ('linear' | 'constant' | 'invsqrt'); floored to 1e-8."""
+def multi_step_schedule(n_epoch: int, milestones, gamma: float = 0.5) -> float:
+    """src/optimization/sched.py:20-25: gamma**i before the i-th (sorted) milestone, gamma**(len+1) after the last one."""
+    ms = sorted(milestones)
+    for i, m in enumerate(ms):
+        if n_epoch < m:
+            return gamma ** i
+    return gamma ** (len(ms) + 1)
+
+
+def get_lr_sched(global_step: int, decay: str, learning_rate: float, num_train_steps: int, warmup_ratio: float = 0.1,
+                 decay_epochs=(), multi_step_epoch: int = -1) -> float:
+    """src/optimization/sched.py:28-47 ('linear' | 'invsqrt' | 'constant' | 'multi_step'); floored to 1e-8."""
     warmup_steps = int(warmup_ratio * num_train_steps)
     if decay == "linear":
         lr = learning_rate * warmup_linear(global_step, warmup_steps, num_train_steps)
@@ -32,6 +42,9 @@ def get_lr_sched(global_step: int, decay: str, learning_rate: float, num_train_s
                               else (warmup_steps ** 0.5) * (global_step ** -0.5))
     elif decay == "constant":
         lr = learning_rate
+    elif decay == "multi_step":
+        assert multi_step_epoch >= 0
+        lr = learning_rate * multi_step_schedule(multi_step_epoch, decay_epochs)
     else:
         raise ValueError(f"unsupported decay {decay}")
     return lr if lr > 0 else 1e-8

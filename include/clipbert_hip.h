@@ -219,6 +219,21 @@ enum { CB_HP_LR = 0, CB_HP_BETA1, CB_HP_BETA2, CB_HP_EPS, CB_HP_WD, CB_HP_BC1, C
 /* y = x * inverted-dropout mask(seed + *seed_ptr, index)  (forward and backward of nn.Dropout). */
 int cb_dropout(int32_t dtype, const void* x, void* y, int64_t n, float p, uint64_t seed,
                const uint64_t* seed_ptr, void* stream);
+
+/* Clip aggregation of the per-clip logits (the stack [n_clips][B*C], fp32) -- the reference does it with torch ops in its
+ * task loops: training src/tasks/run_video_retrieval.py:402-411 (mean / max; "lse" is pooled inside the loss below),
+ * inference :669-676 (mean / max / logsumexp over clips), src/tasks/run_video_qa.py:241-275 likewise.
+ * `argmax` (int32 [B*C]) is written for CB_AGG_MAX and consumed by the backward. */
+enum { CB_AGG_MEAN = 0, CB_AGG_MAX = 1, CB_AGG_LSE = 2 };
+int cb_clip_aggregate_fwd(const float* logits, int32_t n_clips, int64_t bc, int32_t mode, float* out, int32_t* argmax,
+                          void* stream);
+int cb_clip_aggregate_bwd(const float* dout, const float* logits, const float* out, const int32_t* argmax, int32_t n_clips,
+                          int64_t bc, int32_t mode, float* dlogits, void* stream);
+
+/* LSE training loss (run_video_retrieval.py:415-418): loss[b] = logsumexp_{clip,class} - logsumexp_{clip}(class = labels[b]) on
+ * clip-major logits [n_clips][B][C]; `dlogits` (optional) receives dloss[b] (1 if null) times its gradient. */
+int cb_lse_loss(const float* logits, const int64_t* labels, int32_t n_clips, int32_t B, int32_t C, float* loss, const float* dloss,
+                float* dlogits, void* stream);
 int cb_sq_sum(const float* g, int64_t n, float* out_accum, void* stream);
 
 const char* cb_last_error(void);

@@ -1,0 +1,109 @@
+"""Task-loop pieces: feature-cached retrieval inference == the reference's order of evaluation, the
+training step over clips with each pooling method == the oracle's composition, metrics == their definition."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from clipbert_amd import optim, tasks
+from clipbert_amd import synthetic as S
+from oracle import clipbert_oracle as O
+from test_model_small import build, to_dev
+
+RET = dict(num_labels=2, loss_type="ce", margin=0.1)
+
+
+def _frames(n_videos, n_frames, seed):
+    f = S.synthetic_frames(n_videos, n_frames, 64, seed)[..., :64, :].repeat(1, 1, 1, 1, 2).contiguous()   # (Bv, n, 3, 64, 128)
+    return O.image_norm(f, S.PIXEL_MEAN, S.PIXEL_STD)
+
+
+@pytest.mark.parametrize("pool", ["max", "lse"])
+def test_cached_inference_equals_per_clip_loop(hw, pool):
+    cfg, sd, model = build("retrieval", RET, torch.float32, hw.dev)
+    model.eval()
+    icfg = SimpleNamespace(inference_n_clips=2, num_frm=2, score_agg_func=pool, inference_batch_size=2)
+    vis = hw(_frames(1, 4, 11))
+    ids, mask = S.synthetic_text(3, 6, 11, cfg["vocab_size"])
+    ids = hw(ids.clamp(max=cfg["vocab_size"] - 1))
+    mask = hw(mask)
+    fast = tasks.inference_retrieval_video(model, vis, ids, mask, icfg, cache_cnn=True)
+    slow = tasks.inference_retrieval_video(model, vis, ids, mask, icfg, cache_cnn=False)
+    assert len(fast) == len(slow) == 3
+    assert max(abs(a - b) for a, b in zip(fast, slow)) <= 1.01e-4
+    # and both equal the oracle's composition of the reference loop (run_video_retrieval.py:655-690)
+    per_clip = []
+    visc = vis.cpu().view(2, 2, *vis.shape[2:])
+    for c in range(2):
+        batch = dict(visual_inputs=visc[c:c + 1], text_input_ids=ids.cpu(), text_input_mask=mask.cpu(), n_examples_list=[3])
+        with torch.no_grad():
+            per_clip.append(O.clipbert_forward(sd, batch, cfg, "retrieval")["logits"])
+    pooled = O.aggregate_clip_logits(per_clip, pool)
+    if pool == "lse":
+        pooled = torch.logsumexp(pooled, dim=1)
+    ref = [round(s, 4) for s in torch.softmax(pooled, dim=1)[:, 1].tolist()]
+    tol = 2e-4 if hw.name == "emul" else 2e-3
+    assert max(abs(a - b) for a, b in zip(fast, ref)) <= tol
+
+
+@pytest.mark.parametrize("pool", ["lse"])
+def test_train_step_over_clips(hw, pool):
+    cfg, sd, model = build("retrieval", RET, torch.float32, hw.dev)
+    model.eval()                                            # dropout off: the loss is comparable with the oracle
+    opt = optim.FusedAdamW(model.rt.bank, lr=1e-3, betas=(0.9, 0.98), weight_decay=1e-3, cnn_lr=1e-3, max_grad_norm=5.0)
+    tcfg = SimpleNamespace(train_n_clips=2, num_frm=2, score_agg_func=pool, learning_rate=1e-3, cnn_learning_rate=1e-3, decay="linear",
+                           cnn_lr_decay="multi_step", cnn_step_decay_epochs=[2, 4], num_train_steps=10, warmup_ratio=0.1,
+                           transformer_lr_mul=2.0, cnn_lr_mul=3.0)
+    vis = _frames(2, 4, 5)
+    ids, mask = S.synthetic_text(4, 6, 5, cfg["vocab_size"])
+    ids = ids.clamp(max=cfg["vocab_size"] - 1)
+    labels = torch.tensor([1, 0, 1, 0])
+    batch = to_dev(dict(visual_inputs=vis, text_input_ids=ids, text_input_mask=mask, labels=labels, n_examples_list=[2, 2]), hw.dev)
+    # oracle composition of the same loop
+    per_clip = []
+    v = vis.view(2, 2, 2, *vis.shape[2:])
+    for c in range(2):
+        b = dict(visual_inputs=v[:, c], text_input_ids=ids, text_input_mask=mask, labels=labels, n_examples_list=[2, 2])
+        with torch.no_grad():
+            per_clip.append(O.clipbert_forward(sd, b, cfg, "retrieval")["logits"])
+    pooled = O.aggregate_clip_logits(per_clip, pool)
+    ref = O.lse_train_loss(pooled, labels).mean() if pool == "lse" else torch.nn.functional.cross_entropy(pooled, labels)
+    p0 = next(p for n, p in model.named_parameters() if n.endswith("pooler.dense.weight"))
+    w_before = p0.detach().float().cpu().clone()
+    loss = tasks.train_step(model, opt, batch, tcfg, global_step=0, n_epoch=3)
+    torch.testing.assert_close(loss.cpu(), ref, rtol=2e-3, atol=2e-4)
+    lrs = [pg["lr"] for pg in opt.param_groups]
+    lr_t = optim.get_lr_sched(1, "linear", 1e-3, 10, 0.1)
+    lr_c = 1e-3 * 0.5                                       # epoch 3: one milestone (2) passed
+    assert lrs[0] == pytest.approx(2.0 * lr_t) and lrs[2] == pytest.approx(lr_t)
+    assert lrs[4] == pytest.approx(3.0 * lr_c) and lrs[6] == pytest.approx(lr_c)
+    assert (p0.detach().float().cpu() - w_before).abs().max() > 0          # the step moved the weights
+
+
+def test_multi_step_schedule():
+    assert optim.multi_step_schedule(0, [2, 4]) == 1.0
+    assert optim.multi_step_schedule(2, [4, 2]) == 0.5
+    assert optim.multi_step_schedule(9, [2, 4]) == 0.5 ** 3          # the reference's gamma**(len+1) after the last milestone
+
+
+def test_retrieval_metrics_definition():
+    rng = np.random.default_rng(0)
+    n_txt, n_vid = 40, 25
+    sm = rng.random((n_txt, n_vid)).astype(np.float32)
+    gt = rng.integers(0, n_vid, n_txt)
+    got = tasks.retrieval_metrics_from_scores(sm, gt)
+    ranks = np.array([1 + int((sm[i] > sm[i, gt[i]]).sum()) for i in range(n_txt)])      # no ties in random floats
+    assert got["r1"] == pytest.approx(100.0 * (ranks <= 1).mean())
+    assert got["r5"] == pytest.approx(100.0 * (ranks <= 5).mean())
+    assert got["r10"] == pytest.approx(100.0 * (ranks <= 10).mean())
+    assert got["medianR"] == pytest.approx(float(np.median(ranks))) and got["meanR"] == pytest.approx(float(ranks.mean()))
+    # eval_retrieval: one caption per video, ids as strings, a duplicated row must be ignored
+    n = 12
+    sm2 = rng.random((n, n)).astype(np.float32)
+    rows = [dict(vid_id=f"v{j}", txt_id=f"t{i}", score=float(sm2[i, j])) for i in range(n) for j in range(n)]
+    rows.append(dict(vid_id="v0", txt_id="t0", score=123.0))
+    res = tasks.eval_retrieval(rows, {f"t{i}": f"v{i}" for i in range(n)})
+    assert res["text2video"] == tasks.retrieval_metrics_from_scores(sm2, list(range(n)))
+    assert res["video2text"] == tasks.retrieval_metrics_from_scores(sm2.T, list(range(n)))
+    assert tasks.qa_accuracy([1, 2, 3, 0], [1, 2, 0, 0]) == 75.0

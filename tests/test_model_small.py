@@ -121,3 +121,22 @@ def test_bf16_mode_close(hw):
         out = model(to_dev(batch, hw.dev))
     assert (out["logits"].cpu() - ref["logits"]).abs().max() < 5e-2
     assert (out["loss"].cpu() - ref["loss"]).abs().max() < 5e-2
+
+
+def test_ragged_examples_and_long_sequence(hw):
+    """n_examples_list with different counts per video (repeat_tensor_rows, data_utils.py:344-357, fused into the visual
+    embedding gather) and a text long enough that L > 64 (generic attention kernels instead of the one-block MFMA ones)."""
+    cfg, sd, model = build("retrieval", dict(num_labels=2, loss_type="ce", margin=0.1, max_position_embeddings=80), torch.float32, hw.dev)
+    frames = S.synthetic_frames(3, 2, 64, 9)[..., :64, :].repeat(1, 1, 1, 1, 2).contiguous()
+    counts = [1, 3, 2]
+    for lt in (5, 70):
+        ids, mask = S.synthetic_text(sum(counts), lt, 9, cfg["vocab_size"])
+        ids = ids.clamp(max=cfg["vocab_size"] - 1)
+        batch = dict(visual_inputs=O.image_norm(frames, S.PIXEL_MEAN, S.PIXEL_STD), text_input_ids=ids, text_input_mask=mask,
+                     n_examples_list=list(counts), labels=S.synthetic_labels(sum(counts), 2, 9))
+        with torch.no_grad():
+            ref = O.clipbert_forward(sd, dict(batch, n_examples_list=list(counts)), cfg, "retrieval")
+            out = model(to_dev(dict(batch, n_examples_list=list(counts)), hw.dev))
+        tol = dict(rtol=1e-3, atol=1e-4) if hw.name == "emul" else dict(rtol=2e-3, atol=1e-3)
+        torch.testing.assert_close(out["logits"].cpu(), ref["logits"], **tol)
+        torch.testing.assert_close(out["loss"].cpu(), ref["loss"], **tol)

@@ -69,11 +69,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    # test hooks (never set by the driver): run the N > 1 control flow on a 1-GPU box -- all ranks on GPU 0, gloo collectives
+    if os.environ.get("CB_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("CB_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -93,7 +100,7 @@ def main():
     model.prepare(dtype=torch.bfloat16, device=dev, overlap_wgrad=os.environ.get("CB_OVERLAP_WGRAD", "0") != "0")
     log("model prepared")
     bank = model.rt.bank
-    sync = GradSync(bank)
+    sync = GradSync(bank, compress=None if os.environ.get("CB_BENCH_FP32_WIRE") == "1" else "bf16")
     sync.broadcast_parameters(0)
     opt = FusedAdamW(bank, lr=5e-5, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0)
     model.rt.after_encoder_backward = sync.reduce_transformer
@@ -143,19 +150,50 @@ def main():
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
     log(f"eager warm-up done, loss {float(loss.item()):.4f}")
-    graph = None
-    if not args.no_graph:
-        try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                loss = step_fn()
-        except Exception as e:                                    # keep the bench alive: eager launches are still valid
-            if rank == 0:
-                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
-    run = graph.replay if graph is not None else step_fn
-    log(f"graph captured: {graph is not None}")
+    # ---- replay plan -----------------------------------------------------------------------------------------------------
+    #   N = 1          : the whole step in one hipGraph.
+    #   N > 1 (default): two hipGraphs around EAGER RCCL all-reduces: [zero + forward + backward] -> all-reduce (bf16 on the
+    #                    wire) -> [clip + AdamW].  Only this library's kernels are ever captured -- a capture that fails on
+    #                    this stack cannot be recovered from inside the process, so collectives stay out of it.
+    #   CB_BENCH_PLAN=full : N > 1 with the whole step (RCCL calls included) in one hipGraph; the transformer bucket is then
+    #                    issued from inside the backward and overlaps the ResNet backward.  Opt-in until it can be tested
+    #                    on a multi-GPU box.   CB_BENCH_PLAN=eager / --no-graph: no graphs.
+    def capture(fn):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = fn()
+        return g, out
+
+    plan_env = os.environ.get("CB_BENCH_PLAN", "")
+    run, plan = step_fn, "eager"
+    if not args.no_graph and plan_env != "eager":
+        if world == 1 or args.forward_only or plan_env == "full":
+            g1, loss = capture(step_fn)
+            run, plan = g1.replay, "one hipGraph"
+        else:
+            def compute_part():
+                opt.zero_grad()
+                loss_ = forward_loss()
+                loss_.backward()
+                return loss_
+
+            def update_part():
+                model.rt.seed_dev.add_(1)
+                opt.step(grad_scale=sync.grad_scale)
+
+            model.rt.after_encoder_backward = None                 # no collective inside the captured backward
+            ga, loss = capture(compute_part)
+            gb, _ = capture(update_part)
+
+            def run_split():
+                ga.replay()
+                sync.reduce_transformer()
+                sync.reduce_cnn()
+                sync.wait()
+                gb.replay()
+            run, plan = run_split, "two hipGraphs around eager all-reduces"
+    graph = None if plan == "eager" else True
+    log(f"replay plan: {plan}")
 
     for _ in range(args.warmup):
         run()
@@ -187,7 +225,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: MSRVTT retrieval training step (fwd+bwd+allreduce+clip+AdamW), "
                                f"{bv} videos x {nclip} clip x {T} frames {args.size}px + {args.repeat} texts L_txt={args.txt_len} per GPU",
                    "videos_per_gpu": bv, "n_clips": nclip, "n_frames": T, "img_size": args.size, "txt_len": args.txt_len,
-                   "texts_per_video": args.repeat, "parallelism": f"dp{world}", "hip_graph": graph is not None,
+                   "texts_per_video": args.repeat, "parallelism": f"dp{world}", "hip_graph": graph is not None, "replay_plan": plan,
                    "dropout": not args.forward_only, "final_loss": round(final_loss, 5)},
     }
     if rank == 0 and world == 1 and not args.no_roofline:

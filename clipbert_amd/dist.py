@@ -20,7 +20,12 @@ from .params import ParamBank
 
 
 class GradSync:
-    def __init__(self, bank: ParamBank, group=None, bucket_bytes: int = 0):
+    """``compress="bf16"`` sends the gradients as bf16 (half the xGMI payload: 297 MB instead of 594 MB per step; the
+    reference's apex-O2 gradients are fp16 on the wire too): cast -> all-reduce -> cast back, three passes over the flat
+    buffer (~0.3 ms) against ~1.5 ms of link time saved on 8 GPUs."""
+
+    def __init__(self, bank: ParamBank, group=None, bucket_bytes: int = 0, compress: Optional[str] = None):
+        assert compress in (None, "bf16")
         self.bank = bank
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -28,7 +33,10 @@ class GradSync:
         self.t_range = (0, t_end)
         self.c_range = (t_end, bank.n_train)
         self.bucket_elems = bucket_bytes // 4 if bucket_bytes > 0 else 0
+        self.compress = compress
+        self._wire = None
         self._work: List = []
+        self._pending: List = []            # (start, end) ranges whose bf16 wire image must be cast back after wait()
 
     @property
     def grad_scale(self) -> float:
@@ -40,7 +48,18 @@ class GradSync:
         step = self.bucket_elems if self.bucket_elems > 0 else (b - a)
         for s in range(a, b, step):
             e = min(b, s + step)
-            self._work.append(dist.all_reduce(self.bank.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.compress == "bf16":
+                from . import ops
+                if self._wire is None:
+                    self._wire = torch.empty(self.bank.n_train, dtype=torch.bfloat16, device=self.bank.grad.device)
+                if self.bank.grad.is_cuda:
+                    ops.cast(self.bank.grad[s:e], self._wire[s:e])
+                else:                                              # gloo / CPU tests
+                    self._wire[s:e].copy_(self.bank.grad[s:e])
+                self._work.append(dist.all_reduce(self._wire[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._pending.append((s, e))
+            else:
+                self._work.append(dist.all_reduce(self.bank.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def reduce_transformer(self):
         self._reduce(*self.t_range)
@@ -52,6 +71,13 @@ class GradSync:
         for w in self._work:
             w.wait()
         self._work = []
+        for s, e in self._pending:
+            if self.bank.grad.is_cuda:
+                from . import ops
+                ops.cast(self._wire[s:e], self.bank.grad[s:e])
+            else:
+                self.bank.grad[s:e].copy_(self._wire[s:e])
+        self._pending = []
 
     def broadcast_parameters(self, src: int = 0):
         """hvd.broadcast_parameters equivalent (run_video_retrieval.py:304): one flat buffer per kind."""

@@ -152,9 +152,10 @@ def main():
     log(f"eager warm-up done, loss {float(loss.item()):.4f}")
     # ---- replay plan -----------------------------------------------------------------------------------------------------
     #   N = 1          : the whole step in one hipGraph.
-    #   N > 1 (default): two hipGraphs around EAGER RCCL all-reduces: [zero + forward + backward] -> all-reduce (bf16 on the
-    #                    wire) -> [clip + AdamW].  Only this library's kernels are ever captured -- a capture that fails on
-    #                    this stack cannot be recovered from inside the process, so collectives stay out of it.
+    #   N > 1 (default): three hipGraphs with EAGER RCCL all-reduces (bf16 on the wire) between them; the transformer bucket
+    #                    travels while the ResNet-backward graph runs.  Only this library's kernels are ever captured -- a
+    #                    capture that fails on this stack cannot be recovered from inside the process, so collectives stay
+    #                    out of it.
     #   CB_BENCH_PLAN=full : N > 1 with the whole step (RCCL calls included) in one hipGraph; the transformer bucket is then
     #                    issued from inside the backward and overlaps the ResNet backward.  Opt-in until it can be tested
     #                    on a multi-GPU box.   CB_BENCH_PLAN=eager / --no-graph: no graphs.
@@ -171,27 +172,44 @@ def main():
             g1, loss = capture(step_fn)
             run, plan = g1.replay, "one hipGraph"
         else:
-            def compute_part():
+            # [zero + forward + encoder backward] -> transformer bucket (async, crosses xGMI during the next graph) ->
+            # [ResNet backward] -> CNN bucket -> wait -> [clip + AdamW].  The backward is cut at the grid features:
+            # autograd.grad(loss, grid) runs the heads' and the encoder's backward (parameter gradients land in the flat
+            # buffer as a side effect), grid.backward(dgrid) runs the CNN trunk's.
+            assert nclip == 1, "the split replay plan handles one clip per step (the headline config)"
+            state = {}
+
+            def part_a():
                 opt.zero_grad()
-                loss_ = forward_loss()
-                loss_.backward()
+                grid = model.grid_features(vis_clips[:, 0])
+                out = model.forward_from_grid(dict(visual_inputs=grid, text_input_ids=ids, text_input_mask=mask,
+                                                   n_examples_list=list(counts)))
+                _, l = model.transformer.calc_loss(out["logits"], labels, sample_size=bv)
+                loss_ = l.mean()
+                (dgrid,) = torch.autograd.grad(loss_, [grid])
+                state["grid"], state["dgrid"] = grid, dgrid
                 return loss_
 
-            def update_part():
+            def part_b():
+                state["grid"].backward(state["dgrid"])
+
+            def part_c():
                 model.rt.seed_dev.add_(1)
                 opt.step(grad_scale=sync.grad_scale)
 
-            model.rt.after_encoder_backward = None                 # no collective inside the captured backward
-            ga, loss = capture(compute_part)
-            gb, _ = capture(update_part)
+            model.rt.after_encoder_backward = None                 # collectives are issued between the graphs, eagerly
+            ga, loss = capture(part_a)
+            gb, _ = capture(part_b)
+            gc, _ = capture(part_c)
 
             def run_split():
                 ga.replay()
                 sync.reduce_transformer()
+                gb.replay()
                 sync.reduce_cnn()
                 sync.wait()
-                gb.replay()
-            run, plan = run_split, "two hipGraphs around eager all-reduces"
+                gc.replay()
+            run, plan = run_split, "three hipGraphs, eager bf16 all-reduces (transformer bucket overlaps the ResNet backward)"
     graph = None if plan == "eager" else True
     log(f"replay plan: {plan}")
 

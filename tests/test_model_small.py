@@ -140,3 +140,27 @@ def test_ragged_examples_and_long_sequence(hw):
         tol = dict(rtol=1e-3, atol=1e-4) if hw.name == "emul" else dict(rtol=2e-3, atol=1e-3)
         torch.testing.assert_close(out["logits"].cpu(), ref["logits"], **tol)
         torch.testing.assert_close(out["loss"].cpu(), ref["loss"], **tol)
+
+
+def test_backward_cut_at_grid_features(hw):
+    """The DP replay plan of bench.py cuts the backward at the grid features (autograd.grad to the grid, then
+    grid.backward): same gradients as one loss.backward()."""
+    cfg, sd, model = build("retrieval", dict(num_labels=2, loss_type="ce", margin=0.1), torch.float32, hw.dev)
+    batch = make_batch(cfg, "retrieval", 2, 2, 6)
+    batch["labels"] = S.synthetic_labels(4, 2, 5)
+    bank = model.rt.bank
+    bank.zero_grad()
+    out = model(to_dev(dict(batch, n_examples_list=[2, 2]), hw.dev))
+    out["loss"].mean().backward()
+    ref = bank.grad.clone()
+    bank.zero_grad()
+    b = to_dev(dict(batch, n_examples_list=[2, 2]), hw.dev)
+    grid = model.grid_features(b["visual_inputs"])
+    b["visual_inputs"] = grid
+    out = model.forward_from_grid(b)
+    (dgrid,) = torch.autograd.grad(out["loss"].mean(), [grid])
+    enc_only = bank.grad.clone()
+    grid.backward(dgrid)
+    torch.testing.assert_close(bank.grad, ref, rtol=1e-5, atol=1e-7)
+    t_end = bank.group_range[3][1]
+    assert enc_only[t_end:].abs().max() == 0 and (bank.grad[t_end:].abs().max() > 0)      # the CNN part came from phase two

@@ -236,7 +236,7 @@ def main():
     log(f"timed region done: {ms_per_step:.3f} ms/step, {value:.1f} clips/s")
 
     out = {
-        "metric": "clips/sec/node (2x2 frames, 224px, L_txt=32)" if not args.forward_only else "clips/sec/node forward-only (diagnostic)",
+        "metric": "clips/sec/node (2\u00d72 frames, 224px, L_txt=32) at 1/2/4/8 MI355X" if not args.forward_only else "clips/sec/node forward-only (diagnostic)",
         "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",

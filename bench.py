@@ -85,6 +85,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    from clipbert_amd import clips
     from clipbert_amd import modeling as M
     from clipbert_amd import ops
     from clipbert_amd import synthetic as S
@@ -120,7 +121,7 @@ def main():
             batch = dict(visual_inputs=vis_clips[:, c].contiguous() if nclip > 1 else vis_clips[:, 0], text_input_ids=ids,
                          text_input_mask=mask, n_examples_list=list(counts))
             logits.append(model(batch)["logits"])
-        lg = logits[0] if nclip == 1 else torch.stack(logits).mean(0)
+        lg = logits[0] if nclip == 1 else clips.aggregate_clip_logits(logits, "mean")     # score_agg_func of the JSON config
         _, loss = model.transformer.calc_loss(lg, labels, sample_size=bv)
         return loss.mean()
 

@@ -164,3 +164,18 @@ def test_backward_cut_at_grid_features(hw):
     torch.testing.assert_close(bank.grad, ref, rtol=1e-5, atol=1e-7)
     t_end = bank.group_range[3][1]
     assert enc_only[t_end:].abs().max() == 0 and (bank.grad[t_end:].abs().max() > 0)      # the CNN part came from phase two
+
+
+def test_uint8_frames_equal_prenormalised_input(hw):
+    """SURVEY 8f N4 (first step): raw uint8 RGB frames go straight into the stem pack kernel, which fuses ImageNorm
+    (data_utils.py:266-276), the BGR flip and the NHWC pack -- same logits as the fp32 mean-subtracted input."""
+    cfg, sd, model = build("retrieval", dict(num_labels=2, loss_type="ce", margin=0.1), torch.float32, hw.dev)
+    frames = S.synthetic_frames(2, 2, 64, 13)[..., :64, :].repeat(1, 1, 1, 1, 2).contiguous()        # uint8
+    assert frames.dtype == torch.uint8
+    ids, mask = S.synthetic_text(2, 6, 13, cfg["vocab_size"])
+    ids = ids.clamp(max=cfg["vocab_size"] - 1)
+    common = dict(text_input_ids=ids, text_input_mask=mask, labels=None)
+    with torch.no_grad():
+        a = model(to_dev(dict(common, visual_inputs=frames, n_examples_list=[1, 1]), hw.dev))["logits"]
+        b = model(to_dev(dict(common, visual_inputs=O.image_norm(frames, S.PIXEL_MEAN, S.PIXEL_STD), n_examples_list=[1, 1]), hw.dev))["logits"]
+    torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)

@@ -179,3 +179,40 @@ def test_uint8_frames_equal_prenormalised_input(hw):
         a = model(to_dev(dict(common, visual_inputs=frames, n_examples_list=[1, 1]), hw.dev))["logits"]
         b = model(to_dev(dict(common, visual_inputs=O.image_norm(frames, S.PIXEL_MEAN, S.PIXEL_STD), n_examples_list=[1, 1]), hw.dev))["logits"]
     torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_pretraining_pixel_random_sampling_train_mode(hw):
+    """Pixel-BERT style random sub-sampling of the visual tokens (modeling.py:15-34,80-88): training mode only, indices
+    from numpy's global RNG exactly as the reference draws them; forward AND gradients against the oracle."""
+    import numpy as np
+    extra = dict(pixel_random_sampling_size=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    cfg, sd, model = build("pretraining", extra, torch.float32, hw.dev)
+    model.train()
+    batch = make_batch(cfg, "pretraining", 2, 1, 6)
+    mlm = batch["text_input_ids"].clone()
+    mlm[:, ::2] = -100
+    batch["mlm_labels"] = mlm
+    batch["itm_labels"] = S.synthetic_labels(2, 2, 5)
+    sdr = {k: v.clone().requires_grad_(v.is_floating_point() and "norm" not in k) for k, v in sd.items()}
+    sdr["transformer.cls.predictions.decoder.weight"] = sdr["transformer.bert.embeddings.word_embeddings.weight"]
+    sdr["transformer.cls.predictions.decoder.bias"] = sdr["transformer.cls.predictions.bias"]
+    grid = O.grid_feat_backbone(sdr, batch["visual_inputs"], "cnn.")
+    lv = grid.shape[2] * grid.shape[3]
+    assert lv == 2
+    np.random.seed(7)
+    idx = torch.from_numpy(np.sort(np.random.choice(lv, size=1, replace=False))).long()
+    ref = O.pretraining_forward(sdr, batch["text_input_ids"], grid, batch["text_input_mask"], cfg, mlm, batch["itm_labels"], sample_idx=idx)
+    (ref["mlm_loss"].mean() + ref["itm_loss"].mean()).backward()
+    np.random.seed(7)                                     # the product draws from the same global RNG
+    model.rt.bank.zero_grad()
+    out = model(to_dev(dict(batch, n_examples_list=[1, 1]), hw.dev))
+    tol = dict(rtol=1e-3, atol=1e-4) if hw.name == "emul" else dict(rtol=2e-3, atol=1e-3)
+    torch.testing.assert_close(out["itm_scores"].cpu(), ref["itm_scores"].detach(), **tol)
+    torch.testing.assert_close(out["mlm_loss"].cpu(), ref["mlm_loss"].detach(), **tol)
+    (out["mlm_loss"].mean() + out["itm_loss"].mean()).backward()
+    for name in ("transformer.bert.visual_embeddings.row_position_embeddings.weight", "cnn.grid_encoder.0.weight",
+                 "transformer.bert.encoder.layer.0.attention.self.query.weight"):
+        p = dict(model.named_parameters())[name]
+        g_ref = sdr[name].grad
+        diff = (p.grad.cpu() - g_ref).norm() / max(g_ref.norm().item(), 1e-8)
+        assert diff < (2e-3 if hw.name == "emul" else 5e-3), (name, float(diff))

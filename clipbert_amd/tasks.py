@@ -40,8 +40,10 @@ def training_loss(model, logits: List[torch.Tensor], labels, n_examples_list, po
     pooled = clips.aggregate_clip_logits(logits, pool_method)
     if pool_method == "lse":
         loss = clips.lse_train_loss(pooled, labels)
-    else:
+    elif getattr(model, "retrieval", False):
         _, loss = model.transformer.calc_loss(pooled, labels, sample_size=len(n_examples_list))
+    else:                                                   # QA heads (run_video_qa.py:417-419)
+        _, loss = model.transformer.calc_loss(pooled, labels)
     return loss.mean()
 
 
@@ -119,6 +121,21 @@ def inference_retrieval_video(model, visual_inputs: torch.Tensor, text_input_ids
             pooled = clips.lse_inference_logits(pooled)
         scores.extend(clips.retrieval_scores(pooled))
     return scores
+
+
+# ---- video QA inference (run_video_qa.py:216-300) ------------------------------------------------------------------------
+@torch.no_grad()
+def qa_predict(model, batch: Dict, cfg) -> List[int]:
+    """Predicted answer ids of one batch: clip loop over inference_n_clips, pooling, then argmax (classification tasks
+    action / transition / frameqa / msrvtt_qa) or round-and-clamp to 1..10 (the regression task "count")."""
+    logits = forward_clips(model, dict(batch, labels=None), _get(cfg, "inference_n_clips", 1), _get(cfg, "num_frm"))
+    pool = _get(cfg, "score_agg_func", "mean")
+    pooled = clips.aggregate_clip_logits(logits, pool)
+    if pool == "lse":
+        pooled = clips.lse_inference_logits(pooled)
+    if _get(cfg, "task", "action") in ("action", "transition", "frameqa", "msrvtt_qa"):
+        return pooled.max(dim=-1)[1].tolist()
+    return (pooled + 0.5).long().clamp(min=1, max=10).reshape(-1).tolist()
 
 
 # ---- metrics (:519-625) ------------------------------------------------------------------------------------------------

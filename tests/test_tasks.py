@@ -107,3 +107,25 @@ def test_retrieval_metrics_definition():
     assert res["text2video"] == tasks.retrieval_metrics_from_scores(sm2, list(range(n)))
     assert res["video2text"] == tasks.retrieval_metrics_from_scores(sm2.T, list(range(n)))
     assert tasks.qa_accuracy([1, 2, 3, 0], [1, 2, 0, 0]) == 75.0
+
+
+def test_qa_predict_multiple_choice(hw):
+    """TGIF-QA action style: 5 candidate answers per video, 2 clips, mean pooling; answer id = argmax (config 4)."""
+    cfg, sd, model = build("multiple_choice", dict(num_labels=5, loss_type="ce"), torch.float32, hw.dev)
+    model.eval()
+    qcfg = SimpleNamespace(inference_n_clips=2, num_frm=2, score_agg_func="mean", task="action")
+    vis = _frames(2, 4, 21)
+    ids, mask = S.synthetic_text(10, 6, 21, cfg["vocab_size"])
+    ids = ids.clamp(max=cfg["vocab_size"] - 1)
+    batch = dict(visual_inputs=vis, text_input_ids=ids, text_input_mask=mask, n_examples_list=[5, 5])
+    pred = tasks.qa_predict(model, to_dev(batch, hw.dev), qcfg)
+    v = vis.view(2, 2, 2, *vis.shape[2:])
+    per_clip = []
+    for c in range(2):
+        with torch.no_grad():
+            per_clip.append(O.clipbert_forward(sd, dict(visual_inputs=v[:, c], text_input_ids=ids, text_input_mask=mask, n_examples_list=[5, 5]),
+                                               cfg, "multiple_choice")["logits"])
+    ref = O.aggregate_clip_logits(per_clip, "mean")
+    assert tuple(ref.shape) == (2, 5)
+    assert pred == ref.max(dim=-1)[1].tolist()                # argmax-exact answer ids
+    assert tasks.qa_accuracy(pred, pred) == 100.0

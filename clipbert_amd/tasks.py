@@ -69,20 +69,35 @@ def set_learning_rates(optimizer, cfg, global_step: int, n_epoch: int = 0):
     return lr_t, lr_c
 
 
-def train_step(model, optimizer, batch: Dict, cfg, global_step: int, sync=None, n_epoch: int = 0) -> torch.Tensor:
-    """One optimisation step of start_training (:380-494) without gradient accumulation: forward over the clips, pooled
-    loss, backward, gradient all-reduce (``sync`` = clipbert_amd.dist.GradSync or None), LR schedule, clip + AdamW."""
-    optimizer.zero_grad()
-    logits = forward_clips(model, batch, _get(cfg, "train_n_clips", 1), _get(cfg, "num_frm"))
-    loss = training_loss(model, logits, batch["labels"], batch["n_examples_list"], _get(cfg, "score_agg_func", "mean"))
-    loss.backward()
+def train_step(model, optimizer, batch: Dict, cfg, global_step: int, sync=None, n_epoch: int = 0, micro_step: int = 0) -> torch.Tensor:
+    """One micro-step of start_training (:380-494): forward over the clips, pooled loss, backward; on the last micro-step of
+    a gradient-accumulation group ((micro_step + 1) % cfg.gradient_accumulation_steps == 0, :426-436) also the gradient
+    all-reduce (``sync`` = clipbert_amd.dist.GradSync or None), the LR schedule and clip + AdamW.  Gradients of the
+    micro-steps add up un-scaled, as in the reference; the exchange happens once per group (the sum is linear)."""
+    acc = max(1, int(_get(cfg, "gradient_accumulation_steps", 1) or 1))
+    first, last = micro_step % acc == 0, (micro_step + 1) % acc == 0
+    if first:
+        optimizer.zero_grad()
+    hook = model.rt.after_encoder_backward
+    if not last:
+        model.rt.after_encoder_backward = None              # no exchange before the group is complete
+    try:
+        logits = forward_clips(model, batch, _get(cfg, "train_n_clips", 1), _get(cfg, "num_frm"))
+        loss = training_loss(model, logits, batch["labels"], batch["n_examples_list"], _get(cfg, "score_agg_func", "mean"))
+        loss.backward()
+    finally:
+        model.rt.after_encoder_backward = hook
+    model.rt.seed_dev.add_(1)                               # fresh dropout masks for the next forward
+    if not last:
+        return loss.detach()
     scale = 1.0
     if sync is not None:
+        if hook is None:
+            sync.reduce_transformer()
         sync.reduce_cnn()
         sync.wait()
         scale = sync.grad_scale
     set_learning_rates(optimizer, cfg, global_step + 1, n_epoch)
-    model.rt.seed_dev.add_(1)                           # fresh dropout masks next step
     optimizer.step(grad_scale=scale)
     return loss.detach()
 

@@ -129,3 +129,32 @@ def test_qa_predict_multiple_choice(hw):
     assert tuple(ref.shape) == (2, 5)
     assert pred == ref.max(dim=-1)[1].tolist()                # argmax-exact answer ids
     assert tasks.qa_accuracy(pred, pred) == 100.0
+
+
+def test_gradient_accumulation_sums_micro_batches(hw):
+    """two micro-steps with gradient_accumulation_steps=2 == one step whose gradient is the SUM of the two (:426-436)."""
+    cfg, sd, model = build("retrieval", RET, torch.float32, hw.dev)
+    model.eval()
+    base = dict(train_n_clips=1, num_frm=2, score_agg_func="mean", learning_rate=1e-3, cnn_learning_rate=1e-3, decay="constant",
+                cnn_lr_decay="constant", num_train_steps=10, warmup_ratio=0.0)
+    vis = _frames(2, 2, 31)
+    ids, mask = S.synthetic_text(4, 6, 31, cfg["vocab_size"])
+    ids = ids.clamp(max=cfg["vocab_size"] - 1)
+    labels = torch.tensor([1, 0, 0, 1])
+    halves = [to_dev(dict(visual_inputs=vis[i:i + 1], text_input_ids=ids[2 * i:2 * i + 2], text_input_mask=mask[2 * i:2 * i + 2],
+                          labels=labels[2 * i:2 * i + 2], n_examples_list=[2]), hw.dev) for i in range(2)]
+    opt = optim.FusedAdamW(model.rt.bank, lr=1e-3, betas=(0.9, 0.98), weight_decay=0.0, cnn_lr=1e-3, max_grad_norm=-1.0)
+    bank = model.rt.bank
+    # reference gradient: sum of the two micro-batch gradients
+    bank.zero_grad()
+    for h in halves:
+        out = model(dict(h))
+        out["loss"].mean().backward()
+    g_sum = bank.grad.clone()
+    w0 = bank.master.clone()
+    acfg = SimpleNamespace(gradient_accumulation_steps=2, **base)
+    tasks.train_step(model, opt, dict(halves[0]), acfg, global_step=0, micro_step=0)
+    torch.testing.assert_close(bank.master, w0, rtol=0, atol=0)                      # no update after the first micro-step
+    tasks.train_step(model, opt, dict(halves[1]), acfg, global_step=0, micro_step=1)
+    torch.testing.assert_close(bank.grad, g_sum, rtol=1e-5, atol=1e-8)
+    assert (bank.master - w0).abs().max() > 0

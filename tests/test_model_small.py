@@ -216,3 +216,43 @@ def test_pretraining_pixel_random_sampling_train_mode(hw):
         g_ref = sdr[name].grad
         diff = (p.grad.cpu() - g_ref).norm() / max(g_ref.norm().item(), 1e-8)
         assert diff < (2e-3 if hw.name == "emul" else 5e-3), (name, float(diff))
+
+
+@pytest.mark.parametrize("head,extra,repeat,label_kind", [
+    ("retrieval", dict(num_labels=1, loss_type="rank", margin=0.1), 2, "unused"),          # a16 ranking loss
+    ("multiple_choice", dict(num_labels=5, loss_type="ce"), 5, "per_video"),               # a17 (TGIF-QA action / transition)
+    ("sequence_classification", dict(num_labels=7, loss_type="ce"), 1, "class"),           # a18 open-ended QA
+    ("sequence_classification", dict(num_labels=6, loss_type="bce"), 1, "soft"),           # a18 VQA-style soft targets
+    ("sequence_classification", dict(num_labels=1, loss_type="ce"), 1, "real"),            # a18 regression (count): MSE
+])
+def test_other_heads_and_losses_match_oracle(hw, head, extra, repeat, label_kind):
+    """logits, per-example losses and gradients of the remaining heads / loss types (modeling.py:327-451, 543-580)."""
+    cfg, sd, model = build(head, extra, torch.float32, hw.dev)
+    n_videos = 2
+    batch = make_batch(cfg, head, n_videos, repeat, 6)
+    n_pairs = n_videos * repeat
+    g = torch.Generator().manual_seed(3)
+    if label_kind == "per_video":
+        batch["labels"] = torch.randint(0, 5, (n_videos,), generator=g)
+    elif label_kind == "class":
+        batch["labels"] = torch.randint(0, extra["num_labels"], (n_pairs,), generator=g)
+    elif label_kind == "soft":
+        batch["labels"] = torch.rand(n_pairs, extra["num_labels"], generator=g)
+    elif label_kind == "real":
+        batch["labels"] = torch.rand(n_pairs, generator=g) * 10
+    else:
+        batch["labels"] = torch.zeros(n_pairs, dtype=torch.long)
+    ref, sdr = grads_of_oracle(sd, batch, cfg, head, lambda o: o["loss"].mean())
+    model.rt.bank.zero_grad()
+    out = model(to_dev(batch, hw.dev))
+    tol = dict(rtol=1e-3, atol=1e-4) if hw.name == "emul" else dict(rtol=2e-3, atol=1e-3)
+    torch.testing.assert_close(out["logits"].cpu(), ref["logits"].detach(), **tol)
+    torch.testing.assert_close(out["loss"].cpu().reshape(-1), ref["loss"].detach().reshape(-1), **tol)
+    out["loss"].mean().backward()
+    params = dict(model.named_parameters())
+    # (classifier.2.bias is skipped: for the 1-logit multiple-choice head its gradient is exactly zero, softmax shift invariance)
+    for name in ("transformer.classifier.0.weight", "transformer.classifier.2.weight", "transformer.bert.pooler.dense.weight",
+                 "transformer.bert.encoder.layer.1.output.dense.weight", "cnn.grid_encoder.0.weight"):
+        g_ref = sdr[name].grad
+        rel = (params[name].grad.cpu() - g_ref).norm() / max(g_ref.norm().item(), 1e-8)
+        assert rel < (2e-3 if hw.name == "emul" else 5e-3), (name, float(rel))

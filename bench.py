@@ -216,8 +216,8 @@ def main():
 
     # clock / power-state settling (untimed, before the W warm-up steps): right after process start the first replays run
     # ~15 % slow on some boxes; ~0.75 s of steady replays brings the GPU to its sustained clocks
-    t_settle = time.perf_counter() + 0.75
-    while time.perf_counter() < t_settle:
+    # (a FIXED number of replays: with N > 1 every rank must issue the same number of collectives)
+    for _ in range(12):
         for _ in range(8):
             run()
         torch.cuda.synchronize()

@@ -16,9 +16,20 @@ HEAD_CLS = dict(retrieval=M.ClipBertForVideoTextRetrieval, multiple_choice=M.Cli
                 sequence_classification=M.ClipBertForSequenceClassification, pretraining=M.ClipBertForPreTraining)
 
 
+_SD_CACHE = {}
+
+
+def _state_dict(cfg, head, seed):
+    """synthetic weights are deterministic per (config, head, seed): generate once per process (callers never mutate them)"""
+    key = (head, seed, tuple(sorted((k, str(v)) for k, v in cfg.items())))
+    if key not in _SD_CACHE:
+        _SD_CACHE[key] = S.full_state_dict(cfg, head, seed)
+    return _SD_CACHE[key]
+
+
 def build(head, extra, dtype, dev, seed=5):
     cfg = dict(SMALL, **extra)
-    sd = S.full_state_dict(cfg, head, seed)
+    sd = _state_dict(cfg, head, seed)
     model = M.ClipBert(cfg, detectron2_model_cfg="R-50-grid.yaml", transformer_cls=HEAD_CLS[head])
     missing, unexpected = model.load_state_dict(sd, strict=True)
     model.to(dev).eval()

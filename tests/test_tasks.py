@@ -19,7 +19,7 @@ def _frames(n_videos, n_frames, seed):
     return O.image_norm(f, S.PIXEL_MEAN, S.PIXEL_STD)
 
 
-@pytest.mark.parametrize("pool", ["max", "lse"])
+@pytest.mark.parametrize("pool", ["lse"])
 def test_cached_inference_equals_per_clip_loop(hw, pool):
     cfg, sd, model = build("retrieval", RET, torch.float32, hw.dev)
     model.eval()

@@ -140,10 +140,24 @@ def inference_retrieval_video(model, visual_inputs: torch.Tensor, text_input_ids
 
 # ---- video QA inference (run_video_qa.py:216-300) ------------------------------------------------------------------------
 @torch.no_grad()
-def qa_predict(model, batch: Dict, cfg) -> List[int]:
+def qa_predict(model, batch: Dict, cfg, fold_clips: bool = False) -> List[int]:
     """Predicted answer ids of one batch: clip loop over inference_n_clips, pooling, then argmax (classification tasks
-    action / transition / frameqa / msrvtt_qa) or round-and-clamp to 1..10 (the regression task "count")."""
-    logits = forward_clips(model, dict(batch, labels=None), _get(cfg, "inference_n_clips", 1), _get(cfg, "num_frm"))
+    action / transition / frameqa / msrvtt_qa) or round-and-clamp to 1..10 (the regression task "count").
+
+    fold_clips=True (row N1 for QA): all clips of all videos go through the CNN and the encoder as ONE batch -- (clip, video)
+    pairs become the "videos" of a single forward -- instead of inference_n_clips separate forwards; same predictions."""
+    n_clips, num_frm = _get(cfg, "inference_n_clips", 1), _get(cfg, "num_frm")
+    if fold_clips and n_clips > 1:
+        vis = batch["visual_inputs"]
+        bsz = vis.shape[0]
+        vis = vis.view(bsz, n_clips, num_frm, *vis.shape[2:]).transpose(0, 1).reshape(n_clips * bsz, num_frm, *vis.shape[2:])
+        counts = list(batch["n_examples_list"])
+        out = model(dict(visual_inputs=vis.contiguous(), text_input_ids=batch["text_input_ids"].repeat(n_clips, 1),
+                         text_input_mask=batch["text_input_mask"].repeat(n_clips, 1), labels=None, n_examples_list=counts * n_clips))
+        lg = out["logits"]
+        logits = list(lg.view(n_clips, lg.shape[0] // n_clips, *lg.shape[1:]).unbind(0))
+    else:
+        logits = forward_clips(model, dict(batch, labels=None), n_clips, num_frm)
     pool = _get(cfg, "score_agg_func", "mean")
     pooled = clips.aggregate_clip_logits(logits, pool)
     if pool == "lse":

@@ -129,6 +129,8 @@ def test_qa_predict_multiple_choice(hw):
     assert tuple(ref.shape) == (2, 5)
     assert pred == ref.max(dim=-1)[1].tolist()                # argmax-exact answer ids
     assert tasks.qa_accuracy(pred, pred) == 100.0
+    if hw.name == "emul":                                     # all (clip, video) pairs in one forward: same answers
+        assert tasks.qa_predict(model, to_dev(batch, hw.dev), qcfg, fold_clips=True) == pred
 
 
 def test_gradient_accumulation_sums_micro_batches(hw):

@@ -43,11 +43,14 @@ class _LseLossFn(torch.autograd.Function):
         return dx, None
 
 
-def _stack(logits: List[torch.Tensor]) -> torch.Tensor:
+def _stack(logits) -> torch.Tensor:
+    """list of per-clip logits, or their (n_clips, B, C) stack (a folded forward returns it directly), as fp32"""
+    if torch.is_tensor(logits):
+        return logits.float().contiguous()
     return torch.stack([t.float() for t in logits]).contiguous()          # (n_clips, B, C) fp32: layout only
 
 
-def aggregate_clip_logits(logits: List[torch.Tensor], pool_method: str) -> torch.Tensor:
+def aggregate_clip_logits(logits, pool_method: str) -> torch.Tensor:
     """run_video_retrieval.py:402-411: "mean" / "max" over the clips -> (B, C); "lse" -> (B, n_clips, C), pooled inside
     lse_train_loss / lse_inference_logits."""
     st = _stack(logits)

@@ -27,6 +27,7 @@ class GradSync:
     def __init__(self, bank: ParamBank, group=None, bucket_bytes: int = 0, compress: Optional[str] = None):
         assert compress in (None, "bf16")
         self.bank = bank
+        bank.clients += 1
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         t_end = bank.group_range[3][1]

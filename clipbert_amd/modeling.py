@@ -174,6 +174,10 @@ class Runtime:
         self.anchor: Optional[torch.Tensor] = None       # requires_grad leaf that keeps the coarse nodes alive
         self.stem_w = None
         self.after_encoder_backward = None               # hook: launch the transformer-bucket all-reduce
+        self.pending_encoder_nodes = 0                   # encoder autograd nodes created and not yet run backward: the hook
+                                                         # fires when the LAST of them finished (multi-clip loops run several)
+        self.forward_count = 0                           # host counter folded into every dropout seed: each forward (each
+                                                         # clip of a clip loop) draws its own masks; kept in the saved pack
         self.side_stream = None                          # second HIP stream: weight-gradient GEMMs run beside the dgrad chain
         self._side_refs = []
 
@@ -538,8 +542,10 @@ class BertPooler(nn.Module):
 _SITE_EMB, _SITE_ATTN, _SITE_SELF_OUT, _SITE_OUT, _SITE_POOL = 1, 2, 3, 4, 5
 
 
-def _seed(site, layer=0):
-    return (site * 1000003 + layer * 7919) * 2654435761 % (1 << 62)
+def _seed(site, layer=0, fwd=0):
+    """seed of one dropout site of one layer of the fwd-th forward of this process (the device word *rt.seed_dev is added
+    on top by the kernels, so hipGraph replays -- where `fwd` is frozen at capture -- still draw fresh masks)"""
+    return ((site * 1000003 + layer * 7919) * 2654435761 + fwd * 0x9E3779B97F4A7C15) % (1 << 62)
 
 
 class ClipBertBaseModel(nn.Module):
@@ -579,6 +585,10 @@ def encoder_forward(model: ClipBertBaseModel, grid, ids, mask, src_row, pooled_d
     training = model.training
     p_h = _drop_p(model, training)
     p_a = _drop_p(model, training, "attention_probs_dropout_prob")
+    fwd_i = 0
+    if p_h > 0 or p_a > 0:                    # every training forward draws its own dropout masks (the reference's
+        fwd_i = rt.forward_count              # nn.Dropout does); the backward regenerates them from pack.fwd_i
+        rt.forward_count += 1
     bsz, lt = ids.shape
     bv, t, hg, wg, _ = grid.shape
     # optional random pixel sub-sampling: training phase of pre-training only (modeling.py:80-88)
@@ -616,7 +626,7 @@ def encoder_forward(model: ClipBertBaseModel, grid, ids, mask, src_row, pooled_d
                          bank.compute(vemb.col_position_embeddings.weight), bank.compute(vemb.token_type_embeddings.weight)[0],
                          vemb.LayerNorm.weight, vemb.LayerNorm.bias, x, pre, mean0, rstd0, bsz, lv, lt, L, eps)
     if p_h > 0:
-        ops.dropout(x, p_h, _seed(_SITE_EMB), rt.seed_dev, out=x)
+        ops.dropout(x, p_h, _seed(_SITE_EMB, 0, fwd_i), rt.seed_dev, out=x)
     layers = []
     for li, layer in enumerate(model.encoder.layer):
         att, so, it, ou = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
@@ -625,10 +635,10 @@ def encoder_forward(model: ClipBertBaseModel, grid, ids, mask, src_row, pooled_d
         qkv = torch.empty(M, 3 * d, dtype=dt, device=dev)
         ops.gemm(x, wqkv, M, 3 * d, d, out=qkv, shift=bqkv)
         ctx, lse = ops.attention_fwd(qkv, key_mask, bsz, L, nh, save_lse=save, dropout_p=p_a,
-                                     dropout_seed=_seed(_SITE_ATTN, li), seed_ptr=rt.seed_dev, out=stk.ctx[li] if save else None)
+                                     dropout_seed=_seed(_SITE_ATTN, li, fwd_i), seed_ptr=rt.seed_dev, out=stk.ctx[li] if save else None)
         a_pre = torch.empty(M, d, dtype=dt, device=dev)
         ops.gemm(ctx, bank.compute(so.dense.weight), M, d, d, out=a_pre, shift=so.dense.bias, residual=x, dropout_p=p_h,
-                 dropout_seed=_seed(_SITE_SELF_OUT, li), seed_ptr=rt.seed_dev)
+                 dropout_seed=_seed(_SITE_SELF_OUT, li, fwd_i), seed_ptr=rt.seed_dev)
         a, mean1, rstd1 = ops.layernorm_fwd(a_pre, so.LayerNorm.weight, so.LayerNorm.bias, eps, save_stats=save,
                                             out=stk.a[li] if save else None)
         hact = stk.hact[li] if save else torch.empty(M, ff, dtype=dt, device=dev)
@@ -636,7 +646,7 @@ def encoder_forward(model: ClipBertBaseModel, grid, ids, mask, src_row, pooled_d
         ops.gemm(a, bank.compute(it.dense.weight), M, ff, d, out=hact, shift=it.dense.bias, act=ACT_GELU, out2=hpre)
         o_pre = torch.empty(M, d, dtype=dt, device=dev)
         ops.gemm(hact, bank.compute(ou.dense.weight), M, d, ff, out=o_pre, shift=ou.dense.bias, residual=a, dropout_p=p_h,
-                 dropout_seed=_seed(_SITE_OUT, li), seed_ptr=rt.seed_dev)
+                 dropout_seed=_seed(_SITE_OUT, li, fwd_i), seed_ptr=rt.seed_dev)
         out, mean2, rstd2 = ops.layernorm_fwd(o_pre, ou.LayerNorm.weight, ou.LayerNorm.bias, eps, save_stats=save,
                                               out=stk.x[li + 1] if (save and li + 1 < nl) else None)
         if save:
@@ -648,15 +658,15 @@ def encoder_forward(model: ClipBertBaseModel, grid, ids, mask, src_row, pooled_d
     pw = model.pooler.dense
     if pooled_raw is not None:
         ops.gemm(x, bank.compute(pw.weight), bsz, d, d, out=pooled_raw, lda=L * d, shift=pw.bias, act=ACT_TANH)
-        ops.dropout(pooled_raw, p_pool, _seed(_SITE_POOL), rt.seed_dev, out=pooled)
+        ops.dropout(pooled_raw, p_pool, _seed(_SITE_POOL, 0, fwd_i), rt.seed_dev, out=pooled)
     else:
         ops.gemm(x, bank.compute(pw.weight), bsz, d, d, out=pooled, lda=L * d, shift=pw.bias, act=ACT_TANH,
-                 dropout_p=p_pool, dropout_seed=_seed(_SITE_POOL), seed_ptr=rt.seed_dev)
+                 dropout_p=p_pool, dropout_seed=_seed(_SITE_POOL, 0, fwd_i), seed_ptr=rt.seed_dev)
     pack = None
     if save:
         pack = SimpleNamespace(layers=layers, x_final=x, pooled=pooled, pooled_raw=pooled_raw, p_pool=p_pool, pre=pre,
                                mean0=mean0, rstd0=rstd0, ids=ids_c, key_mask=key_mask, src_row=src_row, sel=sel, bsz=bsz,
-                               lt=lt, lv=lv, L=L, grid_shape=tuple(grid.shape), p_h=p_h, p_a=p_a, stk=stk)
+                               lt=lt, lv=lv, L=L, grid_shape=tuple(grid.shape), p_h=p_h, p_a=p_a, stk=stk, fwd_i=fwd_i)
     return x, pooled, pack
 
 
@@ -739,7 +749,7 @@ def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
     if d_pooled is not None:
         g = d_pooled.to(dt).contiguous()
         if pk.pooled_raw is not None:
-            g = ops.dropout(g, pk.p_pool, _seed(_SITE_POOL), rt.seed_dev)
+            g = ops.dropout(g, pk.p_pool, _seed(_SITE_POOL, 0, pk.fwd_i), rt.seed_dev)
             g = ops.act_bwd(ACT_TANH, g, pk.pooled_raw)
         else:
             g = ops.act_bwd(ACT_TANH, g, pk.pooled)
@@ -759,7 +769,7 @@ def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
         x, qkv, ctx, lse, a_pre, mean1, rstd1, a, hpre, hact, o_pre, mean2, rstd2 = pk.layers[li]
         keep = dict(dx2=gs.out[li]) if pk.p_h > 0 else dict(dx=gs.out[li])
         d_o_pre, d_o_drop = ops.layernorm_bwd(dx, o_pre, ou.LayerNorm.weight, mean2, rstd2, bank.grad_image(ou.LayerNorm.weight),
-                                              bank.grad_image(ou.LayerNorm.bias), pk.p_h, _seed(_SITE_OUT, li), rt.seed_dev, **keep)
+                                              bank.grad_image(ou.LayerNorm.bias), pk.p_h, _seed(_SITE_OUT, li, pk.fwd_i), rt.seed_dev, **keep)
         g = d_o_drop if d_o_drop is not None else d_o_pre
         dhp = gs.hp[li]
         ops.gemm(g, bank.compute(ou.dense.weight), M, ff, d, out=dhp, b_mode=KROW, gelu_grad_pre=hpre)   # dgrad + GELU'
@@ -767,11 +777,11 @@ def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
         ops.gemm(dhp, bank.compute(it.dense.weight), M, d, ff, out=da, b_mode=KROW, residual=d_o_pre)
         keep = dict(dx2=gs.att[li]) if pk.p_h > 0 else dict(dx=gs.att[li])
         d_a_pre, d_a_drop = ops.layernorm_bwd(da, a_pre, so.LayerNorm.weight, mean1, rstd1, bank.grad_image(so.LayerNorm.weight),
-                                              bank.grad_image(so.LayerNorm.bias), pk.p_h, _seed(_SITE_SELF_OUT, li), rt.seed_dev, **keep)
+                                              bank.grad_image(so.LayerNorm.bias), pk.p_h, _seed(_SITE_SELF_OUT, li, pk.fwd_i), rt.seed_dev, **keep)
         g = d_a_drop if d_a_drop is not None else d_a_pre
         dctx = torch.empty(M, d, dtype=dt, device=dev)
         ops.gemm(g, bank.compute(so.dense.weight), M, d, d, out=dctx, b_mode=KROW)
-        dqkv = ops.attention_bwd(qkv, pk.key_mask, ctx, dctx, lse, bsz, L, nh, pk.p_a, _seed(_SITE_ATTN, li), rt.seed_dev,
+        dqkv = ops.attention_bwd(qkv, pk.key_mask, ctx, dctx, lse, bsz, L, nh, pk.p_a, _seed(_SITE_ATTN, li, pk.fwd_i), rt.seed_dev,
                                  out=gs.qkv[li])
         wqkv = bank.compute_span(att.query.weight, att.value.weight, (3 * d, d))
         dx = torch.empty(M, d, dtype=dt, device=dev)
@@ -780,7 +790,7 @@ def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
     # ---- embeddings -----------------------------------------------------------------------------------
     rt.join()
     if pk.p_h > 0:
-        dx = ops.dropout(dx, pk.p_h, _seed(_SITE_EMB), rt.seed_dev)
+        dx = ops.dropout(dx, pk.p_h, _seed(_SITE_EMB, 0, pk.fwd_i), rt.seed_dev)
     emb, vemb = model.embeddings, model.visual_embeddings
     dpre = torch.empty(M, d, dtype=dt, device=dev)
     ops.layernorm_bwd(dx, pk.pre, emb.LayerNorm.weight, pk.mean0, pk.rstd0, bank.grad_image(emb.LayerNorm.weight),
@@ -807,14 +817,20 @@ class _EncoderFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         seq, pooled, pack = encoder_forward(model, grid, ids, mask, src_row, pooled_dropout, save)
         ctx.model, ctx.pack = model, pack
+        if save:
+            model.rt.pending_encoder_nodes += 1
         return seq, pooled
 
     @staticmethod
     def backward(ctx, d_seq, d_pooled):
         dgrid = encoder_backward(ctx.model, ctx.pack, d_seq, d_pooled)
         ctx.pack = None
-        hook = ctx.model.rt.after_encoder_backward
-        if hook is not None:
+        rt = ctx.model.rt
+        rt.pending_encoder_nodes = max(0, rt.pending_encoder_nodes - 1)
+        hook = rt.after_encoder_backward
+        # a clip LOOP (train_n_clips forwards before one backward) runs several encoder backwards per step: the
+        # transformer gradients are complete -- and may start their all-reduce -- only after the last of them
+        if hook is not None and rt.pending_encoder_nodes == 0:
             hook()
         return None, dgrid, None, None, None, None, None
 
@@ -1103,6 +1119,20 @@ class ClipBert(nn.Module):
         self.retrieval = transformer_cls == ClipBertForVideoTextRetrieval
         self.rt: Optional[Runtime] = None
         self._src_cache = {}
+        # nn.Module.load_state_dict copies into the fp32 master views of a prepared model: everything derived from them
+        # (bf16 compute copies, folded FrozenBN vectors, packed stem filter) is refreshed afterwards -- also when only
+        # a sub-module is loaded (load_state_dict_with_mismatch(model.transformer, ...), load_separate_ckpt)
+        for mod in (self, self.cnn, self.transformer):
+            mod.register_load_state_dict_post_hook(lambda _m, _keys, owner=self: owner.refresh_compute())
+
+    def refresh_compute(self):
+        if self.rt is None:
+            return
+        self.rt.bank.sync_compute()
+        self.rt.stem_w = None
+        for m in self.modules():
+            if isinstance(m, Conv2d):
+                m._ss = None
 
     # ---- MI355X runtime --------------------------------------------------------------------------------
     def prepare(self, dtype=torch.bfloat16, device=None, transformer_lr_mul_prefix="", cnn_lr_mul_prefix="grid_encoder",
@@ -1144,43 +1174,76 @@ class ClipBert(nn.Module):
         batch["visual_inputs"] = self.cnn(vis)
         return self.forward_from_grid(batch)
 
-    def forward_from_grid(self, batch):
-        """forward() for a batch whose ``visual_inputs`` already are grid features (see grid_features)."""
+    def forward_from_grid(self, batch, clip_fold: int = 1):
+        """forward() for a batch whose ``visual_inputs`` already are grid features (see grid_features).
+
+        clip_fold = n > 1: the grid holds n clips per video, video-major ((Bv*n, T, H', W', d): row v*n + c is clip c of
+        video v -- the plain ``view`` of the reference's (B, n*T, 3, H, W) frame tensor, no copy), and the text batch is
+        the reference's batch repeated n times, clip-major (row c*B' + j = pair j looking at clip c).  One forward then
+        does what the reference's clip loop does in n (run_video_retrieval.py:396-401); logits come back clip-major, i.e.
+        ``logits.view(n, B', C)`` is the stack the loop builds with torch.stack."""
         repeat_counts = batch["n_examples_list"]
         del batch["n_examples_list"]
         vis = batch["visual_inputs"]
         # repeat_tensor_rows (data_utils.py:344-357) is fused into the visual-embedding gather
         src_row = None
-        if sum(repeat_counts) != len(repeat_counts):
+        if clip_fold > 1:
+            key = (tuple(repeat_counts), clip_fold, str(vis.device))
+            src_row = self._src_cache.get(key)
+            if src_row is None:
+                per_video = [i for i, r in enumerate(repeat_counts) for _ in range(r)]
+                src_row = torch.tensor([v * clip_fold + c for c in range(clip_fold) for v in per_video], dtype=torch.int32,
+                                       device=vis.device)
+                self._src_cache[key] = src_row
+            assert vis.shape[0] == len(repeat_counts) * clip_fold, "clip_fold: grid rows != videos x clips"
+        elif sum(repeat_counts) != len(repeat_counts):
             key = (tuple(repeat_counts), str(vis.device))
             src_row = self._src_cache.get(key)
             if src_row is None:
                 src_row = torch.tensor([i for i, r in enumerate(repeat_counts) for _ in range(r)], dtype=torch.int32,
                                        device=vis.device)
                 self._src_cache[key] = src_row
+        if src_row is not None and src_row.numel() != batch["text_input_ids"].shape[0]:
+            raise ValueError(f"n_examples_list describes {src_row.numel()} (video, text) pairs but the text batch has "
+                             f"{batch['text_input_ids'].shape[0]} rows")
         if self.retrieval:
             batch["sample_size"] = len(repeat_counts)
         return self.transformer(src_row=src_row, **batch)
 
     def load_separate_ckpt(self, cnn_weights_path=None, bert_weights_path=None):
+        """e2e_model.py:43-48: detectron2 backbone weights (``grid_feat_R-50.pth`` / a detectron2 ``.pkl`` / a torchvision
+        ResNet-50 state dict, see clipbert_amd.checkpoint) into ``cnn.feature`` and a BERT / ClipBERT transformer
+        checkpoint into ``transformer``.  Works before or after prepare(); raises if a file matches no key at all."""
+        from . import checkpoint as ckpt
         if cnn_weights_path:
-            sd = torch.load(cnn_weights_path, map_location="cpu")
-            sd = sd.get("model", sd)
-            self.cnn.feature.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=False)
+            n = ckpt.load_detectron2_backbone(self.cnn, cnn_weights_path)
+            if n == 0:
+                raise RuntimeError(f"{cnn_weights_path}: no key of the checkpoint matches the ResNet-50 grid backbone")
         if bert_weights_path:
-            sd = torch.load(bert_weights_path, map_location="cpu")
-            load_state_dict_with_mismatch(self.transformer, sd)
-        self.rt = None
+            n = load_state_dict_with_mismatch(self.transformer, bert_weights_path)
+            if n == 0:
+                raise RuntimeError(f"{bert_weights_path}: no key of the checkpoint matches {type(self.transformer).__name__}")
 
     def freeze_cnn_backbone(self):
+        """e2e_model.py:49-51.  Changes which parameters are trainable, i.e. the layout of the flat buffers: call it
+        before prepare() / before building the optimizer."""
+        if self.rt is not None and self.rt.bank.clients > 0:
+            raise RuntimeError("freeze_cnn_backbone() after an optimizer / GradSync was built on this model's parameter "
+                               "bank: freeze first, then prepare() and build the optimizer")
         for _n, p in self.cnn.feature.named_parameters():
             p.requires_grad = False
-        self.rt = None
+        if self.rt is not None:
+            self.prepare(dtype=self.rt.dtype, device=self.rt.bank.device)
 
 
-def load_state_dict_with_mismatch(model: nn.Module, loaded_state_dict):
-    """Key/shape tolerant load (src/utils/load_save.py:71-100): drops shape-mismatched and unknown keys
-    (e.g. the reference checkpoint's dead RPN/ROI-head weights), loads the rest non-strictly."""
+def load_state_dict_with_mismatch(model: nn.Module, loaded_state_dict_or_path) -> int:
+    """Key/shape tolerant load (src/utils/load_save.py:71-100): accepts a state dict or a path to one; drops
+    shape-mismatched and unknown keys (e.g. the reference checkpoint's dead RPN/ROI-head weights), loads the rest
+    non-strictly.  Returns the number of tensors loaded (the reference logs the key differences instead)."""
+    sd = loaded_state_dict_or_path
+    if isinstance(sd, (str, bytes)) or hasattr(sd, "__fspath__"):
+        sd = torch.load(sd, map_location="cpu")
     own = model.state_dict()
-    ok = {k: v for k, v in loaded_state_dict.items() if k in own and tuple(own[k].shape) == tuple(v.shape)}
-    return model.load_state_dict(ok, strict=False)
+    ok = {k: v for k, v in sd.items() if k in own and tuple(own[k].shape) == tuple(v.shape)}
+    model.load_state_dict(ok, strict=False)
+    return len(ok)

@@ -58,6 +58,7 @@ class FusedAdamW:
                  cnn_lr: Optional[float] = None, cnn_weight_decay: Optional[float] = None, transformer_lr_mul: float = 1.0,
                  cnn_lr_mul: float = 1.0, max_grad_norm: float = -1.0):
         self.bank = bank
+        bank.clients += 1
         bank.ensure_state()
         self.betas, self.eps = betas, eps
         self.max_grad_norm = max_grad_norm
@@ -72,26 +73,49 @@ class FusedAdamW:
             self.param_groups.append(dict(lr=base * mul, weight_decay=wd, range=bank.group_range[g]))
         self.step_count = 0
         dev = bank.device
-        self._hp_host = torch.zeros(N_GROUPS, 16, dtype=torch.float32)
+        # hyper-parameter staging: TWO pinned host slots used alternately, each guarded by an event recorded after its
+        # H2D copy -- the host may run ahead of the GPU by a step without overwriting values a pending copy still reads
+        self._hp_host = torch.zeros(2, N_GROUPS, 16, dtype=torch.float32)
         if dev.type == "cuda":
             self._hp_host = self._hp_host.pin_memory()
+        self._hp_events = [None, None]
         self._hp_dev = torch.zeros(N_GROUPS, 16, dtype=torch.float32, device=dev)
         self._sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._last_scale = 1.0
 
     def zero_grad(self):
         self.bank.zero_grad()
 
     @torch.no_grad()
-    def step(self, grad_scale: float = 1.0):
-        """grad_scale multiplies the gradients first (1/world_size after a SUM all-reduce)."""
-        bank = self.bank
+    def prepare_step(self, grad_scale: float = 1.0):
+        """Host half of a step: advance the step count, pack lr / bias corrections / clip norm / grad_scale of the 8 groups
+        and enqueue their (tiny) H2D copy on the current stream.  Never captured into a hipGraph: a training loop that
+        replays a captured step calls ``prepare_step()`` eagerly before each replay and captures only ``launch()``."""
         self.step_count += 1
         self._last_scale = grad_scale
+        slot = self.step_count & 1
+        ev = self._hp_events[slot]
+        if ev is not None:
+            ev.synchronize()                       # the copy that last read this slot has executed
+        host = self._hp_host[slot]
         for g, pg in enumerate(self.param_groups):
             hp = ops.adamw_hyper(pg["lr"], self.betas[0], self.betas[1], self.eps, pg["weight_decay"], self.step_count,
                                  self.max_grad_norm, grad_scale)
-            self._hp_host[g, :HP_COUNT + 1] = torch.tensor(hp[:HP_COUNT + 1])
-        self._hp_dev.copy_(self._hp_host, non_blocking=True)
+            host[g, :HP_COUNT + 1] = torch.tensor(hp[:HP_COUNT + 1])
+        self._hp_dev.copy_(host, non_blocking=True)
+        if self._hp_dev.is_cuda:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FusedAdamW.prepare_step() inside a hipGraph capture: capture launch() only and call "
+                                   "prepare_step() eagerly before each replay (see INTEGRATION.md)")
+            ev = torch.cuda.Event()
+            ev.record()
+            self._hp_events[slot] = ev
+
+    @torch.no_grad()
+    def launch(self):
+        """Device half of a step (capturable): global grad-norm reduction, then clip + AdamW + bf16 weight refresh, reading
+        the hyper-parameters from the device array prepare_step() filled."""
+        bank = self.bank
         sq = None
         if self.max_grad_norm > 0:
             self._sq.zero_()
@@ -104,6 +128,39 @@ class FusedAdamW:
             w16 = bank.w16[a:b] if bank.w16 is not None else None
             ops.adamw(bank.master[a:b], bank.grad[a:b], bank.exp_avg[a:b], bank.exp_avg_sq[a:b], w16, self._hp_dev[g], sq)
 
+    def step(self, grad_scale: float = 1.0):
+        """grad_scale multiplies the gradients first (1/world_size after a SUM all-reduce)."""
+        self.prepare_step(grad_scale)
+        self.launch()
+
     def grad_norm(self) -> float:
         """Host-visible global norm of the (averaged) gradient of the last step (syncs)."""
-        return float(self._sq.sqrt().item()) * getattr(self, "_last_scale", 1.0)
+        return float(self._sq.sqrt().item()) * self._last_scale
+
+    # ---- checkpointing (the reference saves optimizer.state_dict() in *_train_state.pt / restore.pt) ------------------
+    def state_dict(self) -> dict:
+        """{"state": {parameter name: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...], "step": n}: moments in the
+        parameters' LOGICAL shapes (OIHW for convs), keyed by name so that the file does not depend on the flat layout."""
+        bank = self.bank
+        state = {}
+        for name, p in bank._trainable:
+            off = bank.offset[id(p)]
+            state[name] = dict(step=self.step_count, exp_avg=bank._view(bank.exp_avg, off, p).detach().clone().contiguous(),
+                               exp_avg_sq=bank._view(bank.exp_avg_sq, off, p).detach().clone().contiguous())
+        groups = [dict(lr=pg["lr"], weight_decay=pg["weight_decay"], betas=self.betas, eps=self.eps) for pg in self.param_groups]
+        return dict(state=state, param_groups=groups, step=self.step_count)
+
+    @torch.no_grad()
+    def load_state_dict(self, sd: dict):
+        bank = self.bank
+        missing = [n for n, _p in bank._trainable if n not in sd["state"]]
+        if missing:
+            raise KeyError(f"optimizer state lacks {len(missing)} parameters, e.g. {missing[:3]}")
+        for name, p in bank._trainable:
+            off = bank.offset[id(p)]
+            st = sd["state"][name]
+            bank._view(bank.exp_avg, off, p).copy_(st["exp_avg"].to(bank.device, torch.float32))
+            bank._view(bank.exp_avg_sq, off, p).copy_(st["exp_avg_sq"].to(bank.device, torch.float32))
+        self.step_count = int(sd.get("step", 0))
+        for pg, src in zip(self.param_groups, sd.get("param_groups", [])):
+            pg["lr"], pg["weight_decay"] = src["lr"], src["weight_decay"]

@@ -54,6 +54,7 @@ class ParamBank:
         assert compute_dtype in (torch.bfloat16, torch.float32)
         self.device = torch.device(device)
         self.compute_dtype = compute_dtype
+        self.clients = 0            # optimizers / gradient exchangers built on this bank (they hold views of its buffers)
         named = []
         seen = {}
         for name, p in root.named_parameters(remove_duplicate=False):

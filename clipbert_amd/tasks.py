@@ -21,22 +21,57 @@ def _get(cfg, name, default=None):
 
 
 # ---- training (run_video_retrieval.py:380-494) ------------------------------------------------------------------------
-def forward_clips(model, batch: Dict, num_clips: int, num_frm: int) -> List[torch.Tensor]:
-    """The clip loop :391-401: (B, num_clips*num_frm, 3, H, W) frames -> list of per-clip logits."""
+_SKIP_KEYS = ("visual_inputs", "caption_ids", "vid_id", "question_ids", "n_examples_list")
+
+
+def _pair_counts(cfg, n_examples_list):
+    """forward_step of run_video_qa.py:206-210: the multiple-choice tasks present every (question, option) pair as its own
+    text row, so each video's count is multiplied by cfg.num_labels before the model call."""
+    counts = list(n_examples_list)
+    if cfg is not None and _get(cfg, "task") in ("action", "transition"):
+        nl = int(_get(cfg, "num_labels"))
+        counts = [e * nl for e in counts]
+    return counts
+
+
+def forward_clips_stack(model, batch: Dict, num_clips: int, num_frm: int, fold: bool = True, cfg=None,
+                        with_labels: bool = False) -> torch.Tensor:
+    """The clip loop of the reference's training / validation steps (run_video_retrieval.py:391-401, run_video_qa.py:
+    470-482): (B, num_clips*num_frm, 3, H, W) frames -> the (num_clips, B', C) stack of per-clip logits.
+
+    fold=True (default) runs ALL clips as one forward: the frame tensor is viewed as (B*num_clips, num_frm, ...) -- no
+    copy -- for one CNN batch, the text rows are repeated clip-major for one encoder batch of num_clips*B' pairs
+    (ClipBert.forward_from_grid(clip_fold=...)).  The reference pools at logit level, so this is results-identical to its
+    loop while every GEMM sees num_clips x the rows.  fold=False keeps the loop (one forward per clip)."""
     vis = batch["visual_inputs"]
     bsz = vis.shape[0]
+    counts = _pair_counts(cfg, batch["n_examples_list"])
+    labels = batch.get("labels") if with_labels else None
+    extra = {k: v for k, v in batch.items() if k not in _SKIP_KEYS + ("labels", "text_input_ids", "text_input_mask")}
+    ids, mask = batch["text_input_ids"], batch["text_input_mask"]
+    if fold and num_clips > 1:
+        grid = model.grid_features(vis.view(bsz * num_clips, num_frm, *vis.shape[2:]))
+        mini = dict(extra, visual_inputs=grid, text_input_ids=ids.repeat(num_clips, 1), text_input_mask=mask.repeat(num_clips, 1),
+                    labels=None, n_examples_list=counts)
+        lg = model.forward_from_grid(mini, clip_fold=num_clips)["logits"]
+        return lg.reshape(num_clips, lg.shape[0] // num_clips, *lg.shape[1:])
     vis = vis.view(bsz, num_clips, num_frm, *vis.shape[2:])
     logits = []
     for c in range(num_clips):
-        mini = {k: v for k, v in batch.items() if k not in ("visual_inputs", "caption_ids", "vid_id")}
-        mini["visual_inputs"] = vis[:, c].contiguous() if num_clips > 1 else vis[:, 0]
-        mini["n_examples_list"] = list(batch["n_examples_list"])
+        mini = dict(extra, visual_inputs=vis[:, c].contiguous() if num_clips > 1 else vis[:, 0], text_input_ids=ids,
+                    text_input_mask=mask, labels=labels, n_examples_list=list(counts))
         logits.append(model(mini)["logits"])
-    return logits
+    return torch.stack(logits)
 
 
-def training_loss(model, logits: List[torch.Tensor], labels, n_examples_list, pool_method: str) -> torch.Tensor:
-    """:402-419: pool the clips and take the mean per-pair loss."""
+def forward_clips(model, batch: Dict, num_clips: int, num_frm: int, fold: bool = True, cfg=None) -> List[torch.Tensor]:
+    """forward_clips_stack as the list of per-clip logits the reference's loop builds."""
+    return list(forward_clips_stack(model, batch, num_clips, num_frm, fold=fold, cfg=cfg).unbind(0))
+
+
+def training_loss(model, logits, labels, n_examples_list, pool_method: str) -> torch.Tensor:
+    """:402-419: pool the clips (``logits``: list of per-clip logits or their (n_clips, B', C) stack) and take the mean
+    per-pair loss."""
     pooled = clips.aggregate_clip_logits(logits, pool_method)
     if pool_method == "lse":
         loss = clips.lse_train_loss(pooled, labels)
@@ -69,25 +104,30 @@ def set_learning_rates(optimizer, cfg, global_step: int, n_epoch: int = 0):
     return lr_t, lr_c
 
 
-def train_step(model, optimizer, batch: Dict, cfg, global_step: int, sync=None, n_epoch: int = 0, micro_step: int = 0) -> torch.Tensor:
+def train_step(model, optimizer, batch: Dict, cfg, global_step: int, sync=None, n_epoch: int = 0, micro_step: int = 0,
+               fold_clips: bool = True) -> torch.Tensor:
     """One micro-step of start_training (:380-494): forward over the clips, pooled loss, backward; on the last micro-step of
     a gradient-accumulation group ((micro_step + 1) % cfg.gradient_accumulation_steps == 0, :426-436) also the gradient
     all-reduce (``sync`` = clipbert_amd.dist.GradSync or None), the LR schedule and clip + AdamW.  Gradients of the
-    micro-steps add up un-scaled, as in the reference; the exchange happens once per group (the sum is linear)."""
+    micro-steps add up un-scaled, as in the reference; the exchange happens once per group (the sum is linear).
+
+    With ``sync.overlap`` the transformer buckets are issued from inside the LAST encoder backward of the group (the model
+    counts its pending encoder nodes, so an un-folded clip loop does not fire early) and travel during the ResNet backward."""
     acc = max(1, int(_get(cfg, "gradient_accumulation_steps", 1) or 1))
     first, last = micro_step % acc == 0, (micro_step + 1) % acc == 0
     if first:
         optimizer.zero_grad()
-    hook = model.rt.after_encoder_backward
+    rt = model.rt
+    rt.pending_encoder_nodes = 0
+    hook = rt.after_encoder_backward
     if not last:
-        model.rt.after_encoder_backward = None              # no exchange before the group is complete
+        rt.after_encoder_backward = None                    # no exchange before the group is complete
     try:
-        logits = forward_clips(model, batch, _get(cfg, "train_n_clips", 1), _get(cfg, "num_frm"))
-        loss = training_loss(model, logits, batch["labels"], batch["n_examples_list"], _get(cfg, "score_agg_func", "mean"))
+        stack = forward_clips_stack(model, batch, _get(cfg, "train_n_clips", 1), _get(cfg, "num_frm"), fold=fold_clips, cfg=cfg)
+        loss = training_loss(model, stack, batch["labels"], batch["n_examples_list"], _get(cfg, "score_agg_func", "mean"))
         loss.backward()
     finally:
-        model.rt.after_encoder_backward = hook
-    model.rt.seed_dev.add_(1)                               # fresh dropout masks for the next forward
+        rt.after_encoder_backward = hook
     if not last:
         return loss.detach()
     scale = 1.0
@@ -151,13 +191,13 @@ def qa_predict(model, batch: Dict, cfg, fold_clips: bool = False) -> List[int]:
         vis = batch["visual_inputs"]
         bsz = vis.shape[0]
         vis = vis.view(bsz, n_clips, num_frm, *vis.shape[2:]).transpose(0, 1).reshape(n_clips * bsz, num_frm, *vis.shape[2:])
-        counts = list(batch["n_examples_list"])
+        counts = _pair_counts(cfg, batch["n_examples_list"])
         out = model(dict(visual_inputs=vis.contiguous(), text_input_ids=batch["text_input_ids"].repeat(n_clips, 1),
                          text_input_mask=batch["text_input_mask"].repeat(n_clips, 1), labels=None, n_examples_list=counts * n_clips))
         lg = out["logits"]
         logits = list(lg.view(n_clips, lg.shape[0] // n_clips, *lg.shape[1:]).unbind(0))
     else:
-        logits = forward_clips(model, dict(batch, labels=None), n_clips, num_frm)
+        logits = forward_clips(model, dict(batch, labels=None), n_clips, num_frm, fold=False, cfg=cfg)
     pool = _get(cfg, "score_agg_func", "mean")
     pooled = clips.aggregate_clip_logits(logits, pool)
     if pool == "lse":

@@ -113,11 +113,12 @@ def test_qa_predict_multiple_choice(hw):
     """TGIF-QA action style: 5 candidate answers per video, 2 clips, mean pooling; answer id = argmax (config 4)."""
     cfg, sd, model = build("multiple_choice", dict(num_labels=5, loss_type="ce"), torch.float32, hw.dev)
     model.eval()
-    qcfg = SimpleNamespace(inference_n_clips=2, num_frm=2, score_agg_func="mean", task="action")
+    # the collated batch counts QUESTIONS per video ([1, 1]); forward_step multiplies by num_labels (run_video_qa.py:206-210)
+    qcfg = SimpleNamespace(inference_n_clips=2, num_frm=2, score_agg_func="mean", task="action", num_labels=5)
     vis = _frames(2, 4, 21)
     ids, mask = S.synthetic_text(10, 6, 21, cfg["vocab_size"])
     ids = ids.clamp(max=cfg["vocab_size"] - 1)
-    batch = dict(visual_inputs=vis, text_input_ids=ids, text_input_mask=mask, n_examples_list=[5, 5])
+    batch = dict(visual_inputs=vis, text_input_ids=ids, text_input_mask=mask, n_examples_list=[1, 1])
     pred = tasks.qa_predict(model, to_dev(batch, hw.dev), qcfg)
     v = vis.view(2, 2, 2, *vis.shape[2:])
     per_clip = []
@@ -160,3 +161,53 @@ def test_gradient_accumulation_sums_micro_batches(hw):
     tasks.train_step(model, opt, dict(halves[1]), acfg, global_step=0, micro_step=1)
     torch.testing.assert_close(bank.grad, g_sum, rtol=1e-5, atol=1e-8)
     assert (bank.master - w0).abs().max() > 0
+
+
+@pytest.mark.parametrize("pool", ["mean", "lse"])
+def test_folded_clips_equal_clip_loop(hw, pool):
+    """tasks.forward_clips_stack(fold=True) -- all clips in ONE CNN batch and ONE encoder batch -- gives the logits, the
+    loss and the parameter gradients of the reference's clip loop (run_video_retrieval.py:391-419)."""
+    cfg, sd, model = build("retrieval", RET, torch.float32, hw.dev)
+    model.eval()
+    vis = _frames(2, 4, 41)                                   # 2 videos x (2 clips x 2 frames)
+    ids, mask = S.synthetic_text(3, 6, 41, cfg["vocab_size"])
+    ids = ids.clamp(max=cfg["vocab_size"] - 1)
+    labels = torch.tensor([1, 0, 1])
+    batch = to_dev(dict(visual_inputs=vis, text_input_ids=ids, text_input_mask=mask, labels=labels, n_examples_list=[2, 1]), hw.dev)
+    bank = model.rt.bank
+    res = {}
+    for fold in (False, True):
+        bank.zero_grad()
+        stack = tasks.forward_clips_stack(model, dict(batch), 2, 2, fold=fold)
+        assert tuple(stack.shape) == (2, 3, 2)
+        loss = tasks.training_loss(model, stack, batch["labels"], batch["n_examples_list"], pool)
+        loss.backward()
+        res[fold] = (stack.detach().float().cpu(), float(loss), bank.grad.clone().cpu())
+    torch.testing.assert_close(res[True][0], res[False][0], rtol=1e-4, atol=1e-5)
+    assert res[True][1] == pytest.approx(res[False][1], rel=1e-5, abs=1e-6)
+    g0, g1 = res[False][2], res[True][2]
+    assert float((g1 - g0).norm() / g0.norm()) < 2e-4
+    # a text batch that does not match n_examples_list is refused (it would index the grid out of range)
+    bad = dict(batch, n_examples_list=[2, 2])
+    with pytest.raises(ValueError):
+        tasks.forward_clips_stack(model, bad, 2, 2, fold=True)
+
+
+def test_each_forward_draws_its_own_dropout_masks(hw):
+    """nn.Dropout semantics: two training forwards of the same input differ (the per-forward counter is part of every
+    seed), while the backward of each forward regenerates exactly its own masks (gradient check by finite differences is
+    out of scope here: the mask agreement of the kernels is tested in test_kernels_misc)."""
+    cfg, sd, model = build("retrieval", RET, torch.float32, hw.dev)
+    model.train()
+    vis = _frames(1, 2, 43)
+    ids, mask = S.synthetic_text(2, 6, 43, cfg["vocab_size"])
+    ids = ids.clamp(max=cfg["vocab_size"] - 1)
+    b = to_dev(dict(visual_inputs=vis, text_input_ids=ids, text_input_mask=mask, labels=torch.tensor([1, 0]), n_examples_list=[2]), hw.dev)
+    with torch.no_grad():
+        l0 = model(dict(b))["logits"].float().cpu()
+        l1 = model(dict(b))["logits"].float().cpu()
+    assert (l0 - l1).abs().max() > 0
+    model.rt.forward_count = 0                                 # same counter -> same masks
+    with torch.no_grad():
+        l2 = model(dict(b))["logits"].float().cpu()
+    torch.testing.assert_close(l2, l0, rtol=0, atol=0)

@@ -1,23 +1,34 @@
 #!/usr/bin/env python
-"""MI355X benchmark of the ClipBERT hot path (metric of BASELINE.json: clips/sec/node).
+"""MI355X benchmark of the ClipBERT hot path (metric of BASELINE.json: clips/sec/node at N_clip x N_frame = 2 x 2,
+224 px, L_txt = 32).
 
-One "step" = one full data-parallel TRAINING step of BASELINE configs[1] at the headline shape
-(MSRVTT retrieval, N_clip = 1, N_frame = 2, 224x224, L_txt = 32, 16 videos x (pos+neg) text per GPU):
-forward (ResNet-50 grid backbone -> cross-modal BERT -> retrieval head -> CE), backward, gradient
-all-reduce over RCCL (N > 1), global-norm clipping and fused AdamW -- dropout on, bf16 compute, fp32
-master weights.  Inputs are resident in HBM before the timed region.  The whole step is captured in a
-hipGraph (torch.cuda.graph) and replayed.
+Default (`--mode train`): one "step" = one full data-parallel TRAINING step of MSRVTT retrieval
+(src/configs/msrvtt_ret_base_resnet50.json: 16 videos per GPU, 1 positive + 1 negative text per video, score_agg_func
+"lse", AdamW + grad-norm clipping) at the METRIC's shape: every video contributes N_clip = 2 clips of N_frame = 2 frames,
+224 x 224, L_txt = 32 -- 32 clips = 64 frames and 64 (text, clip) pairs per GPU per step.  Inside the timed step:
+uint8 frames (resident in HBM) -> ImageNorm + BGR + NHWC pack -> ResNet-50 grid backbone -> cross-modal BERT over all
+clips at once (the reference's clip loop folded into the batch) -> retrieval head -> LSE pooling over the clips + loss ->
+backward -> gradient all-reduce over RCCL (N > 1) -> global-norm clipping + fused AdamW; dropout on, bf16 compute, fp32
+master weights.  The device work of a step is a hipGraph; the optimizer's hyper-parameter upload and (N > 1) the RCCL
+all-reduces are issued eagerly around / between the graphs.
 
-Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel family of the step (the
-bf16 MFMA GEMM / implicit-GEMM conv kernel), timed live with HIP events on the launch stream;
-`cpu_baseline` is the CPU oracle (oracle/clipbert_oracle.py, a port of the reference arithmetic in
-stock PyTorch fp32 ops) running the same fwd+bwd on a bounded sample on this host.
+Other workloads (rows of BASELINE.json `configs`; never the default line):
+  --mode tgif     configs[3]: TGIF-QA action training step (ClipBertForMultipleChoice, 5 options per question, L_txt = 25,
+                  N_clip = 2, mean pooling)
+  --mode infer16  configs[4]: retrieval inference, one video x 16 clips against a mini-batch of 64 captions per step (grid
+                  features computed once, all 16 x 64 pairs in one encoder batch); N > 1 shards the videos over the ranks and
+                  gathers the (vid, txt, score) rows once at the end (inside the timed region)
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel family of the step (bf16 MFMA GEMM /
+implicit-GEMM conv), timed live with HIP events on the launch stream; `cpu_baseline` is the CPU oracle
+(oracle/clipbert_oracle.py, a port of the reference arithmetic in stock PyTorch fp32 ops) on a bounded sample.
 """
 import argparse
 import json
 import os
 import sys
 import time
+from types import SimpleNamespace
 
 import torch
 
@@ -25,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak (2:1 sparsity excluded)
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 BASE_CONFIG = dict(
     max_temporal_position_embeddings=100, backbone_channel_in_size=2048, max_grid_row_position_embeddings=100,
@@ -33,23 +45,38 @@ BASE_CONFIG = dict(
     model_type="bert", num_attention_heads=12, num_hidden_layers=12, pad_token_id=0, type_vocab_size=2, vocab_size=30522,
     num_labels=2, loss_type="ce", margin=0.1)
 
+MODES = {
+    # mode: (head, defaults)
+    "train": dict(head="retrieval", n_clips=2, frames=2, size=224, txt_len=32, repeat=2, pool="lse", videos=16),
+    "tgif": dict(head="multiple_choice", n_clips=2, frames=2, size=224, txt_len=25, repeat=5, pool="mean", videos=16),
+    "infer16": dict(head="retrieval", n_clips=16, frames=2, size=224, txt_len=32, repeat=64, pool="lse", videos=1),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--videos", type=int, default=16, help="videos per GPU per step (train_batch_size of msrvtt_ret_base_resnet50.json)")
-    ap.add_argument("--n-clips", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=2)
-    ap.add_argument("--size", type=int, default=224)
-    ap.add_argument("--txt-len", type=int, default=32)
-    ap.add_argument("--repeat", type=int, default=2, help="text examples per video (pos + neg)")
+    ap.add_argument("--mode", choices=sorted(MODES), default="train")
+    ap.add_argument("--videos", type=int, default=None, help="videos per GPU per step (train_batch_size of the JSON config: 16)")
+    ap.add_argument("--n-clips", type=int, default=None)
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--txt-len", type=int, default=None)
+    ap.add_argument("--repeat", type=int, default=None, help="text rows per video (train: pos + neg; tgif: options; infer16: captions per mini-batch)")
+    ap.add_argument("--pool", choices=["mean", "max", "lse"], default=None)
+    ap.add_argument("--no-fold", action="store_true", help="diagnostic: the reference's clip LOOP instead of one folded forward")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--forward-only", action="store_true", help="diagnostic: inference throughput (not the reported metric)")
-    return ap.parse_args()
+    ap.add_argument("--forward-only", action="store_true", help="diagnostic: forward of the training batch only (not the reported metric)")
+    a = ap.parse_args()
+    for k, v in MODES[a.mode].items():
+        if k != "head" and getattr(a, k, None) is None:
+            setattr(a, k, v)
+    a.head = MODES[a.mode]["head"]
+    return a
 
 
 _T0 = time.perf_counter()
@@ -85,81 +112,142 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from clipbert_amd import clips
     from clipbert_amd import modeling as M
-    from clipbert_amd import ops
     from clipbert_amd import synthetic as S
+    from clipbert_amd import tasks
     from clipbert_amd.dist import GradSync
     from clipbert_amd.optim import FusedAdamW
 
     log("imports done")
+    train = args.mode in ("train", "tgif") and not args.forward_only
     cfg = dict(BASE_CONFIG)
-    model = M.ClipBert(cfg, detectron2_model_cfg="R-50-grid.yaml", transformer_cls=M.ClipBertForVideoTextRetrieval)
-    model.load_state_dict(S.full_state_dict(cfg, "retrieval", 42), strict=True)
+    if args.head == "multiple_choice":
+        cfg.update(num_labels=args.repeat, loss_type="ce")
+        cls = M.ClipBertForMultipleChoice
+    else:
+        cls = M.ClipBertForVideoTextRetrieval
+    model = M.ClipBert(cfg, detectron2_model_cfg="R-50-grid.yaml", transformer_cls=cls)
+    model.load_state_dict(S.full_state_dict(cfg, args.head, 42), strict=True)
     model.to(dev)
-    model.train(not args.forward_only)
+    model.train(train)
     model.prepare(dtype=torch.bfloat16, device=dev, overlap_wgrad=os.environ.get("CB_OVERLAP_WGRAD", "0") != "0")
     log("model prepared")
     bank = model.rt.bank
-    sync = GradSync(bank, compress=None if os.environ.get("CB_BENCH_FP32_WIRE") == "1" else "bf16")
-    sync.broadcast_parameters(0)
-    opt = FusedAdamW(bank, lr=5e-5, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0)
-    model.rt.after_encoder_backward = sync.reduce_transformer
 
-    bv, nclip, T = args.videos, args.n_clips, args.frames
-    frames = S.synthetic_frames(bv, nclip * T, args.size, 42 + rank)
-    vis_all = ops_image_norm_host(frames).to(dev)                 # (Bv, nclip*T, 3, S, S) fp32, mean-subtracted
-    ids, mask = S.synthetic_text(bv * args.repeat, args.txt_len, 42 + rank)
+    bv, nclip, T, rep = args.videos, args.n_clips, args.frames, args.repeat
+    # uint8 RGB frames, resident in HBM: ImageNorm (a1) runs inside the step, fused into the stem's input pack
+    frames = S.synthetic_frames(bv, nclip * T, args.size, 42 + rank).to(dev)
+    ids, mask = S.synthetic_text(bv * rep, args.txt_len, 42 + rank)
     ids, mask = ids.to(dev), mask.to(dev)
-    labels = torch.tensor([1, 0] * bv if args.repeat == 2 else [1] * (bv * args.repeat), dtype=torch.long, device=dev)
-    counts = [args.repeat] * bv
-    vis_clips = vis_all.view(bv, nclip, T, 3, args.size, args.size)
+    tcfg = SimpleNamespace(train_n_clips=nclip, inference_n_clips=nclip, num_frm=T, score_agg_func=args.pool, task="action" if args.mode == "tgif" else None,
+                           num_labels=cfg["num_labels"], inference_batch_size=rep, gradient_accumulation_steps=1, learning_rate=5e-5,
+                           cnn_learning_rate=5e-5, decay="linear", cnn_lr_decay="linear", num_train_steps=100000, warmup_ratio=0.1)
+    if args.mode == "tgif":
+        labels = S.synthetic_labels(bv, rep, 42 + rank).to(dev)          # answer id per question
+        counts = [1] * bv                                                # questions per video; x num_labels inside (run_video_qa.py:206)
+    else:
+        labels = torch.tensor(([1] + [0] * (rep - 1)) * bv, dtype=torch.long, device=dev)      # 1 positive + negatives per video
+        counts = [rep] * bv
+    batch = dict(visual_inputs=frames, text_input_ids=ids, text_input_mask=mask, labels=labels, n_examples_list=counts)
+    fold = not args.no_fold
 
+    sync = opt = None
+    if train:
+        sync = GradSync(bank, compress=None if os.environ.get("CB_BENCH_FP32_WIRE") == "1" else "bf16")
+        sync.broadcast_parameters(0)
+        opt = FusedAdamW(bank, lr=5e-5, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0)
+    state = {"global_step": 0}
+
+    # ---- the pieces of a step ------------------------------------------------------------------------------------------
     def forward_loss():
-        logits = []
-        for c in range(nclip):                                    # clip loop of run_video_retrieval.py:396-401
-            batch = dict(visual_inputs=vis_clips[:, c].contiguous() if nclip > 1 else vis_clips[:, 0], text_input_ids=ids,
-                         text_input_mask=mask, n_examples_list=list(counts))
-            logits.append(model(batch)["logits"])
-        lg = logits[0] if nclip == 1 else clips.aggregate_clip_logits(logits, "mean")     # score_agg_func of the JSON config
-        _, loss = model.transformer.calc_loss(lg, labels, sample_size=bv)
-        return loss.mean()
+        stack = tasks.forward_clips_stack(model, batch, nclip, T, fold=fold, cfg=tcfg)       # (n_clips, pairs, C) logits
+        return tasks.training_loss(model, stack, labels, counts, args.pool)                  # clip pooling (a20) + loss
 
-    def train_step():
+    def host_prepare():
+        """per-step host work of a real training loop: LR schedule onto the 8 groups, hyper-parameter upload"""
+        state["global_step"] += 1
+        tasks.set_learning_rates(opt, tcfg, state["global_step"])
+        opt.prepare_step(grad_scale=sync.grad_scale)
+
+    def device_step_single():
+        """everything a 1-GPU step enqueues (capturable)"""
         opt.zero_grad()
+        model.rt.pending_encoder_nodes = 0
         loss = forward_loss()
         loss.backward()
+        model.rt.seed_dev.add_(1)
+        opt.launch()
+        return loss
+
+    def train_step_eager():
+        host_prepare()
+        opt.zero_grad()
+        model.rt.pending_encoder_nodes = 0
+        loss = forward_loss()
+        loss.backward()                         # (N > 1: the transformer buckets leave from inside the encoder backward)
+        if model.rt.after_encoder_backward is None:
+            sync.reduce_transformer()
         sync.reduce_cnn()
         sync.wait()
         model.rt.seed_dev.add_(1)
-        opt.step(grad_scale=sync.grad_scale)
+        opt.launch()
         return loss
 
-    def infer_step():
+    def forward_only_step():
         with torch.no_grad():
             return forward_loss()
 
-    step_fn = infer_step if args.forward_only else train_step
+    infer_rows = []
+
+    def infer_step():
+        sc = tasks.inference_retrieval_video(model, frames[:1], ids[:rep], mask[:rep], tcfg, cache_cnn=True)
+        infer_rows.extend(dict(vid_id=f"r{rank}v{len(infer_rows) // rep}", txt_id=j, score=s) for j, s in enumerate(sc))
+        return None
+
+    def infer_device_step():
+        """the device work of infer_step without the host-side score list (capturable)"""
+        with torch.no_grad():
+            grid = model.grid_features(frames[:1].view(nclip, T, *frames.shape[2:]))
+            out = model.forward_from_grid(dict(visual_inputs=grid, text_input_ids=ids[:rep].repeat(nclip, 1),
+                                               text_input_mask=mask[:rep].repeat(nclip, 1), labels=None, n_examples_list=[rep] * nclip))
+            from clipbert_amd import clips
+            pooled = clips.aggregate_clip_logits(out["logits"].view(nclip, rep, -1), args.pool)
+            if args.pool == "lse":
+                pooled = clips.lse_inference_logits(pooled)
+            state["scores"] = torch.softmax(pooled.float(), dim=1)[:, 1]
+        return None
+
+    if args.mode == "infer16":
+        eager_fn = infer_step
+    elif not train:
+        eager_fn = forward_only_step
+    else:
+        if world > 1:
+            model.rt.after_encoder_backward = sync.reduce_transformer
+        eager_fn = train_step_eager
 
     log("inputs ready")
-    # ---- eager warm-up (also builds pixel tables etc.), then graph capture --------------------------------
+    # ---- eager warm-up (also builds pixel tables etc.) ---------------------------------------------------------------------
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
         for _ in range(2):
-            loss = step_fn()
+            loss = eager_fn()
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
-    log(f"eager warm-up done, loss {float(loss.item()):.4f}")
+    log("eager warm-up done" + (f", loss {float(loss.item()):.4f}" if loss is not None else ""))
+    dp_check = None
+    if train and world > 1:
+        dp_check = dp_self_check(bank, dist, dev)
+        log(f"DP self-check: {dp_check}")
+
     # ---- replay plan -----------------------------------------------------------------------------------------------------
-    #   N = 1          : the whole step in one hipGraph.
-    #   N > 1 (default): three hipGraphs with EAGER RCCL all-reduces (bf16 on the wire) between them; the transformer bucket
-    #                    travels while the ResNet-backward graph runs.  Only this library's kernels are ever captured -- a
-    #                    capture that fails on this stack cannot be recovered from inside the process, so collectives stay
-    #                    out of it.
-    #   CB_BENCH_PLAN=full : N > 1 with the whole step (RCCL calls included) in one hipGraph; the transformer bucket is then
-    #                    issued from inside the backward and overlaps the ResNet backward.  Opt-in until it can be tested
-    #                    on a multi-GPU box.   CB_BENCH_PLAN=eager / --no-graph: no graphs.
+    #   N = 1          : host_prepare (eager) + ONE hipGraph with the whole device step.
+    #   N > 1 (default): host_prepare + three hipGraphs with EAGER RCCL all-reduces (bf16 on the wire, 64 MiB buckets) between
+    #                    them: [zero + forward + heads/encoder backward] -> transformer buckets (async: they cross xGMI while
+    #                    the next graph runs) -> [ResNet backward] -> CNN buckets -> wait -> [clip + AdamW].  Only this
+    #                    library's kernels are captured: collectives stay out of the graphs.
+    #   CB_BENCH_PLAN=eager / --no-graph: no graphs (the hook issues the transformer buckets from inside the backward).
     def capture(fn):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -167,68 +255,89 @@ def main():
         return g, out
 
     plan_env = os.environ.get("CB_BENCH_PLAN", "")
-    run, plan = step_fn, "eager"
-    if not args.no_graph and plan_env != "eager":
-        if world == 1 or args.forward_only or plan_env == "full":
-            g1, loss = capture(step_fn)
-            run, plan = g1.replay, "one hipGraph"
-        else:
-            # [zero + forward + encoder backward] -> transformer bucket (async, crosses xGMI during the next graph) ->
-            # [ResNet backward] -> CNN bucket -> wait -> [clip + AdamW].  The backward is cut at the grid features:
-            # autograd.grad(loss, grid) runs the heads' and the encoder's backward (parameter gradients land in the flat
-            # buffer as a side effect), grid.backward(dgrid) runs the CNN trunk's.
-            assert nclip == 1, "the split replay plan handles one clip per step (the headline config)"
-            state = {}
+    run, plan = eager_fn, "eager"
+    use_graph = not args.no_graph and plan_env != "eager"
+    if use_graph and args.mode == "infer16":
+        g1, _ = capture(infer_device_step)
 
-            def part_a():
-                opt.zero_grad()
-                grid = model.grid_features(vis_clips[:, 0])
-                out = model.forward_from_grid(dict(visual_inputs=grid, text_input_ids=ids, text_input_mask=mask,
-                                                   n_examples_list=list(counts)))
-                _, l = model.transformer.calc_loss(out["logits"], labels, sample_size=bv)
-                loss_ = l.mean()
-                (dgrid,) = torch.autograd.grad(loss_, [grid])
-                state["grid"], state["dgrid"] = grid, dgrid
-                return loss_
+        def run_infer():
+            g1.replay()
+            sc = [round(x, 4) for x in state["scores"].tolist()]           # D2H of the 64 scores: the step's result
+            infer_rows.extend(dict(vid_id=f"r{rank}v{len(infer_rows) // rep}", txt_id=j, score=x) for j, x in enumerate(sc))
+        run, plan = run_infer, "one hipGraph per (video, caption mini-batch) + score read-back"
+    elif use_graph and not train:
+        g1, loss = capture(forward_only_step)
+        run, plan = g1.replay, "one hipGraph"
+    elif use_graph and world == 1:
+        g1, loss = capture(device_step_single)
 
-            def part_b():
-                state["grid"].backward(state["dgrid"])
+        def run_single():
+            host_prepare()
+            g1.replay()
+        run, plan = run_single, "eager hyper-parameter upload + one hipGraph"
+    elif use_graph:
+        # The backward is cut at the grid features: autograd.grad(loss, grid) runs the heads' and the encoder's backward
+        # (parameter gradients land in the flat buffer as a side effect), grid.backward(dgrid) runs the CNN trunk's.
+        model.rt.after_encoder_backward = None                 # collectives are issued between the graphs, eagerly
+        cut = {}
 
-            def part_c():
-                model.rt.seed_dev.add_(1)
-                opt.step(grad_scale=sync.grad_scale)
+        def part_a():
+            opt.zero_grad()
+            model.rt.pending_encoder_nodes = 0
+            vis = frames.view(bv * nclip, T, *frames.shape[2:]) if (fold and nclip > 1) else frames
+            assert fold or nclip == 1, "the split replay plan needs the folded clip forward (one encoder node)"
+            grid = model.grid_features(vis)
+            mini = dict(visual_inputs=grid, text_input_ids=ids.repeat(nclip, 1) if nclip > 1 else ids,
+                        text_input_mask=mask.repeat(nclip, 1) if nclip > 1 else mask, labels=None,
+                        n_examples_list=tasks._pair_counts(tcfg, counts))
+            lg = model.forward_from_grid(mini, clip_fold=nclip)["logits"]
+            stack = lg.reshape(nclip, lg.shape[0] // nclip, *lg.shape[1:])
+            loss_ = tasks.training_loss(model, stack, labels, counts, args.pool)
+            (dgrid,) = torch.autograd.grad(loss_, [grid])
+            cut["grid"], cut["dgrid"] = grid, dgrid
+            return loss_
 
-            model.rt.after_encoder_backward = None                 # collectives are issued between the graphs, eagerly
-            ga, loss = capture(part_a)
-            gb, _ = capture(part_b)
-            gc, _ = capture(part_c)
+        def part_b():
+            cut["grid"].backward(cut["dgrid"])
 
-            def run_split():
-                ga.replay()
-                sync.reduce_transformer()
-                gb.replay()
-                sync.reduce_cnn()
-                sync.wait()
-                gc.replay()
-            run, plan = run_split, "three hipGraphs, eager bf16 all-reduces (transformer bucket overlaps the ResNet backward)"
-    graph = None if plan == "eager" else True
+        def part_c():
+            model.rt.seed_dev.add_(1)
+            opt.launch()
+
+        ga, loss = capture(part_a)
+        gb, _ = capture(part_b)
+        gc, _ = capture(part_c)
+
+        def run_split():
+            host_prepare()
+            ga.replay()
+            sync.reduce_transformer()
+            gb.replay()
+            sync.reduce_cnn()
+            sync.wait()
+            gc.replay()
+        run, plan = run_split, "three hipGraphs, eager bucketed bf16 all-reduces (transformer buckets overlap the ResNet backward)"
     log(f"replay plan: {plan}")
 
     # clock / power-state settling (untimed, before the W warm-up steps): right after process start the first replays run
     # ~15 % slow on some boxes; ~0.75 s of steady replays brings the GPU to its sustained clocks
     # (a FIXED number of replays: with N > 1 every rank must issue the same number of collectives)
-    for _ in range(12):
-        for _ in range(8):
+    for _ in range(8):
+        for _ in range(6):
             run()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         run()
+    infer_rows.clear()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
+    gathered = None
+    if args.mode == "infer16":
+        gathered = tasks.gather_retrieval_rows(infer_rows)              # the job's only exchange: (vid, txt, score) rows
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -240,22 +349,45 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     clips_per_step = bv * nclip * world
     value = clips_per_step / (elapsed / args.steps)
-    final_loss = float(loss.item()) if loss is not None else float("nan")
+    final_loss = float(loss.item()) if loss is not None else None
     log(f"timed region done: {ms_per_step:.3f} ms/step, {value:.1f} clips/s")
 
+    pairs = bv * rep * nclip
+    if args.mode == "train" and not args.forward_only:
+        metric = "clips/sec/node (2×2 frames, 224px, L_txt=32) at 1/2/4/8 MI355X"
+        if (nclip, T, args.size, args.txt_len) != (2, 2, 224, 32):
+            metric = f"clips/sec/node ({nclip}×{T} frames, {args.size}px, L_txt={args.txt_len}) -- NOT the BASELINE.json shape (diagnostic)"
+        workload = (f"MSRVTT retrieval training step (msrvtt_ret_base_resnet50.json; BASELINE configs[1]/[2] family) at the metric's shape: "
+                    f"{bv} videos x N_clip={nclip} x N_frame={T} uint8 frames {args.size}px + {rep} texts/video (pos+neg, r={rep}) L_txt={args.txt_len} "
+                    f"per GPU = {bv * nclip} clips, {bv * nclip * T} frames, {pairs} (text, clip) pairs per step; ImageNorm + fwd + "
+                    f"{args.pool}-pooling loss + bwd + all-reduce + clip + AdamW in the timed step; clips {'folded into one forward' if fold else 'looped'}")
+    elif args.mode == "tgif" and not args.forward_only:
+        metric = f"clips/sec/node, TGIF-QA action training ({nclip}×{T} frames, {args.size}px, L_txt={args.txt_len}, {rep} options) -- BASELINE configs[3] row"
+        workload = (f"BASELINE configs[3]: TGIF-QA action training step (ClipBertForMultipleChoice), {bv} videos x N_clip={nclip} x N_frame={T} "
+                    f"frames {args.size}px, {rep} options/question L_txt={args.txt_len} = {pairs} pairs per GPU per step, {args.pool} pooling")
+    elif args.mode == "infer16":
+        metric = f"clips/sec/node, retrieval inference ({nclip} clips × {T} frames, {args.size}px, {rep}-caption mini-batches) -- BASELINE configs[4] row"
+        workload = (f"BASELINE configs[4]: retrieval inference, per step 1 video x {nclip} clips x {T} frames {args.size}px against {rep} captions "
+                    f"L_txt={args.txt_len} per GPU (CNN once per video, {nclip * rep} pairs in one encoder batch, {args.pool} pooling, scores rounded to 4 "
+                    f"places and read back); videos sharded over ranks, one gather of the score rows at the end of the timed region")
+    else:
+        metric = "clips/sec/node forward-only (diagnostic)"
+        workload = f"forward of the {args.mode} batch only"
     out = {
-        "metric": "clips/sec/node (2\u00d72 frames, 224px, L_txt=32) at 1/2/4/8 MI355X" if not args.forward_only else "clips/sec/node forward-only (diagnostic)",
-        "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": metric, "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: MSRVTT retrieval training step (fwd+bwd+allreduce+clip+AdamW), "
-                               f"{bv} videos x {nclip} clip x {T} frames {args.size}px + {args.repeat} texts L_txt={args.txt_len} per GPU",
-                   "videos_per_gpu": bv, "n_clips": nclip, "n_frames": T, "img_size": args.size, "txt_len": args.txt_len,
-                   "texts_per_video": args.repeat, "parallelism": f"dp{world}", "hip_graph": graph is not None, "replay_plan": plan,
-                   "dropout": not args.forward_only, "final_loss": round(final_loss, 5)},
+        "config": {"workload": workload, "mode": args.mode, "videos_per_gpu": bv, "n_clips": nclip, "n_frames": T, "img_size": args.size,
+                   "txt_len": args.txt_len, "texts_per_video": rep, "pairs_per_gpu": pairs, "score_agg_func": args.pool, "clips_folded": fold,
+                   "input": "uint8 frames in HBM", "parallelism": f"dp{world}", "hip_graph": use_graph, "replay_plan": plan,
+                   "dropout": bool(train), "final_loss": None if final_loss is None else round(final_loss, 5)},
     }
+    if dp_check is not None:
+        out["config"]["dp_self_check"] = dp_check
+    if gathered is not None:
+        out["config"]["rows_gathered"] = len(gathered)
     if rank == 0 and world == 1 and not args.no_roofline:
-        out["roofline"] = measure_roofline(step_fn)
+        out["roofline"] = measure_roofline(eager_fn if args.mode != "infer16" else infer_device_step)
         log("roofline measured")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, args)
@@ -265,10 +397,15 @@ def main():
         dist.destroy_process_group()
 
 
-def ops_image_norm_host(frames_u8):
-    """ImageNorm of the synthetic frames (done once, outside the timed region): uint8 -> fp32 - mean."""
-    mean = torch.tensor([123.675, 116.28, 103.53]).view(1, 1, 3, 1, 1)
-    return frames_u8.float() - mean
+def dp_self_check(bank, dist, dev):
+    """After one eager data-parallel step every rank must hold identical parameters (same all-reduced gradients, same
+    AdamW update): compares an order-independent checksum of the fp32 masters across the ranks."""
+    local = torch.stack([bank.master.double().sum(), bank.master.double().abs().sum()]).to(dev)
+    lo, hi = local.clone(), local.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    same = bool(torch.equal(lo, hi))
+    return "ok: parameters identical on all ranks after a step" if same else f"MISMATCH: checksums differ across ranks ({lo.tolist()} vs {hi.tolist()})"
 
 
 def measure_roofline(step_fn):
@@ -328,52 +465,75 @@ def measure_roofline(step_fn):
     dom = max(agg.items(), key=lambda kv: kv[1][1])
     achieved = dom[1][0] / dom[1][1] / 1e12
     # HBM bytes per launch of that kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-    # separate runs, gfx950 correction applied -- profiles/r01_pmc_traffic.json); null when no PMC data is committed
-    traffic = None
+    # separate runs, gfx950 correction applied -- profiles/r02_pmc_traffic.json); null when no PMC data is committed
+    traffic, over = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-            traffic = json.load(fh)["families"][dom[0]]["hbm_bytes_per_launch"]
+        with open(PMC_TRAFFIC_FILE) as fh:
+            fam = json.load(fh)["families"][dom[0]]
+        traffic, over = fam["hbm_bytes_per_launch"], fam.get("hbm_over_algorithmic")
     except Exception:
         traffic = None
     return {"bound": "mfma", "kernel": dom[0], "launches": dom[1][2], "avg_launch_us": round(dom[1][1] / dom[1][2] * 1e6, 2),
             "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
+            "traffic": traffic, "traffic_unit": f"HBM bytes per launch (PMC, {os.path.relpath(PMC_TRAFFIC_FILE, ROOT)})",
+            "hbm_over_algorithmic": over,
             "algorithmic_flop_per_launch": round(dom[1][0] / dom[1][2]),
-            "all_gemm_kernels": {"achieved": round(tot_fl / tot_t / 1e12, 2), "time_ms": round(tot_t * 1e3, 3),
-                                 "gflop_per_step": round(tot_fl / 1e9, 1)},
+            "all_gemm_kernels": {"achieved": round(tot_fl / tot_t / 1e12, 2), "frac": round(tot_fl / tot_t / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+                                 "time_ms": round(tot_t * 1e3, 3), "gflop_per_step": round(tot_fl / 1e9, 1)},
             "by_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms": round(v[1] * 1e3, 3), "launches": v[2]} for k, v in agg.items()}}
 
 
 def cpu_baseline(cfg, args):
-    """The CPU oracle (port of the reference arithmetic in stock PyTorch fp32) on a bounded sample of the
-    same workload: 2 videos x 2 frames + 4 texts, forward + backward, this host's cores."""
+    """The CPU oracle (port of the reference arithmetic in stock PyTorch fp32) on a bounded sample of the same workload --
+    2 videos of the step's shape, the reference's clip LOOP, pooled loss; forward + backward (training modes) or forward only
+    (infer16) -- on this host's cores."""
     from clipbert_amd import synthetic as S
     from oracle import clipbert_oracle as O
     ncores = min(os.cpu_count() or 1, 32)      # more threads than this only adds contention for 4-frame convs
     torch.set_num_threads(ncores)
-    sd = S.full_state_dict(cfg, "retrieval", 42)
-    sd = {k: v.clone().requires_grad_(v.is_floating_point() and ".norm." not in k and "stem" not in k and "res2" not in k) for k, v in sd.items()}
-    nv = 2
-    frames = S.synthetic_frames(nv, args.frames, args.size, 42)
-    ids, mask = S.synthetic_text(nv * args.repeat, args.txt_len, 42)
-    batch = dict(visual_inputs=O.image_norm(frames, S.PIXEL_MEAN, S.PIXEL_STD), text_input_ids=ids, text_input_mask=mask,
-                 n_examples_list=[args.repeat] * nv, labels=torch.tensor([1, 0] * nv)[: nv * args.repeat])
+    train = args.mode != "infer16"
+    sd = S.full_state_dict(cfg, args.head, 42)
+    sd = {k: v.clone().requires_grad_(train and v.is_floating_point() and ".norm." not in k and "stem" not in k and "res2" not in k)
+          for k, v in sd.items()}
+    nv = 1 if args.mode == "infer16" else 2
+    nclip = min(args.n_clips, 2) if args.mode == "infer16" else args.n_clips
+    rep = min(args.repeat, 8) if args.mode == "infer16" else args.repeat
+    frames = S.synthetic_frames(nv, nclip * args.frames, args.size, 42)
+    ids, mask = S.synthetic_text(nv * rep, args.txt_len, 42)
+    vis = O.image_norm(frames, S.PIXEL_MEAN, S.PIXEL_STD).view(nv, nclip, args.frames, 3, args.size, args.size)
+    if args.mode == "tgif":
+        labels = S.synthetic_labels(nv, rep, 42)
+    else:
+        labels = torch.tensor(([1] + [0] * (rep - 1)) * nv)
 
     def one():
-        out = O.clipbert_forward(sd, batch, cfg, "retrieval")
-        out["loss"].mean().backward()
+        per_clip = []
+        for c in range(nclip):                                # the reference's clip loop (run_video_retrieval.py:396-401)
+            b = dict(visual_inputs=vis[:, c], text_input_ids=ids, text_input_mask=mask, n_examples_list=[rep] * nv)
+            per_clip.append(O.clipbert_forward(sd, b, cfg, args.head)["logits"])
+        pooled = O.aggregate_clip_logits(per_clip, args.pool)
+        if not train:
+            return
+        if args.pool == "lse":
+            loss = O.lse_train_loss(pooled, labels).mean()
+        else:
+            loss = torch.nn.functional.cross_entropy(pooled.view(-1, rep) if args.mode == "tgif" else pooled, labels)
+        loss.backward()
 
-    one()                                   # warm-up
-    times = []
-    t_budget = time.perf_counter()
-    while len(times) < 5 and time.perf_counter() - t_budget < 25:
-        t0 = time.perf_counter()
-        one()
-        times.append(time.perf_counter() - t0)
+    ctx = torch.enable_grad() if train else torch.no_grad()
+    with ctx:
+        one()                                   # warm-up
+        times = []
+        t_budget = time.perf_counter()
+        while len(times) < 5 and time.perf_counter() - t_budget < 25:
+            t0 = time.perf_counter()
+            one()
+            times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
-    return {"value": round(nv / med, 3), "unit": "clips/s", "cores": ncores, "kind": "port",
-            "sample": f"{nv} videos x {args.frames} frames {args.size}px + {nv * args.repeat} texts, fwd+bwd (no optimizer), "
-                      f"median of {len(times)} iterations, torch {torch.__version__} fp32, {ncores} threads"}
+    return {"value": round(nv * nclip / med, 3), "unit": "clips/s", "cores": ncores, "kind": "port",
+            "sample": f"{nv} videos x {nclip} clips x {args.frames} frames {args.size}px + {nv * rep} texts L_txt={args.txt_len}, "
+                      f"{'fwd+bwd (no optimizer)' if train else 'forward only'}, clip loop as in the reference, median of {len(times)} iterations, "
+                      f"torch {torch.__version__} fp32, {ncores} threads"}
 
 
 if __name__ == "__main__":

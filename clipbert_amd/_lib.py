@@ -27,7 +27,7 @@ class GemmDesc(C.Structure):
         ("split_k", i32), ("act", i32), ("scale", vp), ("shift", vp), ("residual", vp), ("ldr", i64),
         ("relu_after", i32), ("reserved1", i32), ("mask", vp), ("ldm", i64), ("C2", vp), ("ldc2", i64),
         ("alpha", f32), ("dropout_p", f32), ("dropout_seed", u64), ("dropout_seed_ptr", vp), ("tile", i32),
-        ("reserved2", i32), ("a_bytes", i64), ("b_bytes", i64), ("gelu_grad_pre", vp), ("ld_gelu", i64), ("a_rowsum", vp),
+        ("xcd_order", i32), ("a_bytes", i64), ("b_bytes", i64), ("gelu_grad_pre", vp), ("ld_gelu", i64), ("a_rowsum", vp),
         ("batch", i32), ("relu_bwd", i32), ("batch_stride_a", i64), ("batch_stride_b", i64), ("batch_stride_c", i64),
         ("batch_stride_rowsum", i64), ("post_scale", vp), ("post_scale2", vp),
     ]

@@ -30,7 +30,15 @@ extern template int launch_gemm<float, 64, 64, 2>(const GP&, bool, hipStream_t);
 extern template int launch_gemm<bf16, 128, 128, 2>(const GP&, bool, hipStream_t);
 extern template int launch_gemm<bf16, 128, 64, 2>(const GP&, bool, hipStream_t);
 extern template int launch_gemm<bf16, 64, 64, 3>(const GP&, bool, hipStream_t);
+extern template int launch_gemm<bf16, 256, 128, 2>(const GP&, bool, hipStream_t);
+extern template int launch_gemm<bf16, 256, 64, 2>(const GP&, bool, hipStream_t);
+extern template int launch_gemm<bf16, 128, 128, 1, 2>(const GP&, bool, hipStream_t);
 }
+
+// Per-shape launch configurations measured on MI355X (tools/tune_gemm.py sweeps every cb_gemm call of the benchmark
+// steps over tile x workgroup order, tools/gen_tuned.py writes the table): consulted when the caller leaves tile /
+// xcd_order at 0 (auto); shapes that are not in the table fall through to the heuristics below.
+#include "gemm_tuned.h"
 
 namespace {
 
@@ -161,11 +169,21 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     static const bool no_wide = getenv("CB_GEMM_NO_WIDE_EPILOGUE") != nullptr;
     p.c_vec8 = cv8 && !no_wide;
     static const bool no_remap = getenv("CB_GEMM_NO_XCD_REMAP") != nullptr;
-    p.xcd_remap = !no_remap && p.split_k > 1;   // measured: helps K-split grids (each XCD streams its own K slices), hurts plain M x N grids
+    static const bool no_tuned = getenv("CB_GEMM_NO_TUNED") != nullptr;
+    CB_REQUIRE(d->tile >= 0 && d->tile <= 6, "cb_gemm: bad tile %d", d->tile);
+    CB_REQUIRE(d->xcd_order >= 0 && d->xcd_order <= 2, "cb_gemm: bad xcd_order %d", d->xcd_order);
+    int tile = d->tile, xcd = d->xcd_order;
+    if (d->dtype == CB_BF16 && !no_tuned && (tile == 0 || xcd == 0)) {
+        if (const cbgemm::TunedEntry* e = cbgemm::tuned_lookup(d->a_mode, d->b_mode, d->M, d->N, d->K, p.batch, p.R * p.S, p.split_k)) {
+            if (tile == 0) tile = e->tile;
+            if (xcd == 0) xcd = e->xcd;
+        }
+    }
+    // default order: XCD-compact for K-split grids (each XCD streams its own K slices), dispatch order for plain M x N grids
+    p.xcd_remap = !no_remap && (xcd == 1 || (xcd == 0 && p.split_k > 1));
 
     hipStream_t st = cb_stream(stream);
     if (d->dtype == CB_F32) return launch_gemm<float, 64, 64, 2>(p, fast, st);
-    int tile = d->tile;
     if (tile == 0) {
         int64_t blocks128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * p.split_k * p.batch;
         tile = blocks128 >= 448 ? 1 : 2;               // below ~2 blocks per CU the 64x64 tile fills the chip better
@@ -173,6 +191,11 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
         if (d->N <= 64 && (int64_t)((d->M + 127) / 128) * p.split_k * p.batch >= 448) tile = 3;
     }
     if (tile == 1 && d->N <= 64) tile = 3;           // narrow outputs (stem / res2 convs): 128x64 tile
+    if (tile == 4 && d->N <= 64) tile = 5;
+    if (tile == 6 && d->N <= 64) tile = 3;
+    if (tile == 6) return launch_gemm<bf16, 128, 128, 1, 2>(p, fast, st);
+    if (tile == 4) return launch_gemm<bf16, 256, 128, 2>(p, fast, st);
+    if (tile == 5) return launch_gemm<bf16, 256, 64, 2>(p, fast, st);
     if (tile == 1) return launch_gemm<bf16, 128, 128, 2>(p, fast, st);
     if (tile == 3) return launch_gemm<bf16, 128, 64, 2>(p, fast, st);
     return launch_gemm<bf16, 64, 64, 3>(p, fast, st);

@@ -963,8 +963,10 @@ __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 
 }
 
 
-template <typename T, int BM, int BN, typename LA, typename LB, int PF, bool RS = false>
-__global__ void __launch_bounds__(256) gemm_kernel(GP p) {
+// OCC = blocks per CU the register allocation must leave room for (__launch_bounds__'s second argument counts waves per SIMD;
+// a 256-thread block puts one wave on each SIMD)
+template <typename T, int BM, int BN, typename LA, typename LB, int PF, bool RS = false, int OCC = 1>
+__global__ void __launch_bounds__(256, OCC) gemm_kernel(GP p) {
     using X = Tr<T>;
     constexpr int BK = X::BK;
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
@@ -1348,21 +1350,21 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(GP p) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <typename T, int BM, int BN, int PF, typename LA, typename LB, bool RS = false>
+template <typename T, int BM, int BN, int PF, int OCC, typename LA, typename LB, bool RS = false>
 int launch_k(const GP& p, hipStream_t st) {
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.split_k * (p.batch > 1 ? p.batch : 1));
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, LA, LB, PF, RS>), grid, dim3(NTHREADS), 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, LA, LB, PF, RS, OCC>), grid, dim3(NTHREADS), 0, st, p);
     return cb_launch_status("cb_gemm");
 }
 // weight-gradient form (both operands KROW): with or without the fused row sums of A
-template <typename T, int BM, int BN, int PF, typename LA, typename LB>
+template <typename T, int BM, int BN, int PF, int OCC, typename LA, typename LB>
 int launch_wgrad(const GP& p, hipStream_t st) {
-    if (p.a_rowsum) return launch_k<T, BM, BN, PF, LA, LB, true>(p, st);
-    return launch_k<T, BM, BN, PF, LA, LB, false>(p, st);
+    if (p.a_rowsum) return launch_k<T, BM, BN, PF, OCC, LA, LB, true>(p, st);
+    return launch_k<T, BM, BN, PF, OCC, LA, LB, false>(p, st);
 }
 
 // addressing-mode dispatch: lean compile-time loaders on the fast path, the generic loaders otherwise
-template <typename T, int BM, int BN, int PF>
+template <typename T, int BM, int BN, int PF, int OCC = 1>
 int launch_gemm(const GP& p, bool fast, hipStream_t st) {
     const bool a_krow = p.a_mode == CB_KROW;
     const bool b_krow = p.b_mode != CB_ROWK;
@@ -1412,36 +1414,36 @@ int launch_gemm(const GP& p, bool fast, hipStream_t st) {
             // transpose-read image wins for both tile sizes (profiles/r01_gemm_microbench.md)
             if constexpr (BN < 128) {
                 if (p.a_mode == CB_ROWK && (p.b_mode == CB_KROW || (p.b_mode == CB_KROW_TAPS && taps == 1)))
-                    return launch_k<T, BM, BN, PF, RowkFast<T, BM, false>, KrowTr<BN, KM_PLAIN>>(p, st);
+                    return launch_k<T, BM, BN, PF, OCC, RowkFast<T, BM, false>, KrowTr<BN, KM_PLAIN>>(p, st);
                 if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_KROW_TAPS && p.Ct % Tr<bf16>::BK == 0)
-                    return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, KrowTr<BN, KM_TAPS>>(p, st);
+                    return launch_k<T, BM, BN, PF, OCC, RowkFast<T, BM, true>, KrowTr<BN, KM_TAPS>>(p, st);
             }
             if (p.a_mode == CB_KROW && p.b_mode == CB_KROW)
-                return launch_wgrad<T, BM, BN, PF, KrowTr<BM, KM_PLAIN>, KrowTr<BN, KM_PLAIN>>(p, st);
+                return launch_wgrad<T, BM, BN, PF, OCC, KrowTr<BM, KM_PLAIN>, KrowTr<BN, KM_PLAIN>>(p, st);
             if (p.a_mode == CB_KROW && p.b_mode == CB_KROW_GATHER)
-                return launch_k<T, BM, BN, PF, KrowTr<BM, KM_PLAIN>, KrowTr<BN, KM_GATHER>>(p, st);
+                return launch_k<T, BM, BN, PF, OCC, KrowTr<BM, KM_PLAIN>, KrowTr<BN, KM_GATHER>>(p, st);
         }
         if (p.a_mode == CB_ROWK && p.b_mode == CB_ROWK)
-            return launch_k<T, BM, BN, PF, RowkFast<T, BM, false>, RowkFast<T, BN, false>>(p, st);
+            return launch_k<T, BM, BN, PF, OCC, RowkFast<T, BM, false>, RowkFast<T, BN, false>>(p, st);
         if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_ROWK)
-            return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, RowkFast<T, BN, false>>(p, st);
+            return launch_k<T, BM, BN, PF, OCC, RowkFast<T, BM, true>, RowkFast<T, BN, false>>(p, st);
         // fp32 parity mode (and odd channel counts): register-transposing loaders.  One KROW operand next to a ROWK
         // one is spread over all 256 threads; two KROW operands take half the threads each (B shifted by 128)
         constexpr int KB1B = BN >= 128 ? 4 : 2;
         constexpr int KB2A = BM >= 128 ? 8 : 4, KB2B = BN >= 128 ? 8 : 4;
         if (p.a_mode == CB_ROWK && (p.b_mode == CB_KROW || (p.b_mode == CB_KROW_TAPS && taps == 1)))
-            return launch_k<T, BM, BN, PF, RowkFast<T, BM, false>, KrowFast<T, BN, KM_PLAIN, KB1B, 0>>(p, st);
+            return launch_k<T, BM, BN, PF, OCC, RowkFast<T, BM, false>, KrowFast<T, BN, KM_PLAIN, KB1B, 0>>(p, st);
         if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_KROW_TAPS)
-            return launch_k<T, BM, BN, PF, RowkFast<T, BM, true>, KrowFast<T, BN, KM_TAPS, KB1B, 0>>(p, st);
+            return launch_k<T, BM, BN, PF, OCC, RowkFast<T, BM, true>, KrowFast<T, BN, KM_TAPS, KB1B, 0>>(p, st);
         if (p.a_mode == CB_KROW && p.b_mode == CB_KROW)
-            return launch_wgrad<T, BM, BN, PF, KrowFast<T, BM, KM_PLAIN, KB2A, 0>, KrowFast<T, BN, KM_PLAIN, KB2B, 128>>(p, st);
+            return launch_wgrad<T, BM, BN, PF, OCC, KrowFast<T, BM, KM_PLAIN, KB2A, 0>, KrowFast<T, BN, KM_PLAIN, KB2B, 128>>(p, st);
         if (p.a_mode == CB_KROW && p.b_mode == CB_KROW_GATHER)
-            return launch_k<T, BM, BN, PF, KrowFast<T, BM, KM_PLAIN, KB2A, 0>, KrowFast<T, BN, KM_GATHER, KB2B, 128>>(p, st);
+            return launch_k<T, BM, BN, PF, OCC, KrowFast<T, BM, KM_PLAIN, KB2A, 0>, KrowFast<T, BN, KM_GATHER, KB2B, 128>>(p, st);
     }
-    if (!a_krow && !b_krow) return launch_k<T, BM, BN, PF, RowkLoader<T, BM, false>, RowkLoader<T, BN, false>>(p, st);
-    if (!a_krow) return launch_k<T, BM, BN, PF, RowkLoader<T, BM, false>, KrowLoader<T, BN, false>>(p, st);
-    if (p.b_mode == CB_KROW) return launch_wgrad<T, BM, BN, PF, KrowLoader<T, BM, false>, KrowLoader<T, BN, false>>(p, st);
-    return launch_k<T, BM, BN, PF, KrowLoader<T, BM, false>, KrowLoader<T, BN, false>>(p, st);
+    if (!a_krow && !b_krow) return launch_k<T, BM, BN, PF, OCC, RowkLoader<T, BM, false>, RowkLoader<T, BN, false>>(p, st);
+    if (!a_krow) return launch_k<T, BM, BN, PF, OCC, RowkLoader<T, BM, false>, KrowLoader<T, BN, false>>(p, st);
+    if (p.b_mode == CB_KROW) return launch_wgrad<T, BM, BN, PF, OCC, KrowLoader<T, BM, false>, KrowLoader<T, BN, false>>(p, st);
+    return launch_k<T, BM, BN, PF, OCC, KrowLoader<T, BM, false>, KrowLoader<T, BN, false>>(p, st);
 }
 
 

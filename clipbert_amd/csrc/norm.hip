@@ -73,25 +73,42 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const T* x, const fl
     }
 }
 
-// Each wave walks rows with stride gridDim*4; dgamma/dbeta partials stay in registers, are combined
-// across the block's 4 waves through LDS and flushed with one atomic per element per block.
-template <typename T, int MAXCH>
-__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
-                                                            const float* rstd, T* dx, float* dgamma, float* dbeta,
-                                                            int64_t rows, int D, T* dx2, float drop_p, uint64_t seed,
-                                                            const uint64_t* seed_ptr, int seg_len, int seg_stride, int seg_off) {
-    __shared__ float red[2][4][256];
-    if (dx2 && seed_ptr) seed += *seed_ptr;   // [gamma|beta][wave][one 256-element chunk]
+// Each wave walks rows with stride gridDim*NW; dgamma/dbeta partials stay in registers, are combined across the block's
+// NW waves through LDS and flushed with one atomic per element per block.  NW = 16 (1024 threads) for the encoder's
+// token counts: the 2*D atomics per block bound the number of blocks (~128), so rows in flight come from waves per block --
+// with 4 waves a 2624-row problem made every wave walk 5 rows one after the other (two dependent reductions and a
+// load round trip each); with 16 it is 1-2, and the next row's loads are issued before the current row's reductions.
+template <typename T, int MAXCH, int NW>
+__global__ void __launch_bounds__(NW * 64) layernorm_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
+                                                               const float* rstd, T* dx, float* dgamma, float* dbeta,
+                                                               int64_t rows, int D, T* dx2, float drop_p, uint64_t seed,
+                                                               const uint64_t* seed_ptr, int seg_len, int seg_stride, int seg_off) {
+    __shared__ float red[2][NW][256];          // [gamma|beta][wave][one 256-element chunk]
+    if (dx2 && seed_ptr) seed += *seed_ptr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 ag[MAXCH], ab[MAXCH];
 #pragma unroll
     for (int c = 0; c < MAXCH; ++c) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; ag[c] = z; ab[c] = z; }
-    for (int64_t lrow = (int64_t)blockIdx.x * 4 + wave; lrow < rows; lrow += (int64_t)gridDim.x * 4) {
-        const int64_t row = seg_len > 0 ? (lrow / seg_len) * seg_stride + seg_off + lrow % seg_len : lrow;
-        f32x4 g[MAXCH], xv[MAXCH];
+    const int64_t stride = (int64_t)gridDim.x * NW;
+    auto phys = [&](int64_t lrow) { return seg_len > 0 ? (lrow / seg_len) * seg_stride + seg_off + lrow % seg_len : lrow; };
+    int64_t lrow = (int64_t)blockIdx.x * NW + wave;
+    f32x4 g[MAXCH], xv[MAXCH], gn[MAXCH], xn[MAXCH];
+    float mu = 0.f, rs = 0.f, mun = 0.f, rsn = 0.f;
+    int64_t row = 0, rown = 0;
+    if (lrow < rows) {
+        row = phys(lrow);
         load_row(dy + row * D, D, lane, g);
         load_row(x + row * D, D, lane, xv);
-        const float mu = mean[row], rs = rstd[row];
+        mu = mean[row]; rs = rstd[row];
+    }
+    for (; lrow < rows; lrow += stride) {
+        const bool more = lrow + stride < rows;
+        if (more) {                               // software prefetch of the wave's next row
+            rown = phys(lrow + stride);
+            load_row(dy + rown * D, D, lane, gn);
+            load_row(x + rown * D, D, lane, xn);
+            mun = mean[rown]; rsn = rstd[rown];
+        }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int c = 0; c < MAXCH; ++c) {
@@ -124,8 +141,13 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* dy, const T
                 }
             }
         }
+        if (more) {
+#pragma unroll
+            for (int c = 0; c < MAXCH; ++c) { g[c] = gn[c]; xv[c] = xn[c]; }
+            mu = mun; rs = rsn; row = rown;
+        }
     }
-    // block reduction of the parameter gradients, chunk by chunk (LDS: 2 x 4 waves x 256 floats)
+    // block reduction of the parameter gradients, chunk by chunk (LDS: 2 x NW waves x 256 floats)
 #pragma unroll
     for (int c = 0; c < MAXCH; ++c) {
         if (c * 256 >= D) break;
@@ -136,13 +158,26 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* dy, const T
             red[1][wave][lane * 4 + i] = ab[c][i];
         }
         __syncthreads();
-        int e = threadIdx.x;                        // 256 threads <-> 256 elements of this chunk
-        int col = c * 256 + e;
-        if (col < D) {
-            float sg = red[0][0][e] + red[0][1][e] + red[0][2][e] + red[0][3][e];
-            float sb = red[1][0][e] + red[1][1][e] + red[1][2][e] + red[1][3][e];
-            atomicAdd(dgamma + col, sg);
-            atomicAdd(dbeta + col, sb);
+        if constexpr (NW * 64 >= 512) {                 // threads 0..511 <-> (kind, element): one atomic per element per block
+            if (threadIdx.x < 512) {
+                const int e = threadIdx.x & 255, kind = threadIdx.x >> 8;
+                const int col = c * 256 + e;
+                if (col < D) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) sacc += red[kind][w][e];
+                    atomicAdd((kind ? dbeta : dgamma) + col, sacc);
+                }
+            }
+        } else {
+            const int e = threadIdx.x, col = c * 256 + e;
+            if (col < D) {
+                float sg = 0.f, sb = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { sg += red[0][w][e]; sb += red[1][w][e]; }
+                atomicAdd(dgamma + col, sg);
+                atomicAdd(dbeta + col, sb);
+            }
         }
     }
 }
@@ -320,10 +355,19 @@ template <typename T, int NCH>
 void run_ln_bwd(hipStream_t st, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                 float* dgamma, float* dbeta, int64_t rows, int D, void* dx2, float p, uint64_t seed, const uint64_t* seed_ptr,
                 int seg_len, int seg_stride, int seg_off) {
-    unsigned blocks = nblk(rows, 4);
     static const unsigned cap = getenv("CB_LN_BWD_BLOCKS") ? (unsigned)atoi(getenv("CB_LN_BWD_BLOCKS")) : 128u;
+    if constexpr (NCH <= 4) {
+        if (rows >= 1024) {                  // many rows: 16 waves per block (see the kernel comment)
+            unsigned blocks = nblk(rows, 16);
+            if (blocks > cap) blocks = cap;
+            hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH, 16>), dim3(blocks), dim3(1024), 0, st, (const T*)dy, (const T*)x, gamma, mean,
+                               rstd, (T*)dx, dgamma, dbeta, rows, D, (T*)dx2, p, seed, seed_ptr, seg_len, seg_stride, seg_off);
+            return;
+        }
+    }
+    unsigned blocks = nblk(rows, 4);
     if (blocks > cap) blocks = cap;          // every block ends with 2*D atomics: keep them few
-    hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd,
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH, 4>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd,
                        (T*)dx, dgamma, dbeta, rows, D, (T*)dx2, p, seed, seed_ptr, seg_len, seg_stride, seg_off);
 }
 template <typename T, int NCH>

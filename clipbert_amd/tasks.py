@@ -178,6 +178,46 @@ def inference_retrieval_video(model, visual_inputs: torch.Tensor, text_input_ids
     return scores
 
 
+def shard_for_rank(n_items: int, rank: int, world: int) -> range:
+    """Items (videos) of this rank: a strided partition, what DistributedSampler(shuffle=False) hands out without padding
+    (no duplicated videos: the reference's eval_retrieval drops duplicates anyway, :574-577)."""
+    return range(rank, n_items, world)
+
+
+def gather_retrieval_rows(rows: List[Dict], group=None) -> List[Dict]:
+    """All ranks' dict(vid_id, txt_id, score) rows on every rank, in rank order -- the exchange the reference does through
+    per-rank JSON files on shared storage (:696-724); here ONE all-gather of a compact (ids, float32 scores) payload.
+    Works on RCCL ("nccl") and gloo groups; a single process returns its rows unchanged."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return rows
+    payload = ([r["vid_id"] for r in rows], [r["txt_id"] for r in rows], np.asarray([r["score"] for r in rows], dtype=np.float64))
+    parts = [None] * dist.get_world_size(group)
+    dist.all_gather_object(parts, payload, group=group)
+    out: List[Dict] = []
+    for vids, txts, sc in parts:
+        out.extend(dict(vid_id=v, txt_id=t, score=float(x)) for v, t, x in zip(vids, txts, sc))
+    return out
+
+
+@torch.no_grad()
+def inference_retrieval(model, videos, cfg, gt_txt_id2vid_id: Optional[Dict] = None, group=None, cache_cnn: bool = True):
+    """inference_retrieval of the reference (:628-734) for the videos of THIS rank: ``videos`` yields dict(vid_id,
+    visual_inputs (1, n_clips*num_frm, 3, H, W), text_input_ids, text_input_mask, caption_ids) -- one video against all its
+    candidate captions.  Returns (rows of all ranks, metrics or None); videos are independent units, the only exchange is
+    the final gather of the score rows."""
+    was_training = model.training
+    model.eval()
+    rows: List[Dict] = []
+    for b in videos:
+        scores = inference_retrieval_video(model, b["visual_inputs"], b["text_input_ids"], b["text_input_mask"], cfg, cache_cnn=cache_cnn)
+        rows.extend(dict(vid_id=b["vid_id"], txt_id=c, score=s) for c, s in zip(b["caption_ids"], scores))
+    rows = gather_retrieval_rows(rows, group)
+    metrics = eval_retrieval(rows, gt_txt_id2vid_id) if gt_txt_id2vid_id is not None else None
+    model.train(was_training)
+    return rows, metrics
+
+
 # ---- video QA inference (run_video_qa.py:216-300) ------------------------------------------------------------------------
 @torch.no_grad()
 def qa_predict(model, batch: Dict, cfg, fold_clips: bool = False) -> List[int]:

@@ -62,16 +62,61 @@ def _train_one_step(rank, world, out_path, compress=None):
         torch.save(dict(master=bank.master.clone(), norm=opt.grad_norm()), out_path)
 
 
-def _worker(rank, world, port, out_path, compress=None):
+def _train_multi_clip_accumulated(rank, world, out_path, compress=None):
+    """tasks.train_step with an UN-FOLDED clip loop (two encoder backwards per micro-step) and gradient accumulation over
+    two micro-steps, the overlap hook armed as INTEGRATION.md shows: the transformer buckets must be exchanged exactly once,
+    after the last encoder backward of the last micro-step (they used to go out after the first clip)."""
+    from types import SimpleNamespace
+    import test_model_small as T
+    from clipbert_amd import tasks
+    from clipbert_amd.dist import GradSync
+    from clipbert_amd.optim import FusedAdamW
+    cfg, sd, model = T.build("retrieval", dict(num_labels=2, loss_type="ce", margin=0.1), torch.float32, torch.device("cpu"))
+    from clipbert_amd import synthetic as S
+    from oracle import clipbert_oracle as O
+    frames = S.synthetic_frames(4, 4, 64, 7)[..., :64, :].repeat(1, 1, 1, 1, 2).contiguous()     # 4 videos x (2 clips x 2 frames)
+    ids, mask = S.synthetic_text(4, 6, 7, cfg["vocab_size"])                                     # 1 text each
+    full = dict(visual_inputs=O.image_norm(frames, S.PIXEL_MEAN, S.PIXEL_STD), text_input_ids=ids.clamp(max=cfg["vocab_size"] - 1),
+                text_input_mask=mask, labels=torch.tensor([1, 0, 0, 1]))
+    bank = model.rt.bank
+    sync = GradSync(bank, compress=compress, bucket_bytes=1 << 16)       # several buckets per range
+    sync.broadcast_parameters(0)
+    calls = []
+    model.rt.after_encoder_backward = lambda: (calls.append(1), sync.reduce_transformer())
+    opt = FusedAdamW(bank, lr=1e-3, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0)
+    tcfg = SimpleNamespace(train_n_clips=2, num_frm=2, score_agg_func="lse", gradient_accumulation_steps=2, learning_rate=1e-3,
+                           cnn_learning_rate=1e-3, decay="constant", cnn_lr_decay="constant", num_train_steps=10, warmup_ratio=0.0)
+    per = 2 // world                                         # videos per rank per micro-step
+    for micro in range(2):
+        idx = [micro * 2 + rank * per + j for j in range(per)]
+        batch = dict(visual_inputs=full["visual_inputs"][idx].contiguous(), text_input_ids=full["text_input_ids"][idx].contiguous(),
+                     text_input_mask=full["text_input_mask"][idx].contiguous(), n_examples_list=[1] * per, labels=full["labels"][idx])
+        tasks.train_step(model, opt, batch, tcfg, global_step=0, sync=sync, micro_step=micro, fold_clips=False)
+    assert calls == [1], calls               # one exchange: last encoder backward of the last micro-step
+    if rank == 0:
+        torch.save(dict(master=bank.master.clone(), norm=opt.grad_norm()), out_path)
+
+
+def _worker(rank, world, port, out_path, compress=None, fn="one_step"):
     torch.set_num_threads(2)
     os.environ["EMUL_THREADS"] = "4"
     _setup_emul()
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
-        _train_one_step(rank, world, out_path, compress)
+        (_train_one_step if fn == "one_step" else _train_multi_clip_accumulated)(rank, world, out_path, compress)
     finally:
         dist.destroy_process_group()
+
+
+def test_dp2_multi_clip_loop_with_accumulation(tmp_path):
+    p2, p1 = str(tmp_path / "dp2.pt"), str(tmp_path / "dp1.pt")
+    mp.spawn(_worker, args=(2, _free_port(), p2, None, "multi"), nprocs=2, join=True)
+    mp.spawn(_worker, args=(1, _free_port(), p1, None, "multi"), nprocs=1, join=True)
+    a, b = torch.load(p2), torch.load(p1)
+    # accumulated gradients are SUMS over micro-steps of per-rank mean losses: DP=2 averages two half-size means
+    assert abs(a["norm"] - b["norm"]) / b["norm"] < 1e-3
+    torch.testing.assert_close(a["master"], b["master"], rtol=1e-4, atol=2e-6)
 
 
 def test_dp2_equals_dp1_on_the_global_batch(tmp_path):

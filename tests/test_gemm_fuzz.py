@@ -33,7 +33,8 @@ def test_random_gemm(emul, case):
     M = rng.randint(1, 40) * (mult if form == "wgrad" else 1) + (0 if aligned else rng.randint(0, 3))
     N = rng.randint(1, 30) * mult + (0 if aligned else rng.randint(0, 5))
     K = rng.randint(1, 25) * mult + (0 if aligned else rng.randint(0, 5))
-    tile = rng.choice([0, 1, 2, 3]) if dt == torch.bfloat16 else 0
+    tile = rng.choice([0, 1, 2, 3, 4, 5, 6]) if dt == torch.bfloat16 else 0
+    xcd = rng.choice([0, 1, 2])
     tol = dict(rtol=3e-2, atol=3e-2) if dt == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
     if form == "fwd":
         x, w = hw(_rnd(M, K, gen=gen).to(dt)), hw(_rnd(N, K, gen=gen, scale=0.3).to(dt))
@@ -41,7 +42,7 @@ def test_random_gemm(emul, case):
         res = hw(_rnd(M, N, gen=gen).to(dt)) if rng.random() < 0.5 else None
         act = rng.choice([ops.ACT_NONE, ops.ACT_RELU, ops.ACT_GELU, ops.ACT_TANH])
         out = torch.empty(M, N, dtype=dt, device=hw.dev)
-        ops.gemm(x, w, M, N, K, out=out, shift=bias, act=act, residual=res, tile=tile)
+        ops.gemm(x, w, M, N, K, out=out, shift=bias, act=act, residual=res, tile=tile, xcd_order=xcd)
         ref = x.float() @ w.float().t()
         if bias is not None:
             ref = ref + bias.float()
@@ -53,7 +54,7 @@ def test_random_gemm(emul, case):
         g, w = hw(_rnd(M, K, gen=gen).to(dt)), hw(_rnd(K, N, gen=gen, scale=0.3).to(dt))       # dX[M,N] = g[M,K] W[K,N]
         out = torch.empty(M, N, dtype=dt, device=hw.dev)
         pre = hw(_rnd(M, N, gen=gen).to(dt)) if rng.random() < 0.4 else None
-        ops.gemm(g, w, M, N, K, out=out, b_mode=ops.KROW, ldb=N, tile=tile, gelu_grad_pre=pre)
+        ops.gemm(g, w, M, N, K, out=out, b_mode=ops.KROW, ldb=N, tile=tile, gelu_grad_pre=pre, xcd_order=xcd)
         ref = g.float() @ w.float()
         if pre is not None:
             p = pre.float().requires_grad_(True)
@@ -66,7 +67,7 @@ def test_random_gemm(emul, case):
         out = torch.ones(M, N, dtype=torch.float32, device=hw.dev)
         rs = torch.zeros(M, dtype=torch.float32, device=hw.dev) if rng.random() < 0.5 else None
         ops.gemm(g, x, M, N, K, out=out, a_mode=ops.KROW, b_mode=ops.KROW, lda=M, ldb=N, accumulate=True, split_k=split, tile=tile,
-                 a_rowsum=rs)
+                 a_rowsum=rs, xcd_order=xcd)
         tolw = dict(rtol=3e-2, atol=6e-2) if dt == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
         torch.testing.assert_close(out, 1.0 + g.float().t() @ x.float(), **tolw)
         if rs is not None:

@@ -38,9 +38,8 @@ def ones(*shape, dtype=torch.float32):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("D", [768, 64, 1280])
-def test_layernorm_fwd_bwd(hw, dt, D):
-    rows = 37
+@pytest.mark.parametrize("D,rows", [(768, 37), (64, 37), (1280, 37), (768, 2350)])      # >= 1024 rows: the 16-wave backward
+def test_layernorm_fwd_bwd(hw, dt, D, rows):
     x = rnd(rows, D, seed=1).to(dt)
     g, b = 1 + rnd(D, seed=2, scale=0.1), rnd(D, seed=3, scale=0.1)
     y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-12, save_stats=True)

@@ -16,7 +16,7 @@ Other workloads (rows of BASELINE.json `configs`; never the default line):
   --mode tgif     configs[3]: TGIF-QA action training step (ClipBertForMultipleChoice, 5 options per question, L_txt = 25,
                   N_clip = 2, mean pooling)
   --mode infer16  configs[4]: retrieval inference, one video x 16 clips against a mini-batch of 64 captions per step (grid
-                  features computed once, all 16 x 64 pairs in one encoder batch); N > 1 shards the videos over the ranks and
+                  features computed once, encoder passes of 4 clips x 64 captions = 256 pairs); N > 1 shards the videos over the ranks and
                   gathers the (vid, txt, score) rows once at the end (inside the timed region)
 
 Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel family of the step (bf16 MFMA GEMM /
@@ -204,14 +204,21 @@ def main():
         infer_rows.extend(dict(vid_id=f"r{rank}v{len(infer_rows) // rep}", txt_id=j, score=s) for j, s in enumerate(sc))
         return None
 
+    PAIRS_PER_PASS = 256                        # clips x captions per encoder pass (tasks.inference_retrieval_video)
+
     def infer_device_step():
         """the device work of infer_step without the host-side score list (capturable)"""
+        from clipbert_amd import clips
         with torch.no_grad():
             grid = model.grid_features(frames[:1].view(nclip, T, *frames.shape[2:]))
-            out = model.forward_from_grid(dict(visual_inputs=grid, text_input_ids=ids[:rep].repeat(nclip, 1),
-                                               text_input_mask=mask[:rep].repeat(nclip, 1), labels=None, n_examples_list=[rep] * nclip))
-            from clipbert_amd import clips
-            pooled = clips.aggregate_clip_logits(out["logits"].view(nclip, rep, -1), args.pool)
+            cpp = max(1, min(nclip, PAIRS_PER_PASS // rep))
+            per_clip = []
+            for c0 in range(0, nclip, cpp):
+                nc = min(cpp, nclip - c0)
+                out = model.forward_from_grid(dict(visual_inputs=grid[c0:c0 + nc], text_input_ids=ids[:rep].repeat(nc, 1),
+                                                   text_input_mask=mask[:rep].repeat(nc, 1), labels=None, n_examples_list=[rep] * nc))
+                per_clip.extend(out["logits"].view(nc, rep, -1).unbind(0))
+            pooled = clips.aggregate_clip_logits(per_clip, args.pool)
             if args.pool == "lse":
                 pooled = clips.lse_inference_logits(pooled)
             state["scores"] = torch.softmax(pooled.float(), dim=1)[:, 1]
@@ -368,7 +375,7 @@ def main():
     elif args.mode == "infer16":
         metric = f"clips/sec/node, retrieval inference ({nclip} clips × {T} frames, {args.size}px, {rep}-caption mini-batches) -- BASELINE configs[4] row"
         workload = (f"BASELINE configs[4]: retrieval inference, per step 1 video x {nclip} clips x {T} frames {args.size}px against {rep} captions "
-                    f"L_txt={args.txt_len} per GPU (CNN once per video, {nclip * rep} pairs in one encoder batch, {args.pool} pooling, scores rounded to 4 "
+                    f"L_txt={args.txt_len} per GPU (CNN once per video, encoder passes of <= 256 (clip, caption) pairs, {args.pool} pooling, scores rounded to 4 "
                     f"places and read back); videos sharded over ranks, one gather of the score rows at the end of the timed region")
     else:
         metric = "clips/sec/node forward-only (diagnostic)"

@@ -6,7 +6,9 @@
 // Layout of the sources: gemm_impl.h holds the kernel templates, gemm_inst_*.hip instantiate one tile size each (so the
 // tile sizes compile in parallel), this file validates a cb_gemm_desc and dispatches.
 //
-// * 256 threads = 4 waves (2x2); block tile 128x128 / 128x64 / 64x64, K step 64 (bf16) / 32 (fp32).
+// * 256 threads = 4 waves (2x2); block tile 128x128 (one block per CU with a 2-stage register ring, or two blocks per CU with
+//   one stage and <= 256 registers) / 128x64 / 64x64, K step 64 (bf16) / 32 (fp32).  256-row tiles (256x128, 256x64: one block
+//   per CU, ~450 registers) were built and measured in round 2: never the fastest on any shape of the benchmark steps.
 // * k-contiguous operands: LDS image [rows][128 B], 16-byte segments XOR-swizzled with (row & 7): every ds_read_b128 of an
 //   MFMA fragment is conflict-free.  Reduction-major operands (weights in dgrad, both operands in wgrad) keep their
 //   natural [k][rows] image in LDS and are read with ds_read_b64_tr_b16 -- no transposed copy anywhere.
@@ -30,8 +32,6 @@ extern template int launch_gemm<float, 64, 64, 2>(const GP&, bool, hipStream_t);
 extern template int launch_gemm<bf16, 128, 128, 2>(const GP&, bool, hipStream_t);
 extern template int launch_gemm<bf16, 128, 64, 2>(const GP&, bool, hipStream_t);
 extern template int launch_gemm<bf16, 64, 64, 3>(const GP&, bool, hipStream_t);
-extern template int launch_gemm<bf16, 256, 128, 2>(const GP&, bool, hipStream_t);
-extern template int launch_gemm<bf16, 256, 64, 2>(const GP&, bool, hipStream_t);
 extern template int launch_gemm<bf16, 128, 128, 1, 2>(const GP&, bool, hipStream_t);
 }
 
@@ -170,7 +170,7 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     p.c_vec8 = cv8 && !no_wide;
     static const bool no_remap = getenv("CB_GEMM_NO_XCD_REMAP") != nullptr;
     static const bool no_tuned = getenv("CB_GEMM_NO_TUNED") != nullptr;
-    CB_REQUIRE(d->tile >= 0 && d->tile <= 6, "cb_gemm: bad tile %d", d->tile);
+    CB_REQUIRE(d->tile >= 0 && d->tile <= 4, "cb_gemm: bad tile %d", d->tile);
     CB_REQUIRE(d->xcd_order >= 0 && d->xcd_order <= 2, "cb_gemm: bad xcd_order %d", d->xcd_order);
     int tile = d->tile, xcd = d->xcd_order;
     if (d->dtype == CB_BF16 && !no_tuned && (tile == 0 || xcd == 0)) {
@@ -179,23 +179,31 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
             if (xcd == 0) xcd = e->xcd;
         }
     }
-    // default order: XCD-compact for K-split grids (each XCD streams its own K slices), dispatch order for plain M x N grids
-    p.xcd_remap = !no_remap && (xcd == 1 || (xcd == 0 && p.split_k > 1));
+    // default workgroup order: XCD-compact (it won or tied on ~80 % of the round-2 sweep's shapes and lowers the fabric traffic)
+    p.xcd_remap = !no_remap && xcd != 2;
 
     hipStream_t st = cb_stream(stream);
     if (d->dtype == CB_F32) return launch_gemm<float, 64, 64, 2>(p, fast, st);
     if (tile == 0) {
-        int64_t blocks128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * p.split_k * p.batch;
-        tile = blocks128 >= 448 ? 1 : 2;               // below ~2 blocks per CU the 64x64 tile fills the chip better
-        if (d->a_mode == CB_KROW) tile = 2;            // weight-gradient form: measured faster with 64x64 tiles at every size
-        if (d->N <= 64 && (int64_t)((d->M + 127) / 128) * p.split_k * p.batch >= 448) tile = 3;
+        // Shapes outside the tuned table: rules read off the round-2 sweep (profiles/r02_gemm_tuning.json).  The 128x128 tile
+        // pays once it fills the chip (two blocks per CU resident: >= ~350 tiles) and the reduction is long enough to
+        // amortise its prologue; below that the 128x64 tile while it still gives ~1 block per CU; else 64x64.  N <= 64
+        // (stem / res2 convolutions) measured fastest with 64x64 tiles at every M.
+        const int64_t zmul = (int64_t)p.split_k * p.batch;
+        const int64_t t128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * zmul;
+        const int64_t t12864 = (int64_t)((d->M + 127) / 128) * ((d->N + 63) / 64) * zmul;
+        const int kred = d->K / p.split_k;
+        tile = 2;
+        if (d->a_mode == CB_KROW) {                   // weight gradients: big (batched) outputs only
+            if (t128 >= 256 && kred >= 1024) tile = 4;
+        } else if (d->N > 64) {
+            if (t128 >= 350 && kred >= 256) tile = 4;
+            else if (t12864 >= 200 && kred >= 512) tile = 3;
+        }
     }
     if (tile == 1 && d->N <= 64) tile = 3;           // narrow outputs (stem / res2 convs): 128x64 tile
-    if (tile == 4 && d->N <= 64) tile = 5;
-    if (tile == 6 && d->N <= 64) tile = 3;
-    if (tile == 6) return launch_gemm<bf16, 128, 128, 1, 2>(p, fast, st);
-    if (tile == 4) return launch_gemm<bf16, 256, 128, 2>(p, fast, st);
-    if (tile == 5) return launch_gemm<bf16, 256, 64, 2>(p, fast, st);
+    if (tile == 4 && d->N <= 64) tile = 3;
+    if (tile == 4) return launch_gemm<bf16, 128, 128, 1, 2>(p, fast, st);
     if (tile == 1) return launch_gemm<bf16, 128, 128, 2>(p, fast, st);
     if (tile == 3) return launch_gemm<bf16, 128, 64, 2>(p, fast, st);
     return launch_gemm<bf16, 64, 64, 3>(p, fast, st);

@@ -145,12 +145,15 @@ def train_step(model, optimizer, batch: Dict, cfg, global_step: int, sync=None, 
 # ---- retrieval inference (:628-734) ------------------------------------------------------------------------------------
 @torch.no_grad()
 def inference_retrieval_video(model, visual_inputs: torch.Tensor, text_input_ids: torch.Tensor, text_input_mask: torch.Tensor,
-                              cfg, cache_cnn: bool = True) -> List[float]:
+                              cfg, cache_cnn: bool = True, max_pairs_per_pass: int = 256) -> List[float]:
     """Scores of ONE video (1, inference_n_clips*num_frm, 3, H, W) against all its candidate captions (:640-690).
 
     cache_cnn=True (row N1): the grid features of all clips are computed once, in one CNN batch, and every text
-    mini-batch runs only the cross-modal encoder -- on all clips at once (pairs = clips x captions).  cache_cnn=False is
-    the reference's order of evaluation (full forward per clip per mini-batch).  Both give the same scores."""
+    mini-batch runs only the cross-modal encoder -- on several clips at once (pairs = clips x captions, at most
+    ``max_pairs_per_pass`` per encoder pass: measured on MI355X, an encoder batch whose activations outgrow the 256 MB
+    Infinity Cache (1024 pairs = 42 k token rows: 258 MB per FFN activation) runs its GEMMs 3-5x slower per row than a
+    batch of a few thousand rows).  cache_cnn=False is the reference's order of evaluation (full forward per clip per
+    mini-batch).  Both give the same scores."""
     n_clips, num_frm = _get(cfg, "inference_n_clips", 1), _get(cfg, "num_frm")
     pool, eval_bsz = _get(cfg, "score_agg_func", "mean"), _get(cfg, "inference_batch_size", 64)
     vis = visual_inputs.view(n_clips, num_frm, *visual_inputs.shape[2:])
@@ -161,10 +164,14 @@ def inference_retrieval_video(model, visual_inputs: torch.Tensor, text_input_ids
         ids, mask = text_input_ids[i0:i0 + eval_bsz], text_input_mask[i0:i0 + eval_bsz]
         nb = ids.shape[0]
         if cache_cnn:
-            out = model.forward_from_grid(dict(visual_inputs=grid, text_input_ids=ids.repeat(n_clips, 1),
-                                               text_input_mask=mask.repeat(n_clips, 1), labels=None,
-                                               n_examples_list=[nb] * n_clips))
-            per_clip = list(out["logits"].view(n_clips, nb, -1).unbind(0))
+            cpp = max(1, min(n_clips, max_pairs_per_pass // max(nb, 1)))          # clips per encoder pass
+            per_clip = []
+            for c0 in range(0, n_clips, cpp):
+                nc = min(cpp, n_clips - c0)
+                out = model.forward_from_grid(dict(visual_inputs=grid[c0:c0 + nc], text_input_ids=ids.repeat(nc, 1),
+                                                   text_input_mask=mask.repeat(nc, 1), labels=None,
+                                                   n_examples_list=[nb] * nc))
+                per_clip.extend(out["logits"].view(nc, nb, -1).unbind(0))
         else:
             per_clip = []
             for c in range(n_clips):

@@ -79,8 +79,8 @@ typedef struct {
     uint64_t dropout_seed;    /* mask = f(dropout_seed + *dropout_seed_ptr, m*N + n)                  */
     const uint64_t* dropout_seed_ptr;  /* optional DEVICE word added to the seed (varies per hipGraph replay) */
     int32_t tile;             /* 0 auto (tuned table, then heuristics), 1 = 128x128, 2 = 64x64, 3 = 128x64,
-                                 4 = 256x128, 5 = 256x64, 6 = 128x128 with two blocks per CU (bf16; fp32 parity mode always
-                                 runs 64x64)                                                          */
+                                 4 = 128x128 with its registers capped so that two blocks share a CU  (bf16; fp32 parity mode
+                                 always runs 64x64)                                                   */
     int32_t xcd_order;        /* workgroup -> tile order: 0 auto, 1 = XCD-compact (each XCD, with its own L2, owns a
                                  contiguous run of tiles), 2 = dispatch order (consecutive tiles round-robin over XCDs) */
     int64_t a_bytes, b_bytes; /* sizes of the A / B buffers in bytes (0 = unknown).  When both are known, < 2 GiB

@@ -20,9 +20,9 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("M,N,K,tile", [(100, 72, 96, 2), (130, 136, 64, 1), (5, 2, 8, 0), (33, 37, 40, 2), (300, 136, 128, 4), (270, 40, 192, 5)])
+@pytest.mark.parametrize("M,N,K,tile", [(100, 72, 96, 2), (130, 136, 64, 1), (5, 2, 8, 0), (33, 37, 40, 2), (300, 136, 128, 4), (270, 40, 192, 3)])
 def test_linear_forward_epilogues(hw, dt, M, N, K, tile):
-    if dt == torch.float32 and tile in (1, 4, 5):
+    if dt == torch.float32 and tile in (1, 3, 4):
         tile = 0
     x, w, b = hw(rnd(M, K, seed=1).to(dt)), hw(rnd(N, K, seed=2, scale=0.2).to(dt)), hw(rnd(N, seed=3))
     res = hw(rnd(M, N, seed=4).to(dt))
@@ -142,7 +142,7 @@ def _nhwc(x):
 @pytest.mark.parametrize("tile,k,stride,pad,H,W,Cin,Cout", [
     (2, 3, 1, 1, 7, 9, 32, 64), (2, 1, 2, 0, 8, 6, 64, 40), (2, 1, 1, 0, 5, 5, 32, 64),
     (1, 3, 1, 1, 7, 9, 32, 64), (1, 1, 2, 0, 8, 6, 64, 40), (1, 1, 1, 0, 5, 5, 32, 64),
-    (4, 3, 1, 1, 7, 9, 64, 136), (5, 1, 2, 0, 8, 6, 64, 40), (3, 3, 1, 1, 7, 9, 32, 64)])
+    (4, 3, 1, 1, 7, 9, 64, 136), (4, 1, 2, 0, 8, 6, 64, 40), (3, 3, 1, 1, 7, 9, 32, 64)])
 def test_conv_forward_backward(hw, dt, tile, k, stride, pad, H, W, Cin, Cout):
     if dt == torch.float32 and tile != 2:
         pytest.skip("fp32 parity mode has one tile size")

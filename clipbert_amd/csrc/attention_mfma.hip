@@ -1,4 +1,5 @@
-// MFMA self-attention for short sequences (L <= 64, head size 64, bf16): one block of ceil(L/16) waves owns one
+// MFMA self-attention for short sequences (L <= 192, head size 64, bf16; the register-resident kernels below serve L <= 64,
+// the LDS-resident *_big kernels further down 64 < L <= 192): one block of ceil(L/16) waves owns one
 // (batch, head); each wave owns 16 queries (and, in the backward's second half, 16 keys).
 //
 // The cross-modal encoder of the hot path sees L = Lt + Lv = 41 tokens (29..57 across the reference's tasks), so a
@@ -307,13 +308,220 @@ __global__ void __launch_bounds__(128 * NT) attn_bwd_mfma_kernel(const bf16* qkv
     }
 }
 
+// =================================================================================================================
+// 64 < L <= 192 (the reference's native sizes: 448 px + 20 tokens -> L = 69, 768 px + 25 tokens -> L = 169): the same
+// algorithm with NT = ceil(L/16) rounded up to even <= 12 key tiles.  A whole head still fits on chip (K, V: 27 KiB each at
+// NT = 12), so softmax stays single-pass -- no running max / rescale -- but the operand fragments no longer fit in
+// registers next to NT score tiles: K, V (forward) and Q, K, V, dO (backward) are staged once in LDS in their natural
+// [row][64] image (144-byte rows: conflict-free ds_read_b128 of a fragment) and every fragment is read where it is used,
+// k-contiguous ones with ds_read_b128, row-contracted ones with ds_read_b64_tr_b16 (tr_frag above).  One wave per 16
+// queries; the backward runs its query-owning (dQ) and key-owning (dK, dV) halves one after the other on the same NT waves
+// (2*NT waves would exceed 1024 threads).
+// =================================================================================================================
+__device__ __forceinline__ bf16x8 lds_frag(const unsigned char* mat, int row, int d) {
+    return *reinterpret_cast<const bf16x8*>(mat + row * RS + d * 2);
+}
+
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) attn_fwd_mfma_big_kernel(const bf16* qkv, const float* key_mask, bf16* ctx, float* lse, int B, int L,
+                                                               int H, float drop_p, uint64_t seed, const uint64_t* seed_ptr) {
+    static_assert(NT % 2 == 0, "key tiles are consumed in pairs");
+    constexpr int NP = NT / 2, ROWS = NT * 16;
+    __shared__ __attribute__((aligned(16))) unsigned char Ks[ROWS * RS];
+    __shared__ __attribute__((aligned(16))) unsigned char Vs[ROWS * RS];
+    if (drop_p > 0.f && seed_ptr) seed += *seed_ptr;
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int it = threadIdx.x >> 6;                    // this wave's 16-query tile
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int64_t stride = 3 * H * DH;
+    const bf16* qb = qkv + (int64_t)b * L * stride + h * DH;
+    stage(qb + H * DH, stride, L, ROWS, Ks, threadIdx.x, 64 * NT);
+    stage(qb + 2 * H * DH, stride, L, ROWS, Vs, threadIdx.x, 64 * NT);
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = ld_frag(qb, stride, 16 * it + c, L, 32 * ks + 8 * g);
+    __syncthreads();
+    if (16 * it >= L) return;                           // (no barrier below)
+    const int i = 16 * it + c;                          // this lane's query (accumulator column)
+    f32x4 s[NT];
+    float m = NEG_BIG;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(Ks, 16 * jt + c, 32 * ks + 8 * g), qf[ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * jt + 4 * g + r;
+            const float madd = j < L ? (1.0f - key_mask[(int64_t)b * L + j]) * MASK_NEG : NEG_BIG;
+            acc[r] = acc[r] * 0.125f + madd;
+            m = fmaxf(m, acc[r]);
+        }
+        s[jt] = acc;
+    }
+    m = group_max(m);
+    float l = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[jt][r] = __expf(s[jt][r] - m);
+            l += s[jt][r];
+        }
+    l = group_sum(l);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        s[jt] = s[jt] * inv;
+        if (drop_p > 0.f) s[jt] = s[jt] * dropout_mult4(seed, ((uint64_t)bh * L + i) * ((L + 3) >> 2) + 4 * jt + g, drop_p);
+    }
+    if (lse && g == 0 && i < L) lse[(int64_t)bh * L + i] = m + __logf(l);
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jp = 0; jp < NP; ++jp) {
+        const bf16x8 pf = pack_pair(s[2 * jp], s[2 * jp + 1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Vs, jp, dt, lane), pf, o[dt], 0, 0, 0);
+    }
+    if (i < L) {
+        bf16* dst = ctx + ((int64_t)b * L + i) * (H * DH) + h * DH + 16 * g;
+        *reinterpret_cast<bf16x8*>(dst) = pack_pair(o[0], o[1]);
+        *reinterpret_cast<bf16x8*>(dst + 8) = pack_pair(o[2], o[3]);
+    }
+}
+
+// Backward, 64 < L <= 192: phase X (own 16 queries -> dQ) then phase Y (own 16 keys -> dK, dV) on the same wave; see the
+// role table above attn_bwd_mfma_kernel.
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) attn_bwd_mfma_big_kernel(const bf16* qkv, const float* key_mask, const bf16* ctx, const bf16* dctx,
+                                                               const float* lse, bf16* dqkv, int B, int L, int H, float drop_p,
+                                                               uint64_t seed, const uint64_t* seed_ptr) {
+    static_assert(NT % 2 == 0, "tiles are consumed in pairs");
+    constexpr int NP = NT / 2, ROWS = NT * 16, NTHR = 64 * NT;
+    constexpr float POS_BIG = 3.0e38f;
+    __shared__ __attribute__((aligned(16))) unsigned char Ks[ROWS * RS];
+    __shared__ __attribute__((aligned(16))) unsigned char Qs[ROWS * RS];
+    __shared__ __attribute__((aligned(16))) unsigned char Vs[ROWS * RS];
+    __shared__ __attribute__((aligned(16))) unsigned char Gs[ROWS * RS];
+    __shared__ __attribute__((aligned(16))) float Dl[ROWS];      // D_i = rowsum(dO * O)
+    __shared__ __attribute__((aligned(16))) float Ll[ROWS];      // lse_i (+big past L: probabilities of padding rows = 0)
+    __shared__ __attribute__((aligned(16))) float Ml[ROWS];      // additive key mask (-big past L)
+    if (drop_p > 0.f && seed_ptr) seed += *seed_ptr;
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int wt = threadIdx.x >> 6;
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int64_t stride = 3 * H * DH, cstride = (int64_t)H * DH;
+    const bf16* qb = qkv + (int64_t)b * L * stride + h * DH;
+    const bf16* ob = ctx + (int64_t)b * L * cstride + h * DH;
+    const bf16* gb = dctx + (int64_t)b * L * cstride + h * DH;
+    bf16* dqb = dqkv + (int64_t)b * L * stride + h * DH;
+    stage(qb, stride, L, ROWS, Qs, threadIdx.x, NTHR);
+    stage(qb + H * DH, stride, L, ROWS, Ks, threadIdx.x, NTHR);
+    stage(qb + 2 * H * DH, stride, L, ROWS, Vs, threadIdx.x, NTHR);
+    stage(gb, cstride, L, ROWS, Gs, threadIdx.x, NTHR);
+    const int col = 16 * wt + c;                                    // own query (X) / key (Y)
+    {
+        float part = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 of = ld_frag(ob, cstride, col, L, 32 * ks + 8 * g), gf = ld_frag(gb, cstride, col, L, 32 * ks + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part += (float)gf[e] * (float)of[e];
+        }
+        part = group_sum(part);
+        if (g == 0) {
+            Dl[col] = part;
+            Ll[col] = col < L ? lse[(int64_t)bh * L + col] : POS_BIG;
+            Ml[col] = col < L ? (1.0f - key_mask[(int64_t)b * L + col]) * MASK_NEG : NEG_BIG;
+        }
+    }
+    __syncthreads();
+    if (16 * wt >= L) return;                                       // (no barrier below)
+    const uint64_t ng = (uint64_t)((L + 3) >> 2);
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+        const bool yph = ph == 1;
+        const unsigned char* PA = yph ? Qs : Ks;                    // tiles' rows
+        const unsigned char* PB = yph ? Gs : Vs;
+        const unsigned char* OA = yph ? Ks : Qs;                    // own column
+        const unsigned char* OO = yph ? Vs : Gs;
+        bf16x8 oaf[2], oof[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { oaf[ks] = lds_frag(OA, col, 32 * ks + 8 * g); oof[ks] = lds_frag(OO, col, 32 * ks + 8 * g); }
+        const float cmadd = Ml[col], clse = Ll[col], cD = Dl[col];
+        f32x4 pd[NT], ds[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(PA, 16 * t + c, 32 * ks + 8 * g), oaf[ks], sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(PB, 16 * t + c, 32 * ks + 8 * g), oof[ks], dp, 0, 0, 0);
+            }
+            const int row0 = 16 * t + 4 * g;                        // rows row0..row0+3: keys (X) / queries (Y)
+            f32x4 rmadd, rlse, rD;
+            if (yph) {
+                rlse = *reinterpret_cast<const f32x4*>(&Ll[row0]);
+                rD = *reinterpret_cast<const f32x4*>(&Dl[row0]);
+                rmadd = f32x4{cmadd, cmadd, cmadd, cmadd};
+            } else {
+                rmadd = *reinterpret_cast<const f32x4*>(&Ml[row0]);
+                rlse = f32x4{clse, clse, clse, clse};
+                rD = f32x4{cD, cD, cD, cD};
+            }
+            f32x4 mult = {1.0f, 1.0f, 1.0f, 1.0f};
+            if (drop_p > 0.f) {
+                if (yph) {                                   // 4 queries x own key: 4 rows of the mask, one element each
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mult[r] = dropout_mult1(seed, ((uint64_t)bh * L + row0 + r) * ng + (col >> 2), col & 3, drop_p);
+                } else {                                     // own query x keys row0..row0+3: one group of the mask row
+                    mult = dropout_mult4(seed, ((uint64_t)bh * L + col) * ng + (row0 >> 2), drop_p);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(sc[r] * 0.125f + rmadd[r] - rlse[r]);
+                pd[t][r] = p * mult[r];
+                ds[t][r] = p * (dp[r] * mult[r] - rD[r]) * 0.125f;
+            }
+        }
+        f32x4 a1[4], a2[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { a1[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; a2[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr) {
+            const bf16x8 dsf = pack_pair(ds[2 * pr], ds[2 * pr + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) a1[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(PA, pr, dt, lane), dsf, a1[dt], 0, 0, 0);
+            if (yph) {
+                const bf16x8 pdf = pack_pair(pd[2 * pr], pd[2 * pr + 1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) a2[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Gs, pr, dt, lane), pdf, a2[dt], 0, 0, 0);
+            }
+        }
+        if (col < L) {
+            bf16* dst = dqb + (int64_t)col * stride + (yph ? H * DH : 0) + 16 * g;      // dQ third (X) / dK third (Y)
+            *reinterpret_cast<bf16x8*>(dst) = pack_pair(a1[0], a1[1]);
+            *reinterpret_cast<bf16x8*>(dst + 8) = pack_pair(a1[2], a1[3]);
+            if (yph) {
+                dst += H * DH;                                                          // dV third
+                *reinterpret_cast<bf16x8*>(dst) = pack_pair(a2[0], a2[1]);
+                *reinterpret_cast<bf16x8*>(dst + 8) = pack_pair(a2[2], a2[3]);
+            }
+        }
+    }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
-// Used by cb_attention_fwd / cb_attention_bwd (attention.hip) for bf16, L <= 64, 16-byte aligned operands.
+// Used by cb_attention_fwd / cb_attention_bwd (attention.hip) for bf16, L <= 192, 16-byte aligned operands.
 bool cb_attention_mfma_ok(int32_t dtype, const void* qkv, const void* ctx, const void* other, int32_t L) {
-    return dtype == CB_BF16 && L <= 64 && al16(qkv) && al16(ctx) && (!other || al16(other));
+    return dtype == CB_BF16 && L <= 192 && al16(qkv) && al16(ctx) && (!other || al16(other));
 }
 
 int cb_attention_fwd_mfma(const void* qkv, const float* key_mask, void* ctx, float* lse, int32_t B, int32_t L, int32_t H,
@@ -322,6 +530,17 @@ int cb_attention_fwd_mfma(const void* qkv, const float* key_mask, void* ctx, flo
     dim3 g(B * H), b(64 * nt);
     const bf16* q = (const bf16*)qkv;
     bf16* c = (bf16*)ctx;
+    if (nt > 4) {
+        const int ne = (nt + 1) / 2 * 2;
+        b = dim3(64 * ne);
+        switch (ne) {
+            case 6: hipLaunchKernelGGL((attn_fwd_mfma_big_kernel<6>), g, b, 0, st, q, key_mask, c, lse, B, L, H, p, seed, seed_ptr); break;
+            case 8: hipLaunchKernelGGL((attn_fwd_mfma_big_kernel<8>), g, b, 0, st, q, key_mask, c, lse, B, L, H, p, seed, seed_ptr); break;
+            case 10: hipLaunchKernelGGL((attn_fwd_mfma_big_kernel<10>), g, b, 0, st, q, key_mask, c, lse, B, L, H, p, seed, seed_ptr); break;
+            default: hipLaunchKernelGGL((attn_fwd_mfma_big_kernel<12>), g, b, 0, st, q, key_mask, c, lse, B, L, H, p, seed, seed_ptr); break;
+        }
+        return cb_launch_status("cb_attention_fwd");
+    }
     switch ((L + 15) / 16) {
         case 1: hipLaunchKernelGGL((attn_fwd_mfma_kernel<1>), g, b, 0, st, q, key_mask, c, lse, B, L, H, p, seed, seed_ptr); break;
         case 2: hipLaunchKernelGGL((attn_fwd_mfma_kernel<2>), g, b, 0, st, q, key_mask, c, lse, B, L, H, p, seed, seed_ptr); break;
@@ -337,6 +556,17 @@ int cb_attention_bwd_mfma(const void* qkv, const float* key_mask, const void* ct
     dim3 g(B * H), b(128 * nt);
     const bf16 *q = (const bf16*)qkv, *c = (const bf16*)ctx, *d = (const bf16*)dctx;
     bf16* o = (bf16*)dqkv;
+    if (nt > 4) {
+        const int ne = (nt + 1) / 2 * 2;
+        b = dim3(64 * ne);
+        switch (ne) {
+            case 6: hipLaunchKernelGGL((attn_bwd_mfma_big_kernel<6>), g, b, 0, st, q, key_mask, c, d, lse, o, B, L, H, p, seed, seed_ptr); break;
+            case 8: hipLaunchKernelGGL((attn_bwd_mfma_big_kernel<8>), g, b, 0, st, q, key_mask, c, d, lse, o, B, L, H, p, seed, seed_ptr); break;
+            case 10: hipLaunchKernelGGL((attn_bwd_mfma_big_kernel<10>), g, b, 0, st, q, key_mask, c, d, lse, o, B, L, H, p, seed, seed_ptr); break;
+            default: hipLaunchKernelGGL((attn_bwd_mfma_big_kernel<12>), g, b, 0, st, q, key_mask, c, d, lse, o, B, L, H, p, seed, seed_ptr); break;
+        }
+        return cb_launch_status("cb_attention_bwd");
+    }
     switch ((L + 15) / 16) {
         case 1: hipLaunchKernelGGL((attn_bwd_mfma_kernel<1>), g, b, 0, st, q, key_mask, c, d, lse, o, B, L, H, p, seed, seed_ptr); break;
         case 2: hipLaunchKernelGGL((attn_bwd_mfma_kernel<2>), g, b, 0, st, q, key_mask, c, d, lse, o, B, L, H, p, seed, seed_ptr); break;

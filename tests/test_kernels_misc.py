@@ -116,7 +116,7 @@ def test_visual_embed_pixel_subsample(hw):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("L", [9, 41, 70])
+@pytest.mark.parametrize("L", [9, 41, 69, 112, 169, 192, 200])      # 65..192: LDS-resident MFMA kernels (bf16); 200: generic
 def test_attention_fwd_bwd(hw, dt, L):
     B, H = 2, 2
     qkv = rnd(B * L, 3 * H * 64, seed=1).to(dt)
@@ -135,7 +135,7 @@ def test_attention_fwd_bwd(hw, dt, L):
     torch.testing.assert_close(dqkv.float(), x.grad, **tol(dt, 1e-4, 3e-2))
 
 
-@pytest.mark.parametrize("L", [20, 41, 64])
+@pytest.mark.parametrize("L", [20, 41, 64, 69, 169])
 def test_attention_dropout_mfma_matches_generic(hw, L):
     """bf16 one-wave MFMA kernels vs the generic fp32 kernels on the same (bf16-valued) inputs and the same dropout
     stream: same mask indexing in forward and backward, P rounded to bf16 before P.V the only difference."""

@@ -46,11 +46,25 @@ CASES = {
 }
 
 
+# Multi-clip cases: the reference's task LOOPS around the model (src/tasks/run_video_retrieval.py:387-422 training,
+# :655-690 inference; src/tasks/run_video_qa.py:470-501): N_clip forwards, pooling of the logits, loss / scores.
+CLIP_CASES = {
+    # BASELINE configs[2]: MSRVTT retrieval at the JSON's native sizes (448 px, L_txt 20 -> L = 69), N_clip = 4, LSE pooling
+    "msrvtt_lse_c4_448": dict(head="retrieval", n_videos=2, n_clips=4, n_frames=2, size=448, lt=20, repeat=2, pool="lse", mode="train",
+                              cfg=dict(num_labels=2, loss_type="ce", margin=0.1)),
+    # BASELINE configs[3]: TGIF-QA action at the JSON's native sizes (768 px, L_txt 25 -> L = 169), N_clip = 2, mean pooling
+    "tgif_mc_c2_768": dict(head="multiple_choice", n_videos=2, n_clips=2, n_frames=2, size=768, lt=25, repeat=5, pool="mean", mode="train",
+                           cfg=dict(num_labels=5, loss_type="ce")),
+    # BASELINE configs[4]: retrieval inference, one video x 16 clips against 8 captions, LSE pooling, scores rounded to 4 places
+    "msrvtt_infer_c16": dict(head="retrieval", n_videos=1, n_clips=16, n_frames=2, size=224, lt=32, repeat=8, pool="lse", mode="infer",
+                             cfg=dict(num_labels=2, loss_type="ce", margin=0.1)),
+}
+
 _SD_CACHE = {}
 
 
 def build_case(name: str, seed: int = 42):
-    c = CASES[name]
+    c = CASES[name] if name in CASES else dict(CLIP_CASES[name], n_frames=CLIP_CASES[name]["n_clips"] * CLIP_CASES[name]["n_frames"])
     cfg = dict(O.BASE_CONFIG)
     cfg.update(c["cfg"])
     head = c["head"]
@@ -73,6 +87,8 @@ def build_case(name: str, seed: int = 42):
         batch["itm_labels"] = S.synthetic_labels(n_pairs, 2, seed)
     elif head == "multiple_choice":
         batch["labels"] = S.synthetic_labels(c["n_videos"], cfg["num_labels"], seed)
+    elif head == "retrieval" and name in CLIP_CASES:
+        batch["labels"] = torch.tensor(([1] + [0] * (c["repeat"] - 1)) * c["n_videos"])      # 1 positive + negatives per video
     elif head == "retrieval" and cfg["loss_type"] == "rank":
         batch["labels"] = torch.zeros(n_pairs, dtype=torch.long)  # unused by the rank loss
     else:
@@ -138,10 +154,70 @@ def run_reference(name: str):
     return out
 
 
+@torch.no_grad()
+def run_reference_clips(name: str):
+    """The reference's clip loop around its own transformer classes (CNN half: the oracle), then the runner's pooling and
+    loss / score arithmetic exactly as written in src/tasks/run_video_retrieval.py:402-419 (training), :669-690
+    (inference) and src/tasks/run_video_qa.py:484-501."""
+    c = CLIP_CASES[name]
+    cfg, head, sd, batch = build_case(name)
+    mo, _tr = ref_shim.load_reference_modeling()
+    model = getattr(mo, REF_CLASS[head])(ref_shim.make_config(cfg)).eval()
+    tsd = {k[len("transformer."):]: v for k, v in sd.items() if k.startswith("transformer.")}
+    missing, unexpected = model.load_state_dict(tsd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    bsz, num_clips, num_frm = c["n_videos"], c["n_clips"], c["n_frames"]
+    vis = batch["visual_inputs"]
+    visual_inputs = vis.view(bsz, num_clips, num_frm, *vis.shape[2:])           # :394-395
+    logits = []
+    out = {}
+    for clip_idx in range(num_clips):
+        grid = O.grid_feat_backbone(sd, visual_inputs[:, clip_idx], "cnn.")
+        if clip_idx == 0:
+            out["fp_grid_clip0"] = fingerprint(grid)
+        kw = dict(text_input_ids=batch["text_input_ids"], text_input_mask=batch["text_input_mask"], labels=None,
+                  visual_inputs=O.repeat_rows(grid, batch["n_examples_list"]))
+        if head == "retrieval":
+            kw["sample_size"] = bsz
+        logits.append(model(**kw)["logits"])
+    logits = torch.stack(logits)                                                # :402
+    out["stack"] = logits.numpy().copy()
+    pool_method = c["pool"]
+    if pool_method == "mean":
+        pooled = logits.mean(0)
+    elif pool_method == "max":
+        pooled = logits.max(0)[0]
+    else:
+        pooled = logits.permute(1, 0, 2).contiguous()
+    labels = batch["labels"]
+    if c["mode"] == "train":
+        if pool_method == "lse":                                                # :413-417
+            o = torch.logsumexp(pooled.view(pooled.shape[0], -1), dim=-1, keepdim=True) - torch.logsumexp(pooled, dim=1)
+            loss = torch.gather(o, -1, labels.view(-1, 1))
+        elif head == "retrieval":
+            _, loss = model.calc_loss(pooled, labels, sample_size=bsz)
+        else:
+            pooled, loss = model.calc_loss(pooled, labels)                      # (B, 5) for the multiple-choice head
+        out["pooled"] = pooled.numpy().copy()
+        out["loss"] = loss.numpy().copy()
+        if head == "multiple_choice":
+            out["answer_ids"] = pooled.max(dim=-1)[1].numpy()                   # run_video_qa.py:273-275
+    else:
+        if pool_method == "lse":
+            pooled = torch.logsumexp(pooled, dim=1)                             # :674-676
+        probs = torch.nn.functional.softmax(pooled, dim=1)[:, 1].tolist()       # :681
+        out["pooled"] = pooled.numpy().copy()
+        out["scores"] = np.asarray([round(s_, 4) for s_ in probs], dtype=np.float64)      # :687
+    return out
+
+
 def main():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
-    for name in CASES:
-        out = run_reference(name)
+    only = set(sys.argv[1:])
+    for name in list(CASES) + list(CLIP_CASES):
+        if only and name not in only:
+            continue
+        out = run_reference(name) if name in CASES else run_reference_clips(name)
         path = os.path.join(GOLDEN_DIR, name + ".npz")
         np.savez_compressed(path, **out)
         print(name, {k: v.shape for k, v in out.items() if not k.startswith("fp_")},

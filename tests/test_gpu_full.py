@@ -154,3 +154,53 @@ def test_training_step_reduces_loss_and_updates_bf16_copy():
     assert losses[-1] < losses[0], losses
     torch.testing.assert_close(bank.w16[:bank.n_train].float(), bank.master[:bank.n_train].bfloat16().float())
     assert opt.grad_norm() > 0
+
+
+# ---- multi-clip configurations (BASELINE configs[2], [3], [4]): the reference's task loops around its own classes ------------
+@pytest.mark.parametrize("name", list(G.CLIP_CASES))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_multi_clip_config_matches_reference_golden(name, dtype):
+    """configs[2] (MSRVTT 448 px / L = 69, N_clip = 4, LSE loss), configs[3] (TGIF-QA action 768 px / L = 169, N_clip = 2, mean
+    pooling, answer ids) and configs[4] (16-clip retrieval inference, scores rounded to 4 places) at full model size: the
+    product's FOLDED clip forward + cb_clip_aggregate / cb_lse_loss against goldens made by looping the reference's classes
+    (oracle/make_golden.py: run_reference_clips).  L = 69 and L = 169 run the LDS-resident MFMA attention in bf16."""
+    from types import SimpleNamespace
+    from clipbert_amd import tasks
+    c = G.CLIP_CASES[name]
+    gold = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg, head, sd, batch = G.build_case(name)
+    model = build_model(cfg, head, sd, dtype)
+    f32 = dtype == torch.float32
+    tol = 1e-3 if f32 else 3e-2
+    b = to_dev(batch)
+    if c["mode"] == "train":
+        tcfg = SimpleNamespace(task="action" if head == "multiple_choice" else None, num_labels=cfg["num_labels"])
+        if head == "multiple_choice":
+            b["n_examples_list"] = [1] * c["n_videos"]                    # questions per video; x num_labels inside (run_video_qa.py:206)
+        with torch.no_grad():
+            stack = tasks.forward_clips_stack(model, b, c["n_clips"], c["n_frames"], fold=True, cfg=tcfg)
+            loss = tasks.training_loss(model, stack, b["labels"], b["n_examples_list"], c["pool"])
+        torch.cuda.synchronize()
+        st = stack.float().cpu().numpy()
+        assert st.shape == gold["stack"].shape
+        err = np.abs(st - gold["stack"]).max()
+        assert err < tol, (name, dtype, err)
+        assert abs(float(loss) - float(gold["loss"].mean())) < (1e-3 if f32 else 2e-2)
+        if head == "multiple_choice" and f32:                            # answer ids: argmax-exact after pooling
+            pooled = st.mean(0)
+            assert (pooled.argmax(-1) == gold["answer_ids"]).all()
+            qcfg = SimpleNamespace(inference_n_clips=c["n_clips"], num_frm=c["n_frames"], score_agg_func=c["pool"], task="action",
+                                   num_labels=cfg["num_labels"])
+            assert tasks.qa_predict(model, dict(b), qcfg, fold_clips=True) == gold["answer_ids"].tolist()
+        if f32 and name.startswith("msrvtt"):                            # the un-folded loop gives the same stack
+            with torch.no_grad():
+                loop = tasks.forward_clips_stack(model, b, c["n_clips"], c["n_frames"], fold=False, cfg=tcfg)
+            assert (loop.float().cpu() - stack.float().cpu()).abs().max() < 1e-4
+    else:
+        icfg = SimpleNamespace(inference_n_clips=c["n_clips"], num_frm=c["n_frames"], score_agg_func=c["pool"], inference_batch_size=c["repeat"])
+        scores = tasks.inference_retrieval_video(model, b["visual_inputs"], b["text_input_ids"], b["text_input_mask"], icfg,
+                                                 cache_cnn=True, max_pairs_per_pass=4 * c["repeat"])
+        assert len(scores) == len(gold["scores"])
+        err = max(abs(a - r) for a, r in zip(scores, gold["scores"].tolist()))
+        assert err <= (1.01e-4 if f32 else 1e-2), (name, dtype, err)      # rounded to 4 places: one unit of the last place
+        assert all(round(s, 4) == s for s in scores)

@@ -36,3 +36,27 @@ def test_oracle_matches_reference_golden(name):
     else:
         np.testing.assert_allclose(out["logits"].numpy(), gold["logits"], rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(out["loss"].numpy(), gold["loss"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["msrvtt_lse_c4_448", "msrvtt_infer_c16"])
+def test_oracle_clip_loop_matches_reference_golden(name):
+    """The oracle's clip loop + pooling + LSE loss / rounded scores (what bench.py's cpu_baseline and the emulator-sized
+    task tests use as their checker) against the goldens produced by looping the REFERENCE's classes."""
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    c = G.CLIP_CASES[name]
+    gold = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cfg, head, sd, batch = G.build_case(name)
+    vis = batch["visual_inputs"].view(c["n_videos"], c["n_clips"], c["n_frames"], *batch["visual_inputs"].shape[2:])
+    per_clip = []
+    with torch.no_grad():
+        for k in range(c["n_clips"]):
+            b = dict(visual_inputs=vis[:, k], text_input_ids=batch["text_input_ids"], text_input_mask=batch["text_input_mask"],
+                     n_examples_list=list(batch["n_examples_list"]))
+            per_clip.append(O.clipbert_forward(sd, b, cfg, head)["logits"])
+    np.testing.assert_allclose(torch.stack(per_clip).numpy(), gold["stack"], rtol=1e-4, atol=2e-5)
+    pooled = O.aggregate_clip_logits(per_clip, c["pool"])
+    if c["mode"] == "train":
+        np.testing.assert_allclose(O.lse_train_loss(pooled, batch["labels"]).numpy(), gold["loss"], rtol=1e-4, atol=2e-5)
+    else:
+        probs = torch.softmax(torch.logsumexp(pooled, dim=1), dim=1)[:, 1].tolist()
+        assert max(abs(round(p, 4) - g) for p, g in zip(probs, gold["scores"].tolist())) <= 1.01e-4

@@ -39,12 +39,12 @@ def main():
         key = f"gemm_kernel<bf16> {c['form']}{' (implicit-GEMM conv)' if c['conv'] else ''}"
         a = fam[key]
         nb = c.get("batch", 1)
-        taps = c.get("R", 1) ** 2 if c["conv"] else 1
+        taps = c.get("R", 1) * c.get("S", c.get("R", 1)) if c["conv"] else 1
         m, n, k = c["M"], c["N"], c["K"]
         if c["form"] == "wgrad":                      # A (k x m) + B (k x n, gathered input counted once) + fp32 C read+write
             alg = nb * ((k * m + k * n / taps) * c["esz"] + 2 * m * n * c["c_esz"])
-        else:                                         # A (m x k, gathered input counted once) + B + C
-            alg = nb * ((m * k / taps + n * k) * c["esz"] + m * n * c["c_esz"])
+        else:                                         # A (m x k, gathered input counted once) + B + C + the epilogue's M x N operands
+            alg = nb * ((m * k / taps + n * k) * c["esz"] + m * n * c["c_esz"] + c.get("extra_mn", 0) * m * n * c["esz"])
         a["launches"] += 1; a["fetch_kib"] += f[1]; a["write_kib"] += w[1]; a["algorithmic_bytes"] += alg
         a["flop"] += 2.0 * m * n * k * nb
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python tools/gemm_breakdown.py "

@@ -143,6 +143,21 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     }
     p.a_bytes = (uint32_t)(fast ? d->a_bytes : 0);
     p.b_bytes = (uint32_t)(fast ? d->b_bytes : 0);
+    static const bool no_remap = getenv("CB_GEMM_NO_XCD_REMAP") != nullptr;
+    static const bool no_tuned = getenv("CB_GEMM_NO_TUNED") != nullptr;
+    CB_REQUIRE(d->tile >= 0 && d->tile <= 4, "cb_gemm: bad tile %d", d->tile);
+    CB_REQUIRE(d->xcd_order >= 0 && d->xcd_order <= 2, "cb_gemm: bad xcd_order %d", d->xcd_order);
+    int tile = d->tile, xcd = d->xcd_order;
+    if (d->dtype == CB_BF16 && !no_tuned && (tile == 0 || xcd == 0)) {
+        if (const cbgemm::TunedEntry* e = cbgemm::tuned_lookup(d->a_mode, d->b_mode, d->M, d->N, d->K, p.batch, p.R * p.S, p.split_k)) {
+            if (tile == 0) tile = e->tile;
+            if (xcd == 0) xcd = e->xcd;
+            // weight-gradient form only (plain epilogue, fp32 C accumulated in place: any K split is valid): the measured best split
+            if (e->new_split > 0 && d->tile == 0 && d->a_mode == CB_KROW && d->c_f32 && d->accumulate && !d->C2 && !d->residual &&
+                !d->mask && !d->gelu_grad_pre && d->act == CB_ACT_NONE && !d->relu_after && !d->shift && d->dropout_p <= 0.f)
+                p.split_k = e->new_split;
+        }
+    }
     if (p.split_k > 1) {
         CB_REQUIRE(d->c_f32, "cb_gemm: split_k > 1 needs an fp32 output");
         CB_REQUIRE(!d->C2 && !d->residual && !d->mask && !d->gelu_grad_pre && d->act == CB_ACT_NONE && !d->relu_after && !d->shift && d->dropout_p <= 0.f,
@@ -168,17 +183,6 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     if (d->gelu_grad_pre) cv8 = cv8 && (d->ld_gelu % 8 == 0) && aligned16(d->gelu_grad_pre);
     static const bool no_wide = getenv("CB_GEMM_NO_WIDE_EPILOGUE") != nullptr;
     p.c_vec8 = cv8 && !no_wide;
-    static const bool no_remap = getenv("CB_GEMM_NO_XCD_REMAP") != nullptr;
-    static const bool no_tuned = getenv("CB_GEMM_NO_TUNED") != nullptr;
-    CB_REQUIRE(d->tile >= 0 && d->tile <= 4, "cb_gemm: bad tile %d", d->tile);
-    CB_REQUIRE(d->xcd_order >= 0 && d->xcd_order <= 2, "cb_gemm: bad xcd_order %d", d->xcd_order);
-    int tile = d->tile, xcd = d->xcd_order;
-    if (d->dtype == CB_BF16 && !no_tuned && (tile == 0 || xcd == 0)) {
-        if (const cbgemm::TunedEntry* e = cbgemm::tuned_lookup(d->a_mode, d->b_mode, d->M, d->N, d->K, p.batch, p.R * p.S, p.split_k)) {
-            if (tile == 0) tile = e->tile;
-            if (xcd == 0) xcd = e->xcd;
-        }
-    }
     // default workgroup order: XCD-compact (it won or tied on ~80 % of the round-2 sweep's shapes and lowers the fabric traffic)
     p.xcd_remap = !no_remap && xcd != 2;
 

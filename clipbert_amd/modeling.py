@@ -225,9 +225,9 @@ def _pick_split(mo, no, kred):
     ktiles = (kred + 63) // 64
     b64 = ((mo + 63) // 64) * ((no + 63) // 64)
     if b64 >= 200 or ktiles < 64:
-        return 1, 2
+        return 1, 0
     split = max(1, min(ktiles // 8, (400 + b64 // 2) // b64))
-    return split, 2
+    return split, 0          # tile 0: cb_gemm's tuned table / heuristics choose the tile (and may refine the split)
 
 
 # =================================================================================================

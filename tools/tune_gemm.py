@@ -76,9 +76,11 @@ def key_of(pos, kw):
             str(a.dtype).replace("torch.", ""))
 
 
-def time_config(pos, kw, tile, xcd, inner=16, outer=4, best_of=3):
+def time_config(pos, kw, tile, xcd, inner=16, outer=4, best_of=3, split=None):
     from clipbert_amd import ops
     kw = dict(kw, tile=tile, xcd_order=xcd)
+    if split is not None:
+        kw["split_k"] = split
 
     def burst():
         for _ in range(inner):
@@ -137,6 +139,16 @@ def main():
                 base = {kk: v for kk, v in kw.items() if kk not in ("tile", "xcd_order")}
                 us, err = time_config(pos, base, t, xcd)
                 res[f"{TILES[t]}/{'xcd' if xcd == 1 else 'rr'}"] = us if us is not None else None
+        # weight-gradient form (fp32 C, accumulate): the K split is free to choose as well
+        if k[0] == "wgrad" and k[6] == 1 and kw.get("out") is not None and kw["out"].dtype == torch.float32 and kw.get("accumulate"):
+            ktiles = (k[5] + 63) // 64
+            for sp in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48):
+                if sp == k[7] or sp > max(1, ktiles // 4):
+                    continue
+                for t in tiles:
+                    base = {kk: v for kk, v in kw.items() if kk not in ("tile", "xcd_order", "split_k")}
+                    us, err = time_config(pos, base, t, 1, split=sp)
+                    res[f"{TILES[t]}/xcd/s{sp}"] = us if us is not None else None
         flops = 2.0 * k[3] * k[4] * k[5] * k[6]
         good = {c: v for c, v in res.items() if v is not None and c != "auto"}
         best = min(good, key=good.get)

@@ -142,6 +142,89 @@ def train_step(model, optimizer, batch: Dict, cfg, global_step: int, sync=None, 
     return loss.detach()
 
 
+def _all_sum(x: float, group=None) -> float:
+    """sum of a host scalar over the ranks (the reference's sum(all_gather_list(x)), :254-256)"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return x
+    parts = [None] * dist.get_world_size(group)
+    dist.all_gather_object(parts, float(x), group=group)
+    return float(sum(parts))
+
+
+@torch.no_grad()
+def validate_retrieval(model, val_loader, eval_videos, cfg, gt_txt_id2vid_id=None, group=None) -> Dict[str, float]:
+    """validate of run_video_retrieval.py:224-276: mean ITM loss / accuracy over ``val_loader`` (single-clip batches as the
+    training set yields them) and the retrieval metrics of inference_retrieval over ``eval_videos``; sums over the ranks."""
+    was_training = model.training
+    model.eval()
+    loss, n_ex, n_correct = 0.0, 0, 0
+    for batch in val_loader:
+        batch = {k: v for k, v in batch.items() if k not in ("caption_ids", "vid_id")}
+        targets = batch["labels"]
+        out = model(dict(batch))
+        if torch.is_tensor(out["loss"]):
+            loss += float(out["loss"].sum().item())
+        n_ex += len(targets)
+        logits = out["logits"].float()
+        if logits.shape[1] == 2:
+            n_correct += int((logits.max(dim=-1)[1] == targets).sum().item())
+        else:                                                  # rank loss: first score of each group is the positive (:244-250)
+            pred = (torch.sigmoid(logits) > 0.5).long().view(out["loss"].shape[0], -1)
+            n_correct += int((pred[:, 0] == targets.view(out["loss"].shape[0], -1)[:, 0]).sum().item())
+    loss, n_ex, n_correct = _all_sum(loss, group), _all_sum(n_ex, group), _all_sum(n_correct, group)
+    _rows, metrics = inference_retrieval(model, eval_videos, cfg, gt_txt_id2vid_id, group=group)
+    model.train(was_training)
+    log = {"valid/loss": loss / max(n_ex, 1), "valid/acc": n_correct / max(n_ex, 1)}
+    for kind, m in (metrics or {}).items():
+        log.update({f"valid/{kind}_{k}": round(v, 4) for k, v in m.items()})
+    return log
+
+
+def start_training(model, optimizer, train_loader, cfg, sync=None, validate_fn=None, model_saver=None, restorer=None,
+                   total_n_examples: Optional[int] = None, fold_clips: bool = True, log_fn=None) -> int:
+    """The loop of start_training (run_video_retrieval.py:379-516 / run_video_qa.py:457-560) around train_step: infinite
+    iteration over ``train_loader`` until cfg.num_train_steps optimizer steps, gradient accumulation, LR schedules with the
+    multi-step epoch counter, validation + ``model_step_N.pt`` every cfg.valid_steps (and once at the end), restorer.step()
+    after every optimizer step.  ``train_loader`` yields collated batches (clipbert_amd.data.PrefetchLoader delivers them with
+    uint8 frames already in HBM).  Returns the final global step."""
+    from .data import InfiniteIterator
+    acc = max(1, int(_get(cfg, "gradient_accumulation_steps", 1) or 1))
+    global_step = restorer.global_step if restorer is not None else 0
+    num_train_steps, valid_steps = int(_get(cfg, "num_train_steps")), int(_get(cfg, "valid_steps", 0) or 0)
+    n_gpu = sync.world if sync is not None else 1
+    total_bsz = n_gpu * int(_get(cfg, "train_batch_size", 1)) * acc * int(_get(cfg, "max_n_example_per_group", 1) or 1)
+    model.train()
+
+    def run_validation(step):
+        if validate_fn is not None:
+            log = validate_fn(model, step)
+            if log_fn is not None and log is not None:
+                log_fn(step, log)
+        if model_saver is not None:
+            model_saver.save(step=step, model=model)
+
+    if global_step >= num_train_steps:
+        return global_step
+    for micro, batch in enumerate(InfiniteIterator(train_loader)):
+        n_epoch = int(1.0 * total_bsz * (global_step + 1) / total_n_examples) if total_n_examples else 0
+        loss = train_step(model, optimizer, batch, cfg, global_step, sync=sync, n_epoch=n_epoch, micro_step=micro, fold_clips=fold_clips)
+        if (micro + 1) % acc != 0:
+            continue
+        global_step += 1
+        if log_fn is not None:
+            log_fn(global_step, {"train/loss": float(loss.item()) if global_step % 50 == 0 else None})
+        if restorer is not None:
+            restorer.step()
+        if valid_steps and global_step % valid_steps == 0:
+            run_validation(global_step)
+        if global_step >= num_train_steps:
+            break
+    if not valid_steps or global_step % valid_steps != 0:
+        run_validation(global_step)
+    return global_step
+
+
 # ---- retrieval inference (:628-734) ------------------------------------------------------------------------------------
 @torch.no_grad()
 def inference_retrieval_video(model, visual_inputs: torch.Tensor, text_input_ids: torch.Tensor, text_input_mask: torch.Tensor,

@@ -97,6 +97,32 @@ def _train_multi_clip_accumulated(rank, world, out_path, compress=None):
         torch.save(dict(master=bank.master.clone(), norm=opt.grad_norm()), out_path)
 
 
+def _sharded_inference(rank, world, out_path, compress=None):
+    """configs[4] path: videos are independent units sharded over the ranks (tasks.shard_for_rank), every rank scores its
+    videos against all captions, ONE all-gather of the (vid_id, txt_id, score) rows (run_video_retrieval.py:696-724)."""
+    from types import SimpleNamespace
+    import test_model_small as T
+    from clipbert_amd import synthetic as S
+    from clipbert_amd import tasks
+    from oracle import clipbert_oracle as O
+    cfg, sd, model = T.build("retrieval", dict(num_labels=2, loss_type="ce", margin=0.1), torch.float32, torch.device("cpu"))
+    icfg = SimpleNamespace(inference_n_clips=2, num_frm=2, score_agg_func="lse", inference_batch_size=2)
+    n_vid = 3
+    ids, mask = S.synthetic_text(n_vid, 6, 9, cfg["vocab_size"])
+    ids = ids.clamp(max=cfg["vocab_size"] - 1)
+    videos = []
+    for v in range(n_vid):
+        fr = S.synthetic_frames(1, 4, 64, 100 + v)[..., :64, :].repeat(1, 1, 1, 1, 2).contiguous()
+        videos.append(dict(vid_id=f"video{v}", visual_inputs=O.image_norm(fr, S.PIXEL_MEAN, S.PIXEL_STD), text_input_ids=ids,
+                           text_input_mask=mask, caption_ids=[f"cap{j}" for j in range(n_vid)]))
+    mine = [videos[i] for i in tasks.shard_for_rank(n_vid, rank, world)]
+    gt = {f"cap{j}": f"video{j}" for j in range(n_vid)}
+    rows, metrics = tasks.inference_retrieval(model, mine, icfg, gt_txt_id2vid_id=gt)
+    assert len(rows) == n_vid * n_vid                    # every rank holds all rows after the gather
+    if rank == 0:
+        torch.save(dict(rows=sorted((r["vid_id"], r["txt_id"], r["score"]) for r in rows), metrics=metrics), out_path)
+
+
 def _worker(rank, world, port, out_path, compress=None, fn="one_step"):
     torch.set_num_threads(2)
     os.environ["EMUL_THREADS"] = "4"
@@ -104,7 +130,7 @@ def _worker(rank, world, port, out_path, compress=None, fn="one_step"):
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
-        (_train_one_step if fn == "one_step" else _train_multi_clip_accumulated)(rank, world, out_path, compress)
+        dict(one_step=_train_one_step, multi=_train_multi_clip_accumulated, infer=_sharded_inference)[fn](rank, world, out_path, compress)
     finally:
         dist.destroy_process_group()
 
@@ -132,3 +158,12 @@ def test_dp2_equals_dp1_on_the_global_batch(tmp_path):
     # is ~0, so bound the worst element by 2.5 lr and the mean deviation tightly
     diff = (c["master"] - b["master"]).abs()
     assert diff.max() < 2.5e-3 and diff.mean() < 2e-6, (diff.max(), diff.mean())
+
+
+def test_sharded_retrieval_inference_gathers_all_rows(tmp_path):
+    p2, p1 = str(tmp_path / "inf2.pt"), str(tmp_path / "inf1.pt")
+    mp.spawn(_worker, args=(2, _free_port(), p2, None, "infer"), nprocs=2, join=True)
+    mp.spawn(_worker, args=(1, _free_port(), p1, None, "infer"), nprocs=1, join=True)
+    a, b = torch.load(p2), torch.load(p1)
+    assert a["rows"] == b["rows"]                        # same (vid, txt, score) rows, scores rounded to 4 places
+    assert a["metrics"] == b["metrics"] and set(a["metrics"]) == {"text2video", "video2text"}

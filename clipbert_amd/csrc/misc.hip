@@ -124,6 +124,62 @@ __global__ void __launch_bounds__(256) dropout_kernel(const T* x, T* y, int64_t 
     }
 }
 
+// ---- ELU + BatchNorm1d of the regression head (ClipBertForRegression.regressor[1:3], src/modeling/modeling.py:461-466) ------
+// x: (B, D) pre-activation (output of regressor[0]); one thread per feature column walks the B rows (B = pairs in the batch,
+// D = hidden size: a few hundred rows x 768 columns -- latency-, not bandwidth-relevant).  training: batch statistics
+// (biased variance for the normalisation, unbiased for the running estimate, torch.nn.BatchNorm1d semantics).
+__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expm1f(v); }
+
+template <typename T>
+__global__ void __launch_bounds__(256) elu_bn1d_fwd_kernel(const T* x, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                                                          T* y, float* save_mean, float* save_invstd, int B, int D, int training,
+                                                          float momentum, float eps) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    float mean, invstd;
+    if (training) {
+        float s = 0.f;
+        for (int r = 0; r < B; ++r) s += elu1(to_f32(x[(int64_t)r * D + c]));
+        mean = s / (float)B;
+        float q = 0.f;
+        for (int r = 0; r < B; ++r) { const float d = elu1(to_f32(x[(int64_t)r * D + c])) - mean; q += d * d; }
+        const float var = q / (float)B;
+        invstd = rsqrtf(var + eps);
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (B > 1 ? q / (float)(B - 1) : var);
+    } else {
+        mean = run_mean[c];
+        invstd = rsqrtf(run_var[c] + eps);
+    }
+    if (save_mean) { save_mean[c] = mean; save_invstd[c] = invstd; }
+    const float g = gamma[c] * invstd, b = beta[c];
+    for (int r = 0; r < B; ++r) y[(int64_t)r * D + c] = from_f32<T>((elu1(to_f32(x[(int64_t)r * D + c])) - mean) * g + b);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) elu_bn1d_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* save_mean,
+                                                          const float* save_invstd, T* dx, float* dgamma, float* dbeta, int B, int D,
+                                                          int training) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    const float mean = save_mean[c], invstd = save_invstd[c], g = gamma[c];
+    float sdy = 0.f, sdyx = 0.f;
+    for (int r = 0; r < B; ++r) {
+        const float d = to_f32(dy[(int64_t)r * D + c]);
+        sdy += d;
+        sdyx += d * (elu1(to_f32(x[(int64_t)r * D + c])) - mean) * invstd;
+    }
+    dgamma[c] += sdyx;
+    dbeta[c] += sdy;
+    const float k1 = training ? sdy / (float)B : 0.f, k2 = training ? sdyx / (float)B : 0.f;
+    for (int r = 0; r < B; ++r) {
+        const float xv = to_f32(x[(int64_t)r * D + c]);
+        const float xh = (elu1(xv) - mean) * invstd;
+        const float de = g * invstd * (to_f32(dy[(int64_t)r * D + c]) - k1 - xh * k2);
+        dx[(int64_t)r * D + c] = from_f32<T>(de * (xv > 0.f ? 1.f : __expf(xv)));
+    }
+}
+
 // ---- clip aggregation (a20: run_video_retrieval.py:402-418 training, :664-682 inference) -------------------------
 // logits are clip-major [N][B*C] fp32 (the stack of the per-clip forward outputs); one thread per (pair, class).
 __global__ void __launch_bounds__(256) clip_agg_fwd_kernel(const float* x, int N, int64_t bc, int mode, float* out, int32_t* argmax) {
@@ -298,4 +354,27 @@ extern "C" int cb_act_bwd(int32_t dtype, int32_t act, const void* dy, const void
     else if (dtype == CB_F32) hipLaunchKernelGGL((act_bwd_kernel<float>), g, b, 0, cb_stream(stream), act, (const float*)dy, (const float*)ref, (float*)dx, n);
     else return cb_fail("cb_act_bwd: bad dtype");
     return cb_launch_status("cb_act_bwd");
+}
+
+extern "C" int cb_elu_bn1d_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                               void* y, float* save_mean, float* save_invstd, int32_t B, int32_t D, int32_t training, float momentum,
+                               float eps, void* stream) {
+    CB_REQUIRE(x && gamma && beta && running_mean && running_var && y && B > 0 && D > 0, "cb_elu_bn1d_fwd: bad arguments");
+    CB_REQUIRE((save_mean == nullptr) == (save_invstd == nullptr), "cb_elu_bn1d_fwd: save_mean and save_invstd go together");
+    dim3 g((unsigned)((D + 255) / 256)), b(256);
+    if (dtype == CB_BF16) hipLaunchKernelGGL((elu_bn1d_fwd_kernel<bf16>), g, b, 0, cb_stream(stream), (const bf16*)x, gamma, beta, running_mean, running_var, (bf16*)y, save_mean, save_invstd, B, D, training, momentum, eps);
+    else if (dtype == CB_F32) hipLaunchKernelGGL((elu_bn1d_fwd_kernel<float>), g, b, 0, cb_stream(stream), (const float*)x, gamma, beta, running_mean, running_var, (float*)y, save_mean, save_invstd, B, D, training, momentum, eps);
+    else return cb_fail("cb_elu_bn1d_fwd: bad dtype");
+    return cb_launch_status("cb_elu_bn1d_fwd");
+}
+
+extern "C" int cb_elu_bn1d_bwd(int32_t dtype, const void* dy, const void* x, const float* gamma, const float* save_mean,
+                               const float* save_invstd, void* dx, float* dgamma, float* dbeta, int32_t B, int32_t D, int32_t training,
+                               void* stream) {
+    CB_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && B > 0 && D > 0, "cb_elu_bn1d_bwd: bad arguments");
+    dim3 g((unsigned)((D + 255) / 256)), b(256);
+    if (dtype == CB_BF16) hipLaunchKernelGGL((elu_bn1d_bwd_kernel<bf16>), g, b, 0, cb_stream(stream), (const bf16*)dy, (const bf16*)x, gamma, save_mean, save_invstd, (bf16*)dx, dgamma, dbeta, B, D, training);
+    else if (dtype == CB_F32) hipLaunchKernelGGL((elu_bn1d_bwd_kernel<float>), g, b, 0, cb_stream(stream), (const float*)dy, (const float*)x, gamma, save_mean, save_invstd, (float*)dx, dgamma, dbeta, B, D, training);
+    else return cb_fail("cb_elu_bn1d_bwd: bad dtype");
+    return cb_launch_status("cb_elu_bn1d_bwd");
 }

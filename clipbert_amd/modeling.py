@@ -1046,6 +1046,81 @@ class ClipBertForSequenceClassification(_ClipBertHead):
         return logits, loss
 
 
+class BatchNorm1d(nn.Module):
+    """parameter / buffer holder with torch.nn.BatchNorm1d's state-dict keys"""
+    def __init__(self, d, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d))
+        self.bias = nn.Parameter(torch.zeros(d))
+        self.register_buffer("running_mean", torch.zeros(d))
+        self.register_buffer("running_var", torch.ones(d))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.eps, self.momentum = eps, momentum
+
+
+class _EluBnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, x, rt, bn, training):
+        xc = x.contiguous()
+        y, sm, si = ops.elu_bn1d_fwd(xc, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps, save=True)
+        if training:
+            bn.num_batches_tracked += 1
+        ctx.rt, ctx.bn, ctx.training, ctx.saved = rt, bn, training, (xc, sm, si)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, sm, si = ctx.saved
+        bank, bn = ctx.rt.bank, ctx.bn
+        dx = ops.elu_bn1d_bwd(dy.contiguous(), xc, bn.weight, sm, si, bank.grad_image(bn.weight), bank.grad_image(bn.bias), ctx.training)
+        return None, dx, None, None, None
+
+
+class ClipBertForRegression(_ClipBertHead):
+    """src/modeling/modeling.py:454-507: pooled -> dropout -> Linear -> ELU -> BatchNorm1d -> dropout -> Linear(1); MSE loss.
+    (No runner of the reference instantiates it -- the TGIF "count" task goes through ClipBertForSequenceClassification with
+    num_labels = 1 -- but it is part of the module API.)"""
+    def __init__(self, config):
+        super().__init__(config)
+        d = self.config.hidden_size
+        self.regressor = nn.ModuleList([Linear(d, d), nn.Identity(), BatchNorm1d(d), nn.Identity(), Linear(d, 1)])
+
+    def forward(self, text_input_ids, visual_inputs, text_input_mask, labels=None, src_row=None):
+        rt = self.rt
+        _, pooled = self.bert(text_input_ids, visual_inputs, text_input_mask, src_row, pooled_dropout=True)
+        reg = self.regressor
+        h = _LinearFn.apply(rt.anchor, pooled, rt, reg[0].weight, reg[0].bias, ACT_NONE, False, None)
+        h = _EluBnFn.apply(rt.anchor, h, rt, reg[2], self.training)
+        p = _drop_p(self, self.training)
+        if p > 0:
+            h = _DropoutFn.apply(h, rt, p, rt.forward_count)
+        logits = _LinearFn.apply(rt.anchor, h, rt, reg[4].weight, reg[4].bias, ACT_NONE, True, None)
+        logits, loss = self.calc_loss(logits, labels)
+        return dict(logits=logits, loss=loss)
+
+    def calc_loss(self, logits, labels):
+        if labels is None:
+            return logits, 0
+        if self.config.loss_type == "mse":
+            return logits, (logits.view(-1) - labels.view(-1).to(logits.dtype)) ** 2
+        raise ValueError(f"Invalid option {self.config.loss_type} for config.loss_type")
+
+
+_SITE_REG = 6
+
+
+class _DropoutFn(torch.autograd.Function):
+    """nn.Dropout on a small head activation (the regression head's second dropout): stateless hash mask, same in backward"""
+    @staticmethod
+    def forward(ctx, x, rt, p, fwd_i):
+        ctx.rt, ctx.p, ctx.seed = rt, p, _seed(_SITE_REG, 0, fwd_i)
+        return ops.dropout(x.contiguous(), p, ctx.seed, rt.seed_dev)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout(dy.contiguous(), ctx.p, ctx.seed, ctx.rt.seed_dev), None, None, None
+
+
 class _PredictionHeadTransform(nn.Module):
     def __init__(self, config):
         super().__init__()

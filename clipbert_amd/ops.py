@@ -306,6 +306,25 @@ def dropout(x, p, seed=0, seed_ptr=None, out=None):
     return y
 
 
+def elu_bn1d_fwd(x, gamma, beta, running_mean, running_var, training: bool, momentum: float = 0.1, eps: float = 1e-5, save: bool = False):
+    """ELU + BatchNorm1d over the batch (ClipBertForRegression.regressor[1:3]); returns (y, save_mean, save_invstd)."""
+    b, d = x.shape
+    y = torch.empty_like(x)
+    sm = torch.empty(d, dtype=torch.float32, device=x.device) if save else None
+    si = torch.empty(d, dtype=torch.float32, device=x.device) if save else None
+    _chk(_lib.get().cb_elu_bn1d_fwd(dtype_code(x.dtype), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(y),
+                                    _ptr(sm), _ptr(si), b, d, int(training), momentum, eps, _stream(x)), "cb_elu_bn1d_fwd")
+    return y, sm, si
+
+
+def elu_bn1d_bwd(dy, x, gamma, save_mean, save_invstd, dgamma, dbeta, training: bool):
+    b, d = x.shape
+    dx = torch.empty_like(x)
+    _chk(_lib.get().cb_elu_bn1d_bwd(dtype_code(x.dtype), _ptr(dy), _ptr(x), _ptr(gamma), _ptr(save_mean), _ptr(save_invstd), _ptr(dx),
+                                    _ptr(dgamma), _ptr(dbeta), b, d, int(training), _stream(x)), "cb_elu_bn1d_bwd")
+    return dx
+
+
 AGG_MEAN, AGG_MAX, AGG_LSE = 0, 1, 2
 
 

@@ -116,6 +116,15 @@ def transformer_state_dict(cfg: dict, head: str = "retrieval", seed: int = 42,
         sd[c + "predictions.decoder.weight"] = sd[b + "embeddings.word_embeddings.weight"]
         sd[c + "predictions.decoder.bias"] = sd[c + "predictions.bias"]
         lin(c + "seq_relationship", 2, d)
+    elif head == "regression":
+        r = prefix + "regressor."
+        lin(r + "0", d, d)
+        sd[r + "2.weight"] = _uniform(seed, r + "2.weight", (d,), 0.5, 1.5)
+        sd[r + "2.bias"] = _normal(seed, r + "2.bias", (d,), 0.1)
+        sd[r + "2.running_mean"] = _normal(seed, r + "2.running_mean", (d,), 0.02)
+        sd[r + "2.running_var"] = _uniform(seed, r + "2.running_var", (d,), 0.001, 0.003)     # ELU(N(0, 0.02)-ish) has var ~1e-3
+        sd[r + "2.num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+        lin(r + "4", 1, d)
     else:
         n_out = 1 if head == "multiple_choice" else cfg["num_labels"]
         lin(prefix + "classifier.0", 2 * d, d)

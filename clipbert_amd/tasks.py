@@ -337,6 +337,32 @@ def qa_predict(model, batch: Dict, cfg, fold_clips: bool = False) -> List[int]:
     return (pooled + 0.5).long().clamp(min=1, max=10).reshape(-1).tolist()
 
 
+@torch.no_grad()
+def validate_qa(model, val_loader, cfg, group=None, fold_clips: bool = True):
+    """validate of run_video_qa.py:216-362 without the dataset-specific score tables: per batch the pooled prediction of
+    qa_predict over cfg.inference_n_clips clips -> rows dict(question_id, answer); with labels in the batch also the overall
+    accuracy (classification tasks) / mean absolute error rounded as the reference reports it (count), summed over ranks."""
+    was_training = model.training
+    model.eval()
+    rows, n_ex, n_hit, abs_err = [], 0, 0, 0.0
+    for batch in val_loader:
+        qids = batch.get("question_ids", list(range(n_ex, n_ex + len(batch["n_examples_list"]))))
+        b = {k: v for k, v in batch.items() if k != "question_ids"}
+        pred = qa_predict(model, b, cfg, fold_clips=fold_clips)
+        rows.extend(dict(question_id=q, answer=a) for q, a in zip(qids, pred))
+        if batch.get("labels") is not None:
+            gt = batch["labels"].view(-1).tolist()
+            n_ex += len(gt)
+            n_hit += sum(int(a == int(g)) for a, g in zip(pred, gt))
+            abs_err += sum(abs(a - g) for a, g in zip(pred, gt))
+    n_ex, n_hit, abs_err = _all_sum(n_ex, group), _all_sum(n_hit, group), _all_sum(abs_err, group)
+    model.train(was_training)
+    log = {}
+    if n_ex:
+        log = {"valid/overall_acc": round(100.0 * n_hit / n_ex, 2)} if _get(cfg, "task", "action") != "count" else {"valid/mae": round(abs_err / n_ex, 2)}
+    return rows, log
+
+
 # ---- metrics (:519-625) ------------------------------------------------------------------------------------------------
 def retrieval_metrics_from_scores(score_matrix, gt_cols: Sequence[int]) -> Dict[str, float]:
     """score_matrix (#queries, #candidates), gt_cols[i] = index of query i's ground-truth candidate -> recall@{1,5,10} in %,

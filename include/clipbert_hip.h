@@ -239,6 +239,17 @@ int cb_lse_loss(const float* logits, const int64_t* labels, int32_t n_clips, int
                 float* dlogits, void* stream);
 int cb_sq_sum(const float* g, int64_t n, float* out_accum, void* stream);
 
+/* ELU followed by BatchNorm1d over the batch dimension -- regressor[1:3] of ClipBertForRegression
+ * (src/modeling/modeling.py:461-466; torch.nn.ELU + torch.nn.BatchNorm1d semantics).  x, y: (B, D).  training = 1: batch
+ * statistics (biased variance), running_mean / running_var updated in place with `momentum` (unbiased variance); training = 0:
+ * the running statistics.  save_mean / save_invstd (D floats each, optional) are what the backward consumes. */
+int cb_elu_bn1d_fwd(int32_t dtype, const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    void* y, float* save_mean, float* save_invstd, int32_t B, int32_t D, int32_t training, float momentum, float eps,
+                    void* stream);
+/* dx = d(loss)/d(x) through BatchNorm1d and ELU; dgamma / dbeta (fp32, D) are ACCUMULATED (one writer per column). */
+int cb_elu_bn1d_bwd(int32_t dtype, const void* dy, const void* x, const float* gamma, const float* save_mean, const float* save_invstd,
+                    void* dx, float* dgamma, float* dbeta, int32_t B, int32_t D, int32_t training, void* stream);
+
 const char* cb_last_error(void);
 int cb_version(void);
 

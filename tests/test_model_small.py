@@ -13,7 +13,8 @@ SMALL = dict(O.BASE_CONFIG, hidden_size=128, num_attention_heads=2, intermediate
              vocab_size=200, max_position_embeddings=32, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
 
 HEAD_CLS = dict(retrieval=M.ClipBertForVideoTextRetrieval, multiple_choice=M.ClipBertForMultipleChoice,
-                sequence_classification=M.ClipBertForSequenceClassification, pretraining=M.ClipBertForPreTraining)
+                sequence_classification=M.ClipBertForSequenceClassification, pretraining=M.ClipBertForPreTraining,
+                regression=M.ClipBertForRegression)
 
 
 _SD_CACHE = {}
@@ -267,3 +268,37 @@ def test_other_heads_and_losses_match_oracle(hw, head, extra, repeat, label_kind
         g_ref = sdr[name].grad
         rel = (params[name].grad.cpu() - g_ref).norm() / max(g_ref.norm().item(), 1e-8)
         assert rel < (2e-3 if hw.name == "emul" else 5e-3), (name, float(rel))
+
+
+@pytest.mark.parametrize("train_bn", [False, True])
+def test_regression_head_matches_oracle(hw, train_bn):
+    """ClipBertForRegression (modeling.py:454-507): Linear -> ELU -> BatchNorm1d -> Linear(1), MSE loss; eval mode (running
+    statistics) and training mode with the dropouts at 0 (batch statistics + running-estimate update), forward and gradients."""
+    extra = dict(num_labels=1, loss_type="mse", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    cfg, sd, model = build("regression", extra, torch.float32, hw.dev)
+    model.train(train_bn)
+    batch = make_batch(cfg, "regression", 3, 2, 6)
+    batch["labels"] = torch.tensor([1.0, 4.0, 2.0, 7.0, 3.0, 5.0])
+    out = model(to_dev(dict(batch), hw.dev))
+    model.rt.bank.zero_grad()
+    out["loss"].mean().backward()
+    sdr = {k: v.clone().requires_grad_(v.is_floating_point() and "norm" not in k and "running" not in k) for k, v in sd.items()}
+    b2 = dict(batch)
+    counts = b2.pop("n_examples_list")
+    grid = O.repeat_rows(O.grid_feat_backbone(sdr, b2.pop("visual_inputs"), "cnn."), counts)
+    ref = O.regression_forward(sdr, b2["text_input_ids"], grid, b2["text_input_mask"], cfg, labels=b2["labels"], training=train_bn)
+    ref["loss"].mean().backward()
+    torch.testing.assert_close(out["logits"].float().cpu(), ref["logits"].detach(), rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(out["loss"].float().cpu(), ref["loss"].detach(), rtol=2e-3, atol=2e-3)
+    for key in ("transformer.regressor.0.weight", "transformer.regressor.2.weight", "transformer.regressor.2.bias", "transformer.regressor.4.weight",
+                "transformer.bert.pooler.dense.weight"):
+        p = dict(model.named_parameters())[key]
+        g_ref = sdr[key].grad
+        scale = max(float(g_ref.abs().max()), 1e-6)
+        assert float((p.grad.cpu() - g_ref).abs().max()) / scale < 5e-3, key
+    bn = model.transformer.regressor[2]
+    if train_bn:                                             # running estimates moved towards the batch statistics, once
+        assert int(bn.num_batches_tracked) == 1
+        assert float((bn.running_mean.cpu() - sd["transformer.regressor.2.running_mean"]).abs().max()) > 0
+    else:
+        torch.testing.assert_close(bn.running_var.cpu(), sd["transformer.regressor.2.running_var"], rtol=0, atol=0)

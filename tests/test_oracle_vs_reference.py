@@ -16,7 +16,7 @@ SMALL = dict(O.BASE_CONFIG, num_hidden_layers=2, vocab_size=2000, max_position_e
 def _ref(head, cfg):
     mo, _ = ref_shim.load_reference_modeling()
     cls = dict(retrieval=mo.ClipBertForVideoTextRetrieval, multiple_choice=mo.ClipBertForMultipleChoice,
-               sequence_classification=mo.ClipBertForSequenceClassification,
+               sequence_classification=mo.ClipBertForSequenceClassification, regression=mo.ClipBertForRegression,
                pretraining=mo.ClipBertForPreTraining)[head]
     model = cls(ref_shim.make_config(cfg)).eval()
     sd = S.transformer_state_dict(cfg, head, 7, "")
@@ -32,6 +32,7 @@ def _ref(head, cfg):
     ("sequence_classification", dict(num_labels=11, loss_type="ce")),
     ("sequence_classification", dict(num_labels=11, loss_type="bce")),
     ("sequence_classification", dict(num_labels=1, loss_type="ce")),
+    ("regression", dict(num_labels=1, loss_type="mse")),
 ])
 def test_heads_bit_close(head, extra):
     cfg = dict(SMALL, **extra)

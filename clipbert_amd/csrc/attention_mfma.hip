@@ -37,14 +37,29 @@ __device__ __forceinline__ bf16x8 ld_frag(const bf16* base, int64_t stride, int 
     return z;
 }
 
-// natural [row][64] image of a strided matrix in LDS, rows [L, rows) zero-filled (whole block)
-__device__ __forceinline__ void stage(const bf16* base, int64_t stride, int L, int rows, unsigned char* dst, int tid, int nthreads) {
-    for (int idx = tid; idx < rows * 8; idx += nthreads) {
-        const int r = idx >> 3, seg = idx & 7;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (r < L) v = *reinterpret_cast<const u32x4*>(base + (int64_t)r * stride + seg * 8);
-        *reinterpret_cast<u32x4*>(dst + r * RS + seg * 16) = v;
-    }
+// Natural [row][64] images of NMAT strided matrices in LDS, rows [L, ROWS) zero-filled (whole block), in two phases: ALL global
+// loads of the block are issued before the first LDS write, so the staging costs one memory round trip instead of one per
+// matrix and loop iteration (the kernels are latency-bound: a head is a few dozen MFMAs).
+template <int NMAT, int ROWS, int NTHR>
+__device__ __forceinline__ void stage_all(const bf16* const (&base)[NMAT], const int64_t (&stride)[NMAT], unsigned char* const (&dst)[NMAT],
+                                          int L, int tid) {
+    constexpr int ITER = (ROWS * 8 + NTHR - 1) / NTHR;
+    u32x4 v[NMAT][ITER];
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = tid + it * NTHR, r = idx >> 3, seg = idx & 7;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            v[m][it] = (idx < ROWS * 8 && r < L) ? *reinterpret_cast<const u32x4*>(base[m] + (int64_t)r * stride[m] + seg * 8) : z;
+        }
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = tid + it * NTHR, r = idx >> 3, seg = idx & 7;
+            if (idx < ROWS * 8) *reinterpret_cast<u32x4*>(dst[m] + r * RS + seg * 16) = v[m][it];
+        }
 }
 
 // Transposed operand of a staged matrix X[row][d]: fragment whose MFMA row a <-> d = 16*(a>>2) + 4*dt + (a&3) and
@@ -90,7 +105,6 @@ __global__ void __launch_bounds__(64 * NT) attn_fwd_mfma_kernel(const bf16* qkv,
     const bf16* qb = qkv + (int64_t)b * L * stride + h * DH;
     const bf16* kb = qb + H * DH;
     const bf16* vb = qb + 2 * H * DH;
-    stage(vb, stride, L, NP * 32, Vs, threadIdx.x, 64 * NT);
 
     bf16x8 qf[2], kf[NT][2];
 #pragma unroll
@@ -99,6 +113,12 @@ __global__ void __launch_bounds__(64 * NT) attn_fwd_mfma_kernel(const bf16* qkv,
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) kf[t][ks] = ld_frag(kb, stride, 16 * t + c, L, 32 * ks + 8 * g);
+    {
+        const bf16* const bases[1] = {vb};
+        const int64_t strides[1] = {stride};
+        unsigned char* const dsts[1] = {Vs};
+        stage_all<1, NP * 32, 64 * NT>(bases, strides, dsts, L, threadIdx.x);
+    }
     float madd[NT][4];
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt)
@@ -198,10 +218,6 @@ __global__ void __launch_bounds__(128 * NT) attn_bwd_mfma_kernel(const bf16* qkv
     const bf16* ob = ctx + (int64_t)b * L * cstride + h * DH;
     const bf16* gb = dctx + (int64_t)b * L * cstride + h * DH;
     bf16* dqb = dqkv + (int64_t)b * L * stride + h * DH;
-    stage(kb, stride, L, NP * 32, Ks, threadIdx.x, NTHR);
-    stage(qb, stride, L, NP * 32, Qs, threadIdx.x, NTHR);
-    stage(gb, cstride, L, NP * 32, Gs, threadIdx.x, NTHR);
-
     const bf16* pa = yph ? qb : kb;
     const bf16* pb = yph ? gb : vb;
     const bf16* oa = yph ? kb : qb;
@@ -220,11 +236,20 @@ __global__ void __launch_bounds__(128 * NT) attn_bwd_mfma_kernel(const bf16* qkv
             pbf[t][ks] = ld_frag(pb, spb, 16 * t + c, L, d);
         }
     }
+    bf16x8 ofr[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) ofr[ks] = ld_frag(ob, cstride, col, L, 32 * ks + 8 * g);     // (X waves use it below)
+    {   // all global loads of the block are in flight before the first wait
+        const bf16* const bases[3] = {kb, qb, gb};
+        const int64_t strides[3] = {stride, stride, cstride};
+        unsigned char* const dsts[3] = {Ks, Qs, Gs};
+        stage_all<3, NP * 32, NTHR>(bases, strides, dsts, L, threadIdx.x);
+    }
     if (!yph) {
         float part = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 of = ld_frag(ob, cstride, col, L, 32 * ks + 8 * g);
+            const bf16x8 of = ofr[ks];
 #pragma unroll
             for (int e = 0; e < 8; ++e) part += (float)oof[ks][e] * (float)of[e];
         }
@@ -335,11 +360,15 @@ __global__ void __launch_bounds__(64 * NT) attn_fwd_mfma_big_kernel(const bf16* 
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int64_t stride = 3 * H * DH;
     const bf16* qb = qkv + (int64_t)b * L * stride + h * DH;
-    stage(qb + H * DH, stride, L, ROWS, Ks, threadIdx.x, 64 * NT);
-    stage(qb + 2 * H * DH, stride, L, ROWS, Vs, threadIdx.x, 64 * NT);
     bf16x8 qf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[ks] = ld_frag(qb, stride, 16 * it + c, L, 32 * ks + 8 * g);
+    {
+        const bf16* const bases[2] = {qb + H * DH, qb + 2 * H * DH};
+        const int64_t strides[2] = {stride, stride};
+        unsigned char* const dsts[2] = {Ks, Vs};
+        stage_all<2, ROWS, 64 * NT>(bases, strides, dsts, L, threadIdx.x);
+    }
     __syncthreads();
     if (16 * it >= L) return;                           // (no barrier below)
     const int i = 16 * it + c;                          // this lane's query (accumulator column)
@@ -418,16 +447,21 @@ __global__ void __launch_bounds__(64 * NT) attn_bwd_mfma_big_kernel(const bf16* 
     const bf16* ob = ctx + (int64_t)b * L * cstride + h * DH;
     const bf16* gb = dctx + (int64_t)b * L * cstride + h * DH;
     bf16* dqb = dqkv + (int64_t)b * L * stride + h * DH;
-    stage(qb, stride, L, ROWS, Qs, threadIdx.x, NTHR);
-    stage(qb + H * DH, stride, L, ROWS, Ks, threadIdx.x, NTHR);
-    stage(qb + 2 * H * DH, stride, L, ROWS, Vs, threadIdx.x, NTHR);
-    stage(gb, cstride, L, ROWS, Gs, threadIdx.x, NTHR);
     const int col = 16 * wt + c;                                    // own query (X) / key (Y)
     {
+        bf16x8 ofr[2], gfr[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { ofr[ks] = ld_frag(ob, cstride, col, L, 32 * ks + 8 * g); gfr[ks] = ld_frag(gb, cstride, col, L, 32 * ks + 8 * g); }
+        {   // all global loads of the block are in flight before the first wait
+            const bf16* const bases[4] = {qb, qb + H * DH, qb + 2 * H * DH, gb};
+            const int64_t strides[4] = {stride, stride, stride, cstride};
+            unsigned char* const dsts[4] = {Qs, Ks, Vs, Gs};
+            stage_all<4, ROWS, NTHR>(bases, strides, dsts, L, threadIdx.x);
+        }
         float part = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 of = ld_frag(ob, cstride, col, L, 32 * ks + 8 * g), gf = ld_frag(gb, cstride, col, L, 32 * ks + 8 * g);
+            const bf16x8 of = ofr[ks], gf = gfr[ks];
 #pragma unroll
             for (int e = 0; e < 8; ++e) part += (float)gf[e] * (float)of[e];
         }

@@ -74,7 +74,7 @@ def _train_multi_clip_accumulated(rank, world, out_path, compress=None):
     cfg, sd, model = T.build("retrieval", dict(num_labels=2, loss_type="ce", margin=0.1), torch.float32, torch.device("cpu"))
     from clipbert_amd import synthetic as S
     from oracle import clipbert_oracle as O
-    frames = S.synthetic_frames(4, 4, 64, 7)[..., :64, :].repeat(1, 1, 1, 1, 2).contiguous()     # 4 videos x (2 clips x 2 frames)
+    frames = S.synthetic_frames(4, 4, 64, 7).contiguous()                                       # 4 videos x (2 clips x 2 frames), 64 x 64 px: one visual token
     ids, mask = S.synthetic_text(4, 6, 7, cfg["vocab_size"])                                     # 1 text each
     full = dict(visual_inputs=O.image_norm(frames, S.PIXEL_MEAN, S.PIXEL_STD), text_input_ids=ids.clamp(max=cfg["vocab_size"] - 1),
                 text_input_mask=mask, labels=torch.tensor([1, 0, 0, 1]))
@@ -112,7 +112,7 @@ def _sharded_inference(rank, world, out_path, compress=None):
     ids = ids.clamp(max=cfg["vocab_size"] - 1)
     videos = []
     for v in range(n_vid):
-        fr = S.synthetic_frames(1, 4, 64, 100 + v)[..., :64, :].repeat(1, 1, 1, 1, 2).contiguous()
+        fr = S.synthetic_frames(1, 4, 64, 100 + v).contiguous()                             # 64 x 64 px: one visual token
         videos.append(dict(vid_id=f"video{v}", visual_inputs=O.image_norm(fr, S.PIXEL_MEAN, S.PIXEL_STD), text_input_ids=ids,
                            text_input_mask=mask, caption_ids=[f"cap{j}" for j in range(n_vid)]))
     mine = [videos[i] for i in tasks.shard_for_rank(n_vid, rank, world)]

@@ -23,7 +23,7 @@ CPU = torch.device("cpu")
 def _batches(cfg, n, seed0=50, n_clips=2):
     out = []
     for i in range(n):
-        frames = S.synthetic_frames(2, 2 * n_clips, 64, seed0 + i)[..., :64, :].repeat(1, 1, 1, 1, 2).contiguous()   # uint8
+        frames = S.synthetic_frames(2, 2 * n_clips, 64, seed0 + i).contiguous()   # uint8, 64 x 64 px: one visual token
         ids, mask = S.synthetic_text(4, 6, seed0 + i, cfg["vocab_size"])
         out.append(dict(visual_inputs=frames, text_input_ids=ids.clamp(max=cfg["vocab_size"] - 1), text_input_mask=mask,
                         labels=torch.tensor([1, 0, 1, 0]), n_examples_list=[2, 2], caption_ids=[0, 1, 2, 3]))

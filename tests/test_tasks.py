@@ -163,7 +163,7 @@ def test_gradient_accumulation_sums_micro_batches(hw):
     assert (bank.master - w0).abs().max() > 0
 
 
-@pytest.mark.parametrize("pool", ["mean", "lse"])
+@pytest.mark.parametrize("pool", [pytest.param("mean", marks=pytest.mark.gpu), "lse"])
 def test_folded_clips_equal_clip_loop(hw, pool):
     """tasks.forward_clips_stack(fold=True) -- all clips in ONE CNN batch and ONE encoder batch -- gives the logits, the
     loss and the parameter gradients of the reference's clip loop (run_video_retrieval.py:391-419)."""

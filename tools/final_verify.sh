@@ -4,8 +4,11 @@ cd $R
 (time timeout 900 python -m pytest tests -x -q -m gpu) > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 (time timeout 300 python -c "import __graft_entry__ as g; g.smoke()") > $O/smoke.log 2>&1; grep smoke $O/smoke.log
 (time timeout 600 python bench.py) > $O/bench.log 2>&1; grep -E "timed region|real" $O/bench.log
-
-
-cd /tmp; export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/trace/bench.log 2>&1
-grep -c . $O/trace/bench_kernel_stats.csv
+(time timeout 300 python bench.py --mode tgif --no-cpu-baseline) > $O/bench_tgif.log 2>&1; grep -E "timed region" $O/bench_tgif.log
+(time timeout 300 python bench.py --mode infer16 --no-cpu-baseline) > $O/bench_infer16.log 2>&1; grep -E "timed region" $O/bench_infer16.log
+# N > 1 control flow on this 1-GPU box: two ranks share GPU 0, gloo collectives (captures, split replay plan, bucketed exchange,
+# cross-rank parameter check, sharded inference + row gather).  A control-flow check, not a measurement.
+export CB_BENCH_SHARE_GPU=1 CB_BENCH_BACKEND=gloo
+(time timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1) > $O/dp2_train.log 2>&1; grep -E "DP self-check|replay plan|timed region" $O/dp2_train.log
+(time timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --mode infer16 --steps 3 --warmup 1) > $O/dp2_infer.log 2>&1; grep -E "timed region|rows_gathered" $O/dp2_infer.log | cut -c1-200
+unset CB_BENCH_SHARE_GPU CB_BENCH_BACKEND

@@ -1372,7 +1372,10 @@ int launch_gemm(const GP& p, bool fast, hipStream_t st) {
     if (fast) {
         const int taps = p.R * p.S;
         if constexpr (sizeof(T) == 2) {
-            // The LDS-DMA ring kernel is OPT-IN (CB_GEMM_DMA=1).  Measured on MI355X against the register-staged kernel
+            // The LDS-DMA ring kernel is OPT-IN (CB_GEMM_DMA=1).  Round 2 re-measured it on 128x128 tiles with 3 / 4 / 5 stages
+            // (2-4 K tiles in flight, tools/dma_probe.py): 366 / 370 / 400 TF on 2624x3072x768 against 542 TF of the two-blocks-
+            // per-CU register ring, 465-514 vs 734 TF on 8192x8192x1024 -- its one block per CU and one barrier per K step lose
+            // more than the deeper prefetch gains.  Round 1: measured on MI355X against the register-staged kernel
             // below for every GEMM of the step: equal where K is long (both run into the L2->LDS bandwidth of the 64x64
             // tile, profiles/r01_gemm_l2_analysis.md; an 8-stage ring, CB_GEMM_DMA_DEEP=1, changes nothing either) and
             // 10-20 % slower for short-K convolutions (its 64 KiB ring halves the blocks per CU).

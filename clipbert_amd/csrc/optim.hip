@@ -25,6 +25,37 @@ __global__ void __launch_bounds__(256) sq_sum_kernel(const float* g, int64_t n, 
     if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+// Deterministic variant: a FIXED grid writes one partial per block, a second one-block launch adds the partials in index order.
+// The result depends on (n, grid) only -- not on the order blocks retire -- so every data-parallel rank, holding bit-identical
+// all-reduced gradients, derives the bit-identical clip coefficient and stays bit-identical after the update.
+__global__ void __launch_bounds__(256) sq_sum_partial_kernel(const float* g, int64_t n, float* partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            f32x4 v = load4(g + i);
+            s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        } else {
+            for (int64_t j = i; j < n; ++j) s += g[j] * g[j];
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(256) sq_sum_final_kernel(const float* partial, int nb, float* out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] += (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 struct PMV { float p, m, v; };
 __device__ __forceinline__ PMV adamw_one(float p, float g, float m, float v, float gs, float b1, float b2, float eps,
                                          float step_size, float decay) {
@@ -79,6 +110,17 @@ extern "C" int cb_sq_sum(const float* g, int64_t n, float* out_accum, void* stre
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(sq_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, cb_stream(stream), g, n, out_accum);
     return cb_launch_status("cb_sq_sum");
+}
+
+extern "C" int cb_sq_sum_det(const float* g, int64_t n, float* out_accum, float* ws, int32_t ws_floats, void* stream) {
+    CB_REQUIRE(g && out_accum && ws && ws_floats >= 1, "cb_sq_sum_det: null pointer / empty workspace");
+    if (n == 0) return 0;
+    int64_t blocks = (n + 1023) / 1024;
+    if (blocks > ws_floats) blocks = ws_floats;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(sq_sum_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, cb_stream(stream), g, n, ws);
+    hipLaunchKernelGGL(sq_sum_final_kernel, dim3(1), dim3(256), 0, cb_stream(stream), ws, (int)blocks, out_accum);
+    return cb_launch_status("cb_sq_sum_det");
 }
 
 extern "C" int cb_adamw(float* p, const float* g, float* m, float* v, void* w16, int64_t n, const float* hyper,

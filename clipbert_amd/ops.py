@@ -284,8 +284,12 @@ def act_bwd(act, dy, ref):
     return dx
 
 
-def sq_sum(g, out):
-    _chk(_lib.get().cb_sq_sum(_ptr(g), g.numel(), _ptr(out), _stream(g)), "cb_sq_sum")
+def sq_sum(g, out, ws=None):
+    """out += sum(g^2); with a scratch tensor ``ws`` (fp32, <= 1024 floats used) the result is independent of workgroup timing"""
+    if ws is not None:
+        _chk(_lib.get().cb_sq_sum_det(_ptr(g), g.numel(), _ptr(out), _ptr(ws), ws.numel(), _stream(g)), "cb_sq_sum_det")
+    else:
+        _chk(_lib.get().cb_sq_sum(_ptr(g), g.numel(), _ptr(out), _stream(g)), "cb_sq_sum")
 
 
 def adamw_hyper(lr, beta1, beta2, eps, weight_decay, step, max_norm=-1.0, grad_scale=1.0):

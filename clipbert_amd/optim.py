@@ -81,6 +81,7 @@ class FusedAdamW:
         self._hp_events = [None, None]
         self._hp_dev = torch.zeros(N_GROUPS, 16, dtype=torch.float32, device=dev)
         self._sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._sq_ws = torch.zeros(1024, dtype=torch.float32, device=dev)     # partials of the order-independent norm reduction
         self._last_scale = 1.0
 
     def zero_grad(self):
@@ -119,7 +120,7 @@ class FusedAdamW:
         sq = None
         if self.max_grad_norm > 0:
             self._sq.zero_()
-            ops.sq_sum(bank.grad[:bank.n_train], self._sq)
+            ops.sq_sum(bank.grad[:bank.n_train], self._sq, self._sq_ws)     # deterministic: ranks must derive the same clip coefficient
             sq = self._sq
         for g, pg in enumerate(self.param_groups):
             a, b = pg["range"]

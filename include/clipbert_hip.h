@@ -238,6 +238,11 @@ int cb_clip_aggregate_bwd(const float* dout, const float* logits, const float* o
 int cb_lse_loss(const float* logits, const int64_t* labels, int32_t n_clips, int32_t B, int32_t C, float* loss, const float* dloss,
                 float* dlogits, void* stream);
 int cb_sq_sum(const float* g, int64_t n, float* out_accum, void* stream);
+/* The same sum with a result that does not depend on the order in which workgroups retire (fixed grid of <= min(1024, ws_floats)
+ * blocks -> `ws` partials -> one block adds them in index order): data-parallel ranks holding bit-identical all-reduced
+ * gradients derive the bit-identical clip coefficient (torch.nn.utils.clip_grad_norm_ in run_video_retrieval.py:477-482 is
+ * deterministic per rank too).  ws: caller-owned scratch of ws_floats floats. */
+int cb_sq_sum_det(const float* g, int64_t n, float* out_accum, float* ws, int32_t ws_floats, void* stream);
 
 /* ELU followed by BatchNorm1d over the batch dimension -- regressor[1:3] of ClipBertForRegression
  * (src/modeling/modeling.py:461-466; torch.nn.ELU + torch.nn.BatchNorm1d semantics).  x, y: (B, D).  training = 1: batch

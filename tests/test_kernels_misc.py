@@ -192,6 +192,16 @@ def test_adamw_matches_reference_restatement_with_clipping(hw):
     sq = zeros(1)
     ops.sq_sum(g, sq)
     torch.testing.assert_close(sq[0], (g * g).sum(), rtol=1e-5, atol=1e-3)
+    # the order-independent variant (what FusedAdamW uses): same value, bit-identical from call to call
+    big = rnd(3 * 1024 * 1024 + 5, seed=9)
+    ws = zeros(1024)
+    outs = []
+    for _ in range(3):
+        o = zeros(1)
+        ops.sq_sum(big, o, ws)
+        outs.append(float(o[0]))
+    assert outs[0] == outs[1] == outs[2]
+    assert abs(outs[0] - float((big.double() ** 2).sum())) / outs[0] < 1e-5
     gc, total = O.clip_grad_norm([g.cpu()], 5.0)
     pr, mr, vr = O.adamw_step(p.cpu(), gc[0], m.cpu(), v.cpu(), step=3, lr=5e-5, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=1e-3)
     pr, mr, vr = pr.to(DEV[0]), mr.to(DEV[0]), vr.to(DEV[0])

@@ -92,6 +92,9 @@ class FusedAdamW:
         """Host half of a step: advance the step count, pack lr / bias corrections / clip norm / grad_scale of the 8 groups
         and enqueue their (tiny) H2D copy on the current stream.  Never captured into a hipGraph: a training loop that
         replays a captured step calls ``prepare_step()`` eagerly before each replay and captures only ``launch()``."""
+        if self._hp_dev.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("FusedAdamW.prepare_step() inside a hipGraph capture: capture launch() only and call "
+                               "prepare_step() eagerly before each replay (see INTEGRATION.md)")
         self.step_count += 1
         self._last_scale = grad_scale
         slot = self.step_count & 1
@@ -105,9 +108,6 @@ class FusedAdamW:
             host[g, :HP_COUNT + 1] = torch.tensor(hp[:HP_COUNT + 1])
         self._hp_dev.copy_(host, non_blocking=True)
         if self._hp_dev.is_cuda:
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("FusedAdamW.prepare_step() inside a hipGraph capture: capture launch() only and call "
-                                   "prepare_step() eagerly before each replay (see INTEGRATION.md)")
             ev = torch.cuda.Event()
             ev.record()
             self._hp_events[slot] = ev

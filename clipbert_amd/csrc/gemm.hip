@@ -8,7 +8,8 @@
 //
 // * 256 threads = 4 waves (2x2); block tile 128x128 (one block per CU with a 2-stage register ring, or two blocks per CU with
 //   one stage and <= 256 registers) / 128x64 / 64x64, K step 64 (bf16) / 32 (fp32).  256-row tiles (256x128, 256x64: one block
-//   per CU, ~450 registers) were built and measured in round 2: never the fastest on any shape of the benchmark steps.
+//   per CU, ~450 registers) were built and measured in round 2: never the fastest on any shape of the benchmark steps; a 128x128 tile
+//   with two register stages AND two blocks per CU (192-242 VGPR, four K tiles in flight per CU) measured equal to the one-stage one.
 // * k-contiguous operands: LDS image [rows][128 B], 16-byte segments XOR-swizzled with (row & 7): every ds_read_b128 of an
 //   MFMA fragment is conflict-free.  Reduction-major operands (weights in dgrad, both operands in wgrad) keep their
 //   natural [k][rows] image in LDS and are read with ds_read_b64_tr_b16 -- no transposed copy anywhere.

@@ -1264,8 +1264,8 @@ template <int ROWS, int KMODE> struct KrowDma {
     }
 };
 
-template <int BM, int BN, typename LA, typename LB, int NST>
-__global__ void __launch_bounds__(256) gemm_dma_kernel(GP p) {
+template <int BM, int BN, typename LA, typename LB, int NST, int OCC = 1>
+__global__ void __launch_bounds__(256, OCC) gemm_dma_kernel(GP p) {
     using T = bf16;
     using X = Tr<bf16>;
     constexpr int BK = X::BK;
@@ -1380,7 +1380,7 @@ int launch_gemm(const GP& p, bool fast, hipStream_t st) {
             // tile, profiles/r01_gemm_l2_analysis.md; an 8-stage ring, CB_GEMM_DMA_DEEP=1, changes nothing either) and
             // 10-20 % slower for short-K convolutions (its 64 KiB ring halves the blocks per CU).
             static const bool use_dma = getenv("CB_GEMM_DMA") != nullptr;
-            constexpr int NST = (BM >= 128 && BN >= 128) ? 3 : 4;
+            constexpr int NST = (BM >= 128 && BN >= 128) ? (OCC >= 2 ? 2 : 3) : 4;    // (OCC 2: 64 KiB ring, two blocks per CU)
             const bool ct_ok = p.Ct % Tr<bf16>::BK == 0;
             if (use_dma) {
                 dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.split_k * (p.batch > 1 ? p.batch : 1));
@@ -1395,7 +1395,7 @@ int launch_gemm(const GP& p, bool fast, hipStream_t st) {
                 return cb_launch_status("cb_gemm");                                                           \
             }                                                                                                 \
         }                                                                                                     \
-        hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, LA_, LB_, NST>), grid, dim3(NTHREADS), 0, st, p);         \
+        hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, LA_, LB_, NST, OCC>), grid, dim3(NTHREADS), 0, st, p);    \
         return cb_launch_status("cb_gemm");                                                                   \
     } while (0)
                 using RA0 = RowkDma<BM, false>; using RA1 = RowkDma<BM, true>; using RB0 = RowkDma<BN, false>;

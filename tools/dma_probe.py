@@ -36,6 +36,7 @@ if __name__ == "__main__":
                           ("register ring 128x128 PF=2 (tile 1)", dict(PROBE_TILE="1")),
                           ("register ring 64x64 (tile 2)", dict(PROBE_TILE="2")),
                           ("DMA ring 128x128, 3 stages", dict(PROBE_TILE="1", CB_GEMM_DMA="1", CB_GEMM_DMA_KROW="1")),
+                          ("DMA ring 128x128, 2 stages, two blocks per CU (tile 4)", dict(PROBE_TILE="4", CB_GEMM_DMA="1", CB_GEMM_DMA_KROW="1")),
                           ("DMA ring 64x64, 4 stages", dict(PROBE_TILE="2", CB_GEMM_DMA="1", CB_GEMM_DMA_KROW="1")),
                           ("DMA ring 64x64, 8 stages", dict(PROBE_TILE="2", CB_GEMM_DMA="1", CB_GEMM_DMA_KROW="1", CB_GEMM_DMA_DEEP="1"))]:
             print(name, flush=True)

@@ -171,7 +171,7 @@ def main():
 
     def device_step_single():
         """everything a 1-GPU step enqueues (capturable)"""
-        opt.zero_grad()
+        opt.zero_grad(lazy=True)
         model.rt.pending_encoder_nodes = 0
         loss = forward_loss()
         loss.backward()
@@ -181,7 +181,7 @@ def main():
 
     def train_step_eager():
         host_prepare()
-        opt.zero_grad()
+        opt.zero_grad(lazy=True)
         model.rt.pending_encoder_nodes = 0
         loss = forward_loss()
         loss.backward()                         # (N > 1: the transformer buckets leave from inside the encoder backward)
@@ -289,7 +289,7 @@ def main():
         cut = {}
 
         def part_a():
-            opt.zero_grad()
+            opt.zero_grad(lazy=True)
             model.rt.pending_encoder_nodes = 0
             vis = frames.view(bv * nclip, T, *frames.shape[2:]) if (fold and nclip > 1) else frames
             assert fold or nclip == 1, "the split replay plan needs the folded clip forward (one encoder node)"

@@ -722,10 +722,19 @@ def _encoder_wgrads(model, pk, gs, M):
         (gs.att, stk.ctx, d, d, [bank.grad_image(l.attention.output.dense.weight) for l in layers], [bank.grad_image(l.attention.output.dense.bias) for l in layers]),
         (gs.qkv, stk.x, 3 * d, d, [qkv_w(l) for l in layers], [qkv_b(l) for l in layers]),
     ]
+    # first-writer stores: after zero_grad(lazy=True) the encoder weight gradients were NOT zeroed -- the batched launches
+    # overwrite them (no memset, no fp32 read-modify-write); any other path zeroes the span first
+    fresh = bank.take_fresh()
+    batched = [(_uniform_stride(gws), _uniform_stride(gbs)) for _g, _x, _n, _k, gws, gbs in kinds]
+    all_batched = all(sw is not None and sb is not None and n % 8 == 0 and k % 8 == 0 for (sw, sb), (_g, _x, n, k, _w, _b) in zip(batched, kinds))
+    if fresh and not all_batched:
+        a, b = bank.lazy_span
+        bank.grad[a:b].zero_()
+        fresh = False
     for g, x, n, k, gws, gbs in kinds:
         sw, sb = _uniform_stride(gws), _uniform_stride(gbs)
         if sw is not None and sb is not None and n % 8 == 0 and k % 8 == 0:
-            ops.gemm(g, x, n, k, M, out=gws[0], a_mode=KROW, lda=n, b_mode=KROW, ldb=k, ldc=k, accumulate=True, a_rowsum=gbs[0],
+            ops.gemm(g, x, n, k, M, out=gws[0], a_mode=KROW, lda=n, b_mode=KROW, ldb=k, ldc=k, accumulate=not fresh, a_rowsum=gbs[0],
                      batch=nl, batch_strides=(M * n, M * k, sw, sb))
         else:
             for li in range(nl):
@@ -1230,6 +1239,11 @@ class ClipBert(nn.Module):
                 m.rt = rt
             if isinstance(m, (Conv2d,)):
                 m._ss = None
+        enc = []
+        for layer in self.transformer.bert.encoder.layer:
+            enc += [layer.attention.self.query.weight, layer.attention.self.key.weight, layer.attention.self.value.weight,
+                    layer.attention.output.dense.weight, layer.intermediate.dense.weight, layer.output.dense.weight]
+        rt.bank.set_lazy_span(enc)
         return self
 
     def _ensure_prepared(self, device):

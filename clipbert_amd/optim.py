@@ -84,8 +84,10 @@ class FusedAdamW:
         self._sq_ws = torch.zeros(1024, dtype=torch.float32, device=dev)     # partials of the order-independent norm reduction
         self._last_scale = 1.0
 
-    def zero_grad(self):
-        self.bank.zero_grad()
+    def zero_grad(self, lazy: bool = False):
+        """lazy=True (training loops whose backward always follows, e.g. tasks.train_step / bench.py): skip the memset of the
+        encoder weight gradients; the batched weight-gradient launches overwrite them (ParamBank.set_lazy_span)."""
+        self.bank.zero_grad(lazy=lazy)
 
     @torch.no_grad()
     def prepare_step(self, grad_scale: float = 1.0):
@@ -117,6 +119,9 @@ class FusedAdamW:
         """Device half of a step (capturable): global grad-norm reduction, then clip + AdamW + bf16 weight refresh, reading
         the hyper-parameters from the device array prepare_step() filled."""
         bank = self.bank
+        if getattr(bank, "lazy_fresh", False):
+            raise RuntimeError("FusedAdamW: zero_grad(lazy=True) was not followed by an encoder backward -- the encoder weight "
+                               "gradients were never written")
         sq = None
         if self.max_grad_norm > 0:
             self._sq.zero_()

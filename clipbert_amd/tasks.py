@@ -116,7 +116,7 @@ def train_step(model, optimizer, batch: Dict, cfg, global_step: int, sync=None, 
     acc = max(1, int(_get(cfg, "gradient_accumulation_steps", 1) or 1))
     first, last = micro_step % acc == 0, (micro_step + 1) % acc == 0
     if first:
-        optimizer.zero_grad()
+        optimizer.zero_grad(lazy=True)                      # a backward always follows: the encoder weight gradients are overwritten
     rt = model.rt
     rt.pending_encoder_nodes = 0
     hook = rt.after_encoder_backward

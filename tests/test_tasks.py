@@ -211,3 +211,40 @@ def test_each_forward_draws_its_own_dropout_masks(hw):
     with torch.no_grad():
         l2 = model(dict(b))["logits"].float().cpu()
     torch.testing.assert_close(l2, l0, rtol=0, atol=0)
+
+
+def test_lazy_zero_grad_first_writer_stores(hw):
+    """zero_grad(lazy=True) skips the memset of the encoder weight gradients; the batched weight-gradient launches then STORE
+    instead of accumulating.  Same gradients as the fully zeroed path, also when garbage sits in the span beforehand, for a
+    second (accumulating) backward, and the optimizer refuses to step if no backward followed."""
+    cfg, sd, model = build("retrieval", RET, torch.float32, hw.dev)
+    model.eval()
+    bank = model.rt.bank
+    assert bank.lazy_span is not None and bank.lazy_span[1] - bank.lazy_span[0] > 0.5 * bank.n_train * 0   # the encoder weights tile one range
+    opt = optim.FusedAdamW(bank, lr=1e-3, betas=(0.9, 0.98), weight_decay=0.0, cnn_lr=1e-3, max_grad_norm=-1.0)
+    vis = _frames(2, 2, 61)
+    ids, mask = S.synthetic_text(4, 6, 61, cfg["vocab_size"])
+    b = to_dev(dict(visual_inputs=vis, text_input_ids=ids.clamp(max=cfg["vocab_size"] - 1), text_input_mask=mask,
+                    labels=torch.tensor([1, 0, 0, 1]), n_examples_list=[2, 2]), hw.dev)
+
+    def backward():
+        model(dict(b))["loss"].mean().backward()
+
+    opt.zero_grad()
+    backward()
+    ref1 = bank.grad.clone()
+    backward()
+    ref2 = bank.grad.clone()                                   # two accumulated backwards
+    a, e = bank.lazy_span
+    bank.grad[a:e].fill_(123.0)                                # stale values in the span
+    opt.zero_grad(lazy=True)
+    assert float(bank.grad[a:e].min()) == 123.0                # not touched by the lazy zero
+    backward()
+    torch.testing.assert_close(bank.grad[a:e], ref1[a:e], rtol=0, atol=0)           # stored, not accumulated onto the stale values
+    torch.testing.assert_close(bank.grad, ref1, rtol=1e-4, atol=1e-7)               # (atomically accumulated gradients elsewhere: order noise)
+    backward()                                                 # the second backward accumulates
+    torch.testing.assert_close(bank.grad, ref2, rtol=1e-4, atol=1e-7)
+    opt.zero_grad(lazy=True)
+    with pytest.raises(RuntimeError):
+        opt.step()                                             # no backward wrote the span
+    opt.zero_grad()

@@ -23,7 +23,8 @@ TILES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "128x128o2"}
 
 
 def record_calls(mode):
-    """bench.py --mode <mode> in-process up to the first eager step, with ops.gemm logged."""
+    """bench.py --mode <mode> in-process up to the first eager step, with ops.gemm logged.  ``mode`` may carry extra bench flags
+    after a colon, e.g. "train:--size 448 --txt-len 20 --n-clips 4" (the JSON config's native sizes)."""
     import importlib
     bench = importlib.import_module("bench")
     from clipbert_amd import ops
@@ -47,7 +48,8 @@ def record_calls(mode):
 
     bench.log = log_hook
     argv = sys.argv
-    sys.argv = ["bench.py", "--mode", mode, "--no-cpu-baseline", "--no-roofline"]
+    extra = mode.split(":", 1)[1].split() if ":" in mode else []
+    sys.argv = ["bench.py", "--mode", mode.split(":", 1)[0], "--no-cpu-baseline", "--no-roofline"] + extra
     try:
         bench.main()
     except Stop:
@@ -117,7 +119,7 @@ def main():
     tiles = [int(t) for t in args.tiles.split(",")]
     os.environ["CB_GEMM_NO_TUNED"] = "1"                  # the recorded calls carry tile = 0: measure the heuristics as "auto"
     problems = {}
-    for mode in args.modes.split(","):
+    for mode in args.modes.split(";" if ";" in args.modes or ":" in args.modes else ","):
         calls = record_calls(mode)
         print(f"[tune] mode {mode}: {len(calls)} cb_gemm calls per step", file=sys.stderr, flush=True)
         for pos, kw in calls:

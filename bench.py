@@ -188,9 +188,10 @@ def main():
         if model.rt.after_encoder_backward is None:
             sync.reduce_transformer()
         sync.reduce_cnn()
-        sync.wait()
+        g16 = sync.wire_gradients()             # N > 1, bf16 wire: AdamW reads the reduced image directly (no cast back to fp32)
+        sync.wait(cast_back=g16 is None)
         model.rt.seed_dev.add_(1)
-        opt.launch()
+        opt.launch(grad16=g16)
         return loss
 
     def forward_only_step():
@@ -309,7 +310,7 @@ def main():
 
         def part_c():
             model.rt.seed_dev.add_(1)
-            opt.launch()
+            opt.launch(grad16=sync.wire_gradients())
 
         ga, loss = capture(part_a)
         gb, _ = capture(part_b)
@@ -321,7 +322,7 @@ def main():
             sync.reduce_transformer()
             gb.replay()
             sync.reduce_cnn()
-            sync.wait()
+            sync.wait(cast_back=sync.wire_gradients() is None)
             gc.replay()
         run, plan = run_split, "three hipGraphs, eager bucketed bf16 all-reduces (transformer buckets overlap the ResNet backward)"
     log(f"replay plan: {plan}")

@@ -61,6 +61,8 @@ _SIGNATURES = {
     "cb_lse_loss": [vp, vp, i32, i32, i32, vp, vp, vp, vp],
     "cb_sq_sum": [vp, i64, vp, vp],
     "cb_sq_sum_det": [vp, i64, vp, vp, i32, vp],
+    "cb_sq_sum_det_bf16": [vp, i64, vp, vp, i32, vp],
+    "cb_adamw_g16": [vp, vp, vp, vp, vp, i64, vp, vp, vp],
     "cb_elu_bn1d_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp],
     "cb_elu_bn1d_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
 }

@@ -28,7 +28,8 @@ __global__ void __launch_bounds__(256) sq_sum_kernel(const float* g, int64_t n, 
 // Deterministic variant: a FIXED grid writes one partial per block, a second one-block launch adds the partials in index order.
 // The result depends on (n, grid) only -- not on the order blocks retire -- so every data-parallel rank, holding bit-identical
 // all-reduced gradients, derives the bit-identical clip coefficient and stays bit-identical after the update.
-__global__ void __launch_bounds__(256) sq_sum_partial_kernel(const float* g, int64_t n, float* partial) {
+template <typename G>
+__global__ void __launch_bounds__(256) sq_sum_partial_kernel(const G* g, int64_t n, float* partial) {
     __shared__ float red[4];
     float s = 0.f;
     int64_t stride = (int64_t)gridDim.x * 256 * 4;
@@ -37,7 +38,7 @@ __global__ void __launch_bounds__(256) sq_sum_partial_kernel(const float* g, int
             f32x4 v = load4(g + i);
             s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
         } else {
-            for (int64_t j = i; j < n; ++j) s += g[j] * g[j];
+            for (int64_t j = i; j < n; ++j) { const float x = to_f32(g[j]); s += x * x; }
         }
     }
     s = wave_sum(s);
@@ -69,7 +70,8 @@ __device__ __forceinline__ PMV adamw_one(float p, float g, float m, float v, flo
     return r;
 }
 
-__global__ void __launch_bounds__(256) adamw_kernel(float* p, const float* g, float* m, float* v, bf16* w16, int64_t n,
+template <typename G>
+__global__ void __launch_bounds__(256) adamw_kernel(float* p, const G* g, float* m, float* v, bf16* w16, int64_t n,
                                                     const float* hp, const float* sq_sum) {
     const float lr = hp[CB_HP_LR], b1 = hp[CB_HP_BETA1], b2 = hp[CB_HP_BETA2], eps = hp[CB_HP_EPS];
     const float wd = hp[CB_HP_WD], max_norm = hp[CB_HP_MAX_NORM];
@@ -94,7 +96,7 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* p, const float* g, fl
         if (w16) store4(w16 + i, pp);
     } else {
         for (; i < n; ++i) {
-            PMV r = adamw_one(p[i], g[i], m[i], v[i], gs, b1, b2, eps, step_size, decay);
+            PMV r = adamw_one(p[i], to_f32(g[i]), m[i], v[i], gs, b1, b2, eps, step_size, decay);
             p[i] = r.p; m[i] = r.m; v[i] = r.v;
             if (w16) w16[i] = (bf16)r.p;
         }
@@ -118,16 +120,37 @@ extern "C" int cb_sq_sum_det(const float* g, int64_t n, float* out_accum, float*
     int64_t blocks = (n + 1023) / 1024;
     if (blocks > ws_floats) blocks = ws_floats;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(sq_sum_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, cb_stream(stream), g, n, ws);
+    hipLaunchKernelGGL(sq_sum_partial_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, cb_stream(stream), g, n, ws);
     hipLaunchKernelGGL(sq_sum_final_kernel, dim3(1), dim3(256), 0, cb_stream(stream), ws, (int)blocks, out_accum);
     return cb_launch_status("cb_sq_sum_det");
+}
+
+// bf16 gradients (the data-parallel wire image after the all-reduce): the optimizer consumes them directly, no cast back to fp32
+extern "C" int cb_sq_sum_det_bf16(const void* g16, int64_t n, float* out_accum, float* ws, int32_t ws_floats, void* stream) {
+    CB_REQUIRE(g16 && out_accum && ws && ws_floats >= 1, "cb_sq_sum_det_bf16: null pointer / empty workspace");
+    if (n == 0) return 0;
+    int64_t blocks = (n + 1023) / 1024;
+    if (blocks > ws_floats) blocks = ws_floats;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(sq_sum_partial_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, cb_stream(stream), (const bf16*)g16, n, ws);
+    hipLaunchKernelGGL(sq_sum_final_kernel, dim3(1), dim3(256), 0, cb_stream(stream), ws, (int)blocks, out_accum);
+    return cb_launch_status("cb_sq_sum_det_bf16");
+}
+
+extern "C" int cb_adamw_g16(float* p, const void* g16, float* m, float* v, void* w16, int64_t n, const float* hyper,
+                            const float* grad_sq_sum, void* stream) {
+    CB_REQUIRE(p && g16 && m && v && hyper, "cb_adamw_g16: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(adamw_kernel<bf16>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, cb_stream(stream), p, (const bf16*)g16, m, v,
+                       (bf16*)w16, n, hyper, grad_sq_sum);
+    return cb_launch_status("cb_adamw_g16");
 }
 
 extern "C" int cb_adamw(float* p, const float* g, float* m, float* v, void* w16, int64_t n, const float* hyper,
                         const float* grad_sq_sum, void* stream) {
     CB_REQUIRE(p && g && m && v && hyper, "cb_adamw: bad arguments");
     if (n == 0) return 0;
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, cb_stream(stream), p, g, m, v, (bf16*)w16, n,
+    hipLaunchKernelGGL(adamw_kernel<float>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, cb_stream(stream), p, g, m, v, (bf16*)w16, n,
                        hyper, grad_sq_sum);
     return cb_launch_status("cb_adamw");
 }

@@ -76,11 +76,21 @@ class GradSync:
     def reduce_cnn(self):
         self._reduce(*self.c_range)
 
-    def wait(self):
+    def wire_gradients(self) -> Optional[torch.Tensor]:
+        """The flat bf16 gradient image (valid after wait(cast_back=False) once BOTH ranges were reduced): hand it to
+        FusedAdamW.step / launch(grad16=...) and the two cast-back passes over the 594 MB fp32 buffer disappear."""
+        return self._wire if (self.compress == "bf16" and self.world > 1) else None
+
+    def wait(self, cast_back: bool = True):
+        """cast_back=False (bf16 wire only): leave the reduced gradients in the wire buffer for an optimizer that reads bf16
+        (wire_gradients()); bank.grad then still holds THIS rank's un-reduced fp32 gradients."""
         for w in self._work:
             w.wait()
         self._work = []
         self._inflight = []
+        if not cast_back and self.compress == "bf16":
+            self._pending = []
+            return
         for s, e in self._pending:
             if self.bank.grad.is_cuda:
                 from . import ops

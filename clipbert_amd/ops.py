@@ -286,7 +286,10 @@ def act_bwd(act, dy, ref):
 
 def sq_sum(g, out, ws=None):
     """out += sum(g^2); with a scratch tensor ``ws`` (fp32, <= 1024 floats used) the result is independent of workgroup timing"""
-    if ws is not None:
+    if g.dtype == torch.bfloat16:
+        assert ws is not None, "bf16 gradients use the order-independent reduction (pass ws)"
+        _chk(_lib.get().cb_sq_sum_det_bf16(_ptr(g), g.numel(), _ptr(out), _ptr(ws), ws.numel(), _stream(g)), "cb_sq_sum_det_bf16")
+    elif ws is not None:
         _chk(_lib.get().cb_sq_sum_det(_ptr(g), g.numel(), _ptr(out), _ptr(ws), ws.numel(), _stream(g)), "cb_sq_sum_det")
     else:
         _chk(_lib.get().cb_sq_sum(_ptr(g), g.numel(), _ptr(out), _stream(g)), "cb_sq_sum")
@@ -298,7 +301,11 @@ def adamw_hyper(lr, beta1, beta2, eps, weight_decay, step, max_norm=-1.0, grad_s
 
 
 def adamw(p, g, m, v, w16, hyper_dev, grad_sq_sum=None):
-    """hyper_dev: DEVICE fp32 tensor of >= HP_COUNT entries (adamw_hyper)."""
+    """hyper_dev: DEVICE fp32 tensor of >= HP_COUNT entries (adamw_hyper).  g: fp32, or bf16 (the reduced data-parallel wire image)."""
+    if g.dtype == torch.bfloat16:
+        _chk(_lib.get().cb_adamw_g16(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(w16), p.numel(), _ptr(hyper_dev), _ptr(grad_sq_sum),
+                                     _stream(p)), "cb_adamw_g16")
+        return
     _chk(_lib.get().cb_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(w16), p.numel(), _ptr(hyper_dev),
                              _ptr(grad_sq_sum), _stream(p)), "cb_adamw")
 

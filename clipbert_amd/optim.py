@@ -115,9 +115,10 @@ class FusedAdamW:
             self._hp_events[slot] = ev
 
     @torch.no_grad()
-    def launch(self):
+    def launch(self, grad16: Optional[torch.Tensor] = None):
         """Device half of a step (capturable): global grad-norm reduction, then clip + AdamW + bf16 weight refresh, reading
-        the hyper-parameters from the device array prepare_step() filled."""
+        the hyper-parameters from the device array prepare_step() filled.  ``grad16``: consume these bf16 gradients (flat, same
+        layout as bank.grad -- GradSync's reduced wire image, ``sync.wire_gradients()``) instead of the fp32 buffer."""
         bank = self.bank
         if getattr(bank, "lazy_fresh", False):
             raise RuntimeError("FusedAdamW: zero_grad(lazy=True) was not followed by an encoder backward -- the encoder weight "
@@ -125,19 +126,21 @@ class FusedAdamW:
         sq = None
         if self.max_grad_norm > 0:
             self._sq.zero_()
-            ops.sq_sum(bank.grad[:bank.n_train], self._sq, self._sq_ws)     # deterministic: ranks must derive the same clip coefficient
+            src = bank.grad if grad16 is None else grad16
+            ops.sq_sum(src[:bank.n_train], self._sq, self._sq_ws)           # deterministic: ranks must derive the same clip coefficient
             sq = self._sq
         for g, pg in enumerate(self.param_groups):
             a, b = pg["range"]
             if b <= a:
                 continue
             w16 = bank.w16[a:b] if bank.w16 is not None else None
-            ops.adamw(bank.master[a:b], bank.grad[a:b], bank.exp_avg[a:b], bank.exp_avg_sq[a:b], w16, self._hp_dev[g], sq)
+            gsrc = bank.grad if grad16 is None else grad16
+            ops.adamw(bank.master[a:b], gsrc[a:b], bank.exp_avg[a:b], bank.exp_avg_sq[a:b], w16, self._hp_dev[g], sq)
 
-    def step(self, grad_scale: float = 1.0):
+    def step(self, grad_scale: float = 1.0, grad16: Optional[torch.Tensor] = None):
         """grad_scale multiplies the gradients first (1/world_size after a SUM all-reduce)."""
         self.prepare_step(grad_scale)
-        self.launch()
+        self.launch(grad16=grad16)
 
     def grad_norm(self) -> float:
         """Host-visible global norm of the (averaged) gradient of the last step (syncs)."""

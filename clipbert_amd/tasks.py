@@ -130,15 +130,16 @@ def train_step(model, optimizer, batch: Dict, cfg, global_step: int, sync=None, 
         rt.after_encoder_backward = hook
     if not last:
         return loss.detach()
-    scale = 1.0
+    scale, g16 = 1.0, None
     if sync is not None:
         if hook is None:
             sync.reduce_transformer()
         sync.reduce_cnn()
-        sync.wait()
+        g16 = sync.wire_gradients()                         # bf16 wire: the optimizer reads the reduced image directly
+        sync.wait(cast_back=g16 is None)
         scale = sync.grad_scale
     set_learning_rates(optimizer, cfg, global_step + 1, n_epoch)
-    optimizer.step(grad_scale=scale)
+    optimizer.step(grad_scale=scale, grad16=g16)
     return loss.detach()
 
 

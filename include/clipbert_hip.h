@@ -243,6 +243,12 @@ int cb_sq_sum(const float* g, int64_t n, float* out_accum, void* stream);
  * gradients derive the bit-identical clip coefficient (torch.nn.utils.clip_grad_norm_ in run_video_retrieval.py:477-482 is
  * deterministic per rank too).  ws: caller-owned scratch of ws_floats floats. */
 int cb_sq_sum_det(const float* g, int64_t n, float* out_accum, float* ws, int32_t ws_floats, void* stream);
+/* The same two for bf16 GRADIENTS: in data-parallel runs the all-reduce travels in bf16 (as the reference's apex-O2 fp16 gradients
+ * do through Horovod, run_video_retrieval.py:298-301); the optimizer then reads the reduced wire image directly instead of a
+ * copy cast back to fp32 (same values: bf16 -> fp32 is exact). */
+int cb_sq_sum_det_bf16(const void* g16, int64_t n, float* out_accum, float* ws, int32_t ws_floats, void* stream);
+int cb_adamw_g16(float* p, const void* g16, float* m, float* v, void* w16, int64_t n, const float* hyper, const float* grad_sq_sum,
+                 void* stream);
 
 /* ELU followed by BatchNorm1d over the batch dimension -- regressor[1:3] of ClipBertForRegression
  * (src/modeling/modeling.py:461-466; torch.nn.ELU + torch.nn.BatchNorm1d semantics).  x, y: (B, D).  training = 1: batch

@@ -46,7 +46,7 @@ def _train_one_step(rank, world, out_path, compress=None):
                      text_input_mask=full["text_input_mask"][2 * rank:2 * rank + 2].contiguous(),
                      n_examples_list=[2], labels=full["labels"][2 * rank:2 * rank + 2])
     bank = model.rt.bank
-    sync = GradSync(bank, compress=compress)
+    sync = GradSync(bank, compress="bf16" if compress == "bf16direct" else compress)
     sync.broadcast_parameters(0)
     calls = []
     model.rt.after_encoder_backward = lambda: (calls.append(1), sync.reduce_transformer())
@@ -55,8 +55,9 @@ def _train_one_step(rank, world, out_path, compress=None):
     out = model(batch)
     out["loss"].mean().backward()
     sync.reduce_cnn()
-    sync.wait()
-    opt.step(grad_scale=sync.grad_scale)
+    g16 = sync.wire_gradients() if compress == "bf16direct" else None     # the optimizer reads the reduced bf16 image itself
+    sync.wait(cast_back=g16 is None)
+    opt.step(grad_scale=sync.grad_scale, grad16=g16)
     assert calls == [1]                     # transformer bucket was launched from inside the backward
     if rank == 0:
         torch.save(dict(master=bank.master.clone(), norm=opt.grad_norm()), out_path)
@@ -146,11 +147,15 @@ def test_dp2_multi_clip_loop_with_accumulation(tmp_path):
 
 
 def test_dp2_equals_dp1_on_the_global_batch(tmp_path):
-    p2, p2c, p1 = str(tmp_path / "dp2.pt"), str(tmp_path / "dp2c.pt"), str(tmp_path / "dp1.pt")
+    p2, p2c, p2d, p1 = str(tmp_path / "dp2.pt"), str(tmp_path / "dp2c.pt"), str(tmp_path / "dp2d.pt"), str(tmp_path / "dp1.pt")
     mp.spawn(_worker, args=(2, _free_port(), p2), nprocs=2, join=True)
     mp.spawn(_worker, args=(2, _free_port(), p2c, "bf16"), nprocs=2, join=True)       # bf16 gradients on the wire
+    mp.spawn(_worker, args=(2, _free_port(), p2d, "bf16direct"), nprocs=2, join=True)  # ... consumed by AdamW without the cast back
     mp.spawn(_worker, args=(1, _free_port(), p1), nprocs=1, join=True)
     a, c, b = torch.load(p2), torch.load(p2c), torch.load(p1)
+    d = torch.load(p2d)
+    torch.testing.assert_close(d["master"], c["master"], rtol=0, atol=0)            # same values as cast-back + fp32 AdamW, bit for bit
+    assert d["norm"] == c["norm"]
     assert abs(a["norm"] - b["norm"]) / b["norm"] < 1e-3
     torch.testing.assert_close(a["master"], b["master"], rtol=1e-4, atol=2e-6)
     assert abs(c["norm"] - b["norm"]) / b["norm"] < 1e-2

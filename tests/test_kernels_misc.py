@@ -213,6 +213,17 @@ def test_adamw_matches_reference_restatement_with_clipping(hw):
     torch.testing.assert_close(m2, mr, rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(v2, vr, rtol=1e-5, atol=1e-8)
     torch.testing.assert_close(w16, pr.bfloat16())
+    # bf16 gradients (the reduced data-parallel wire image) == fp32 gradients holding the same bf16 values, bit for bit
+    g16 = g.bfloat16()
+    sq_a, sq_b, ws = zeros(1), zeros(1), zeros(1024)
+    ops.sq_sum(g16, sq_a, ws)
+    ops.sq_sum(g16.float(), sq_b, ws)
+    assert float(sq_a[0]) == float(sq_b[0])
+    pa, ma, va, pb, mb, vb = p.clone(), m.clone(), v.clone(), p.clone(), m.clone(), v.clone()
+    ops.adamw(pa, g16, ma, va, None, hp, grad_sq_sum=sq_a)
+    ops.adamw(pb, g16.float(), mb, vb, None, hp, grad_sq_sum=sq_b)
+    torch.testing.assert_close(pa, pb, rtol=0, atol=0)
+    torch.testing.assert_close(va, vb, rtol=0, atol=0)
 
 
 @pytest.mark.parametrize("dt", DT)

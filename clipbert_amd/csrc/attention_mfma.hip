@@ -62,6 +62,11 @@ __device__ __forceinline__ void stage_all(const bf16* const (&base)[NMAT], const
         }
 }
 
+// k-contiguous MFMA fragment (row `row`, head dims d..d+7) of a staged [row][64] image: one conflict-free ds_read_b128
+__device__ __forceinline__ bf16x8 lds_frag(const unsigned char* mat, int row, int d) {
+    return *reinterpret_cast<const bf16x8*>(mat + row * RS + d * 2);
+}
+
 // Transposed operand of a staged matrix X[row][d]: fragment whose MFMA row a <-> d = 16*(a>>2) + 4*dt + (a&3) and
 // whose k-slots (group g, e) <-> row = 32*pair + 16*(e>>2) + 4*g + (e&3) -- the slot order of pack_pair() below.
 // With it as the first MFMA operand the lane's 4 accumulator rows are d = 16*g + 4*dt + 0..3: 16 consecutive head
@@ -193,8 +198,12 @@ __global__ void __launch_bounds__(64 * NT) attn_fwd_mfma_kernel(const bf16* qkv,
 // matrices swapped:  tiles(rows of PA) x own columns of OA,
 //   X: PA = K, PB = V, OA = Q, OB = dO  ->  S^T = K.Q^T,  dP^T = V.dO^T,  dQ^T = K^T.dS^T
 //   Y: PA = Q, PB = dO, OA = K, OB = V  ->  S   = Q.K^T,  dP   = dO.V^T,  dK^T = Q^T.dS,  dV^T = dO^T.P_drop
+// Occupancy: the cross-modal batches give ~3 (batch, head) blocks per CU (64 pairs x 12 heads = 768 blocks); with NT = 3 a block is 6
+// waves, so all of them are resident at once only if 18 waves fit a CU (5 per SIMD: <= 96 registers).  The tiles' row operands
+// (K / V for the query-owning waves, Q / dO for the key-owning ones) are therefore read from the staged LDS images where they are
+// used instead of being preloaded from global memory into 16 * NT registers (104 registers: two blocks per CU, two rounds).
 template <int NT>
-__global__ void __launch_bounds__(128 * NT) attn_bwd_mfma_kernel(const bf16* qkv, const float* key_mask, const bf16* ctx, const bf16* dctx,
+__global__ void __launch_bounds__(128 * NT, (NT == 3 ? 5 : 1)) attn_bwd_mfma_kernel(const bf16* qkv, const float* key_mask, const bf16* ctx, const bf16* dctx,
                                                             const float* lse, bf16* dqkv, int B, int L, int H, float drop_p,
                                                             uint64_t seed, const uint64_t* seed_ptr) {
     constexpr int NP = (NT + 1) / 2;
@@ -203,6 +212,7 @@ __global__ void __launch_bounds__(128 * NT) attn_bwd_mfma_kernel(const bf16* qkv
     __shared__ __attribute__((aligned(16))) unsigned char Ks[NP * 32 * RS];
     __shared__ __attribute__((aligned(16))) unsigned char Qs[NP * 32 * RS];
     __shared__ __attribute__((aligned(16))) unsigned char Gs[NP * 32 * RS];
+    __shared__ __attribute__((aligned(16))) unsigned char Vs[NP * 32 * RS];
     __shared__ __attribute__((aligned(16))) float Dl[NP * 32];      // D_i = rowsum(dO * O)
     __shared__ __attribute__((aligned(16))) float Ll[NP * 32];      // lse_i (+big past L: probabilities of padding rows = 0)
     if (drop_p > 0.f && seed_ptr) seed += *seed_ptr;
@@ -218,32 +228,27 @@ __global__ void __launch_bounds__(128 * NT) attn_bwd_mfma_kernel(const bf16* qkv
     const bf16* ob = ctx + (int64_t)b * L * cstride + h * DH;
     const bf16* gb = dctx + (int64_t)b * L * cstride + h * DH;
     bf16* dqb = dqkv + (int64_t)b * L * stride + h * DH;
-    const bf16* pa = yph ? qb : kb;
-    const bf16* pb = yph ? gb : vb;
     const bf16* oa = yph ? kb : qb;
     const bf16* oo = yph ? vb : gb;
-    const int64_t spb = yph ? cstride : stride, soo = yph ? stride : cstride;
+    const int64_t soo = yph ? stride : cstride;
+    const unsigned char* PA = yph ? Qs : Ks;                        // LDS images of the tiles' row operands
+    const unsigned char* PB = yph ? Gs : Vs;
     const int col = 16 * wt + c;                                    // own query (X) / key (Y)
-    bf16x8 paf[NT][2], pbf[NT][2], oaf[2], oof[2];
+    bf16x8 oaf[2], oof[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         const int d = 32 * ks + 8 * g;
         oaf[ks] = ld_frag(oa, stride, col, L, d);
         oof[ks] = ld_frag(oo, soo, col, L, d);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            paf[t][ks] = ld_frag(pa, stride, 16 * t + c, L, d);
-            pbf[t][ks] = ld_frag(pb, spb, 16 * t + c, L, d);
-        }
     }
     bf16x8 ofr[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) ofr[ks] = ld_frag(ob, cstride, col, L, 32 * ks + 8 * g);     // (X waves use it below)
     {   // all global loads of the block are in flight before the first wait
-        const bf16* const bases[3] = {kb, qb, gb};
-        const int64_t strides[3] = {stride, stride, cstride};
-        unsigned char* const dsts[3] = {Ks, Qs, Gs};
-        stage_all<3, NP * 32, NTHR>(bases, strides, dsts, L, threadIdx.x);
+        const bf16* const bases[4] = {kb, qb, gb, vb};
+        const int64_t strides[4] = {stride, stride, cstride, stride};
+        unsigned char* const dsts[4] = {Ks, Qs, Gs, Vs};
+        stage_all<4, NP * 32, NTHR>(bases, strides, dsts, L, threadIdx.x);
     }
     if (!yph) {
         float part = 0.f;
@@ -271,8 +276,8 @@ __global__ void __launch_bounds__(128 * NT) attn_bwd_mfma_kernel(const bf16* qkv
         if (t < NT) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(paf[t][ks], oaf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pbf[t][ks], oof[ks], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(PA, 16 * t + c, 32 * ks + 8 * g), oaf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(PB, 16 * t + c, 32 * ks + 8 * g), oof[ks], dp, 0, 0, 0);
             }
             const int row0 = 16 * t + 4 * g;                        // rows row0..row0+3: keys (X) / queries (Y)
             f32x4 rmadd, rlse, rD;
@@ -343,9 +348,6 @@ __global__ void __launch_bounds__(128 * NT) attn_bwd_mfma_kernel(const bf16* qkv
 // queries; the backward runs its query-owning (dQ) and key-owning (dK, dV) halves one after the other on the same NT waves
 // (2*NT waves would exceed 1024 threads).
 // =================================================================================================================
-__device__ __forceinline__ bf16x8 lds_frag(const unsigned char* mat, int row, int d) {
-    return *reinterpret_cast<const bf16x8*>(mat + row * RS + d * 2);
-}
 
 template <int NT>
 __global__ void __launch_bounds__(64 * NT) attn_fwd_mfma_big_kernel(const bf16* qkv, const float* key_mask, bf16* ctx, float* lse, int B, int L,

@@ -1,0 +1,56 @@
+"""bench.py: the default workload IS the metric's configuration (BASELINE.json: N_clip x N_frame = 2 x 2, 224 px, L_txt = 32), and the
+N > 1 plan runs end to end.  The second test needs a GPU: it launches `--gpus 2` with both ranks on GPU 0 and gloo collectives
+(the bench's own dry-run switches) -- a control-flow check of the three-graph replay plan, the bucketed exchange, the bf16-direct
+optimizer path, the cross-rank parameter check and the sharded inference + row gather; never a measurement."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_default_workload_is_the_metric_configuration(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert (a.mode, a.gpus, a.videos, a.n_clips, a.frames, a.size, a.txt_len, a.repeat, a.pool) == ("train", 1, 16, 2, 2, 224, 32, 2, "lse")
+    assert a.steps > 0 and a.warmup >= 0
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--mode", "infer16"])
+    b = bench.parse()
+    assert (b.n_clips, b.repeat, b.videos) == (16, 64, 1)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--mode", "tgif"])
+    c = bench.parse()
+    assert (c.head, c.n_clips, c.repeat, c.txt_len) == ("multiple_choice", 2, 5, 25)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["train", "infer16"])
+def test_two_rank_dry_run_on_one_gpu(mode):
+    env = dict(os.environ, CB_BENCH_SHARE_GPU="1", CB_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--mode", mode]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]                     # rank 0 prints ONE JSON line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["config"]["parallelism"] == "dp2" and out["config"]["n_clips"] == (2 if mode == "train" else 16)
+    if mode == "train":
+        assert out["config"]["dp_self_check"].startswith("ok"), out["config"]["dp_self_check"]
+        assert "three hipGraphs" in out["config"]["replay_plan"]
+    else:
+        assert out["config"]["rows_gathered"] == 2 * 2 * 64       # 2 ranks x 2 timed steps x 64 captions

@@ -355,7 +355,9 @@ template <typename T, int NCH>
 void run_ln_bwd(hipStream_t st, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                 float* dgamma, float* dbeta, int64_t rows, int D, void* dx2, float p, uint64_t seed, const uint64_t* seed_ptr,
                 int seg_len, int seg_stride, int seg_off) {
-    static const unsigned cap = getenv("CB_LN_BWD_BLOCKS") ? (unsigned)atoi(getenv("CB_LN_BWD_BLOCKS")) : 128u;
+    // grid cap: every block ends with 2*D atomics, but a block per CU (one row per wave at the encoder's 2624 rows) measured faster
+    // next to other kernels than 128 blocks with two rows per wave (tools/small_kernel_probe.py: 13.3 vs 16.5 us)
+    static const unsigned cap = getenv("CB_LN_BWD_BLOCKS") ? (unsigned)atoi(getenv("CB_LN_BWD_BLOCKS")) : 256u;
     if constexpr (NCH <= 4) {
         if (rows >= 1024) {                  // many rows: 16 waves per block (see the kernel comment)
             unsigned blocks = nblk(rows, 16);

@@ -303,15 +303,18 @@ def main():
             loss_ = tasks.training_loss(model, stack, labels, counts, args.pool)
             (dgrid,) = torch.autograd.grad(loss_, [grid])
             cut["grid"], cut["dgrid"] = grid, dgrid
+            sync.cast_transformer()                # the bf16 wire image of the finished range is produced inside the graph
             return loss_
 
         def part_b():
             cut["grid"].backward(cut["dgrid"])
+            sync.cast_cnn()
 
         def part_c():
             model.rt.seed_dev.add_(1)
             opt.launch(grad16=sync.wire_gradients())
 
+        wire16 = sync.wire_gradients() is not None
         ga, loss = capture(part_a)
         gb, _ = capture(part_b)
         gc, _ = capture(part_c)
@@ -319,10 +322,10 @@ def main():
         def run_split():
             host_prepare()
             ga.replay()
-            sync.reduce_transformer()
+            sync.reduce_transformer(cast=not wire16)       # only the collectives are issued eagerly
             gb.replay()
-            sync.reduce_cnn()
-            sync.wait(cast_back=sync.wire_gradients() is None)
+            sync.reduce_cnn(cast=not wire16)
+            sync.wait(cast_back=not wire16)
             gc.replay()
         run, plan = run_split, "three hipGraphs, eager bucketed bf16 all-reduces (transformer buckets overlap the ResNet backward)"
     log(f"replay plan: {plan}")

@@ -47,7 +47,29 @@ class GradSync:
     def grad_scale(self) -> float:
         return 1.0 / self.world
 
-    def _reduce(self, a: int, b: int):
+    def _ensure_wire(self):
+        if self._wire is None and self.compress == "bf16":
+            self._wire = torch.empty(self.bank.n_train, dtype=torch.bfloat16, device=self.bank.grad.device)
+
+    def cast_range(self, a: int, b: int):
+        """fp32 gradients [a, b) -> the bf16 wire image (no communication: capturable into a hipGraph, so that a replay plan can
+        end each of its graphs with the cast of the range it just finished and issue only the collectives eagerly)."""
+        if self.world == 1 or b <= a or self.compress != "bf16":
+            return
+        from . import ops
+        self._ensure_wire()
+        if self.bank.grad.is_cuda:
+            ops.cast(self.bank.grad[a:b], self._wire[a:b])
+        else:
+            self._wire[a:b].copy_(self.bank.grad[a:b])
+
+    def cast_transformer(self):
+        self.cast_range(*self.t_range)
+
+    def cast_cnn(self):
+        self.cast_range(*self.c_range)
+
+    def _reduce(self, a: int, b: int, cast: bool = True):
         if self.world == 1 or b <= a:
             return
         for s0, e0 in self._inflight:
@@ -58,23 +80,20 @@ class GradSync:
         for s in range(a, b, step):
             e = min(b, s + step)
             if self.compress == "bf16":
-                from . import ops
-                if self._wire is None:
-                    self._wire = torch.empty(self.bank.n_train, dtype=torch.bfloat16, device=self.bank.grad.device)
-                if self.bank.grad.is_cuda:
-                    ops.cast(self.bank.grad[s:e], self._wire[s:e])
-                else:                                              # gloo / CPU tests
-                    self._wire[s:e].copy_(self.bank.grad[s:e])
+                if cast:
+                    self.cast_range(s, e)                          # (per bucket: the cast of bucket i+1 overlaps bucket i's transfer)
+                self._ensure_wire()
                 self._work.append(dist.all_reduce(self._wire[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                 self._pending.append((s, e))
             else:
                 self._work.append(dist.all_reduce(self.bank.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def reduce_transformer(self):
-        self._reduce(*self.t_range)
+    def reduce_transformer(self, cast: bool = True):
+        """cast=False: the wire image of the range was already produced by cast_transformer() (e.g. inside a captured graph)"""
+        self._reduce(*self.t_range, cast=cast)
 
-    def reduce_cnn(self):
-        self._reduce(*self.c_range)
+    def reduce_cnn(self, cast: bool = True):
+        self._reduce(*self.c_range, cast=cast)
 
     def wire_gradients(self) -> Optional[torch.Tensor]:
         """The flat bf16 gradient image (valid after wait(cast_back=False) once BOTH ranges were reduced): hand it to

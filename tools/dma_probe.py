@@ -8,6 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 SHAPES = [("fwd", 2624, 3072, 768), ("fwd", 2624, 2304, 768), ("fwd", 2624, 768, 3072), ("fwd", 5440, 3072, 768), ("fwd", 8192, 8192, 1024),
+          ("fwd", 8192, 8192, 4096), ("fwd", 10496, 3072, 768), ("fwd", 10496, 2304, 768), ("fwd", 10496, 768, 3072), ("fwd", 10496, 768, 768),
           ("dgrad", 2624, 3072, 768), ("dgrad", 2624, 768, 3072)]
 
 

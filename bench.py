@@ -179,7 +179,37 @@ def main():
         opt.launch()
         return loss
 
+    # diagnostic (CB_BENCH_CHAINS=2): the videos split into two independent forward+backward chains on two HIP streams, so that
+    # the launch ramps / tails of one chain's kernels overlap the other's main loops
+    chains = int(os.environ.get("CB_BENCH_CHAINS", "1"))
+    chain_streams = [torch.cuda.Stream() for _ in range(chains)] if chains > 1 else []
+
+    def device_step_chains():
+        opt.zero_grad(lazy=False)
+        model.rt.pending_encoder_nodes = 0
+        cur = torch.cuda.current_stream()
+        per, prep = bv // chains, rep * (bv // chains)
+        total = None
+        for h, st in enumerate(chain_streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                sub = dict(visual_inputs=frames[h * per:(h + 1) * per], text_input_ids=ids[h * prep:(h + 1) * prep],
+                           text_input_mask=mask[h * prep:(h + 1) * prep], labels=labels[h * (len(labels) // chains):(h + 1) * (len(labels) // chains)],
+                           n_examples_list=counts[h * per:(h + 1) * per])
+                stack = tasks.forward_clips_stack(model, sub, nclip, T, fold=fold, cfg=tcfg)
+                loss_h = tasks.training_loss(model, stack, sub["labels"], sub["n_examples_list"], args.pool) / chains
+                loss_h.backward()
+                total = loss_h.detach()
+        for st in chain_streams:
+            cur.wait_stream(st)
+        model.rt.seed_dev.add_(1)
+        opt.launch()
+        return total
+
     def train_step_eager():
+        if chains > 1:
+            host_prepare()
+            return device_step_chains()
         host_prepare()
         opt.zero_grad(lazy=True)
         model.rt.pending_encoder_nodes = 0
@@ -258,7 +288,9 @@ def main():
     #   CB_BENCH_PLAN=eager / --no-graph: no graphs (the hook issues the transformer buckets from inside the backward).
     def capture(fn):
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # N > 1: the process group's watchdog thread polls HIP events while this thread captures; "thread_local" keeps calls made
+        # by OTHER threads from invalidating the capture (the default "global" mode would)
+        with torch.cuda.graph(g, capture_error_mode="thread_local" if world > 1 else "global"):
             out = fn()
         return g, out
 
@@ -277,7 +309,7 @@ def main():
         g1, loss = capture(forward_only_step)
         run, plan = g1.replay, "one hipGraph"
     elif use_graph and world == 1:
-        g1, loss = capture(device_step_single)
+        g1, loss = capture(device_step_chains if chains > 1 else device_step_single)
 
         def run_single():
             host_prepare()

@@ -43,6 +43,8 @@ _SIGNATURES = {
     "cb_relu_scale_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],
     "cb_layernorm_fwd": [i32, vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, i32, i32, vp],
     "cb_layernorm_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, f32, u64, vp, i32, i32, i32, vp],
+    "cb_layernorm_bwd_part": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, f32, u64, vp, i32, i32, i32, vp],
+    "cb_ln_partials_reduce": [vp, vp, vp, vp, i32, i32, i32, vp],
     "cb_text_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "cb_visual_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
                             i32, i32, i32, f32, vp],

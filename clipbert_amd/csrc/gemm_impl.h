@@ -72,6 +72,7 @@ struct Opnd {
 template <typename T, int ROWS, bool FAST> struct RowkLoader {
     using X = Tr<T>;
     static constexpr bool TR = false;
+    static constexpr bool KROW = false;        // operand stored [k][row] (dgrad's B, wgrad's A and B)
     static constexpr int NS = ROWS * X::SEGS / NTHREADS;
     static constexpr int ESZ = (int)sizeof(T);
     static_assert(ROWS * X::SEGS % NTHREADS == 0, "tile/threads mismatch");
@@ -149,6 +150,7 @@ template <typename T, int ROWS, bool FAST> struct RowkLoader {
 template <typename T, int ROWS, bool FAST> struct KrowLoader {
     using X = Tr<T>;
     static constexpr bool TR = false;
+    static constexpr bool KROW = true;        // operand stored [k][row] (dgrad's B, wgrad's A and B)
     static constexpr int RBLK = ROWS / X::RB;              // row blocks per tile
     static constexpr int CNT = RBLK * (X::BK / 4);         // thread-blocks per tile
     static constexpr int NI = (CNT + NTHREADS - 1) / NTHREADS;
@@ -268,6 +270,7 @@ enum { KM_PLAIN = 0, KM_TAPS = 1, KM_GATHER = 2 };
 template <typename T, int ROWS, bool GATHER> struct RowkFast {
     using X = Tr<T>;
     static constexpr bool TR = false;
+    static constexpr bool KROW = false;        // operand stored [k][row] (dgrad's B, wgrad's A and B)
     static constexpr int NS = ROWS * X::SEGS / NTHREADS;
     static constexpr uint32_t ESZ = (uint32_t)sizeof(T);
     struct Stage { u32x4 r[NS]; };
@@ -345,6 +348,7 @@ template <typename T, int ROWS, bool GATHER> struct RowkFast {
 template <typename T, int ROWS, int KMODE, int KB_ = 4, int SHIFT = 0> struct KrowFast {
     using X = Tr<T>;
     static constexpr bool TR = false;
+    static constexpr bool KROW = true;        // operand stored [k][row] (dgrad's B, wgrad's A and B)
     static constexpr int KB = sizeof(T) == 2 ? KB_ : 4;
     static constexpr int NKB = X::BK / KB;
     static constexpr int RBLK = ROWS / X::RB;
@@ -515,6 +519,7 @@ template <int ROWS> __device__ __forceinline__ bf16x8 tr_frag(const unsigned cha
 template <int ROWS, int KMODE> struct KrowTr {
     using X = Tr<bf16>;
     static constexpr bool TR = true;
+    static constexpr bool KROW = true;
     static constexpr int CH = ROWS / 8;                           // 16-byte chunks per k-line
     static constexpr int NS = CH * X::BK / NTHREADS;
     static_assert(CH * X::BK % NTHREADS == 0, "tile/threads mismatch");
@@ -742,9 +747,22 @@ __device__ __forceinline__ void store8(bf16* q, const float (&v)[8]) {
 
 // Epilogue of 8 consecutive columns n..n+7 of row m (row-contiguous: every global access is a full 16-byte lane
 // access and a wave touches whole cache lines).  sc/sh are the per-column scale/shift the thread loaded once.
-template <typename T>
+// EPF: the residual / (mask | GELU pre-activation) chunk was fetched before the K loop (epi_prefetch) -- rpre / apre hold it.
+template <typename T, bool EPF = false>
 __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const float (&sc)[8], const float (&sh)[8],
-                                          int m, int64_t orow, int n) {
+                                          int m, int64_t orow, int n, bf16x8 rpre = bf16x8{}, bf16x8 apre = bf16x8{}) {
+    auto load_res = [&](float (&t)[8]) {
+        if constexpr (EPF) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t[r] = (float)rpre[r];
+        } else load8(reinterpret_cast<const T*>(p.residual) + orow * p.ldr + n, t);
+    };
+    auto load_aux = [&](const void* base, int64_t ld, float (&t)[8]) {
+        if constexpr (EPF) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t[r] = (float)apre[r];
+        } else load8(reinterpret_cast<const T*>(base) + orow * ld + n, t);
+    };
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
     if (p.relu_bwd) {          // t = (acc [+ C] [+ residual]) where mask > 0;  C2 = t * post_scale2,  C = t * post_scale
@@ -756,11 +774,11 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
             for (int r = 0; r < 8; ++r) v[r] += t[r];
         }
         if (p.residual) {
-            load8(reinterpret_cast<const T*>(p.residual) + orow * p.ldr + n, t);
+            load_res(t);
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] += t[r];
         }
-        load8(reinterpret_cast<const T*>(p.mask) + orow * p.ldm + n, t);
+        load_aux(p.mask, p.ldm, t);
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = t[r] > 0.f ? v[r] : 0.f;
         if (p.C2) {
@@ -804,7 +822,7 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
     }
     if (p.residual) {
         float t[8];
-        load8(reinterpret_cast<const T*>(p.residual) + orow * p.ldr + n, t);
+        load_res(t);
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += t[r];
     }
@@ -814,13 +832,12 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
     }
     if (p.mask) {
         float t[8];
-        load8(reinterpret_cast<const T*>(p.mask) + orow * p.ldm + n, t);
+        load_aux(p.mask, p.ldm, t);
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = t[r] > 0.f ? v[r] : 0.f;
-    }
-    if (p.dact_pre) {
+    } else if (p.dact_pre) {
         float t[8];
-        load8(reinterpret_cast<const T*>(p.dact_pre) + orow * p.ldd + n, t);
+        load_aux(p.dact_pre, p.ldd, t);
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_grad(t[r]);
     }
@@ -846,10 +863,45 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
 }
 
 // ---------------------------------------------------------------------------------------------
+// Epilogue-operand prefetch (row-contiguous bf16 epilogue only).  The epilogue's global READS -- the residual and the ReLU mask
+// / GELU pre-activation -- do not depend on the product, so the thread's chunks are requested before the K loop and land while it
+// runs: for the short-K 1x1 convolutions of the ResNet (1-4 K tiles, HBM-bound) the block otherwise waits a full HBM round trip
+// between its last MFMA and its stores.  Same (row, chunk) map as tile_epilogue's c_vec8 branch.  NCH chunks x 2 operands x 4 VGPR.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN>
+struct EpiPre {
+    static constexpr int WM = BM / 2, CPR = BN / 8, ITER = WM * CPR / NTHREADS, NCH = 2 * ITER;
+    bf16x8 r[NCH], a[NCH];
+};
+
+template <typename T, int BM, int BN>
+__device__ __forceinline__ void epi_prefetch(const GP& p, EpiPre<BM, BN>& pre, int m0, int n0, int tid) {
+    using E = EpiPre<BM, BN>;
+    const int cc = tid % E::CPR, n = n0 + cc * 8;
+    const void* aux = p.mask ? p.mask : p.dact_pre;
+    const int64_t lda = p.mask ? p.ldm : p.ldd;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int it = 0; it < E::ITER; ++it) {
+            const int m = m0 + h * E::WM + (tid + it * NTHREADS) / E::CPR;
+            bf16x8 z = {};
+            pre.r[h * E::ITER + it] = z;
+            pre.a[h * E::ITER + it] = z;
+            if (m < p.M && n < p.N) {
+                const int64_t orow = p.c_rowmap ? (int64_t)p.c_rowmap[m] : (int64_t)m;
+                if (p.residual) pre.r[h * E::ITER + it] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(p.residual) + orow * p.ldr + n);
+                if (aux) pre.a[h * E::ITER + it] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(aux) + orow * lda + n);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Tile epilogue shared by both kernel structures.  acc[i][j] = 4 consecutive n of row m (swapped MFMA operands).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int SMEM_BYTES>
-__device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 32], unsigned char* smem, int m0, int n0, int tid) {
+template <typename T, int BM, int BN, int SMEM_BYTES, bool EPF = false>
+__device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 32], unsigned char* smem, int m0, int n0, int tid,
+                                              const EpiPre<BM, BN>& pre = EpiPre<BM, BN>{}, bool use_pre = false) {
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -889,7 +941,10 @@ __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 
                     const int64_t orow = p.c_rowmap ? (int64_t)p.c_rowmap[m] : (int64_t)m;
                     float v[8];
                     load8(reinterpret_cast<const float*>(smem + rl * SROW + cc * 32), v);
-                    epilogue8<T>(p, v, sc, sh, m, orow, n);
+                    if constexpr (EPF) {
+                        if (use_pre) epilogue8<T, true>(p, v, sc, sh, m, orow, n, pre.r[h * ITER + it], pre.a[h * ITER + it]);
+                        else epilogue8<T>(p, v, sc, sh, m, orow, n);
+                    } else epilogue8<T>(p, v, sc, sh, m, orow, n);
                 }
             }
         }
@@ -1026,6 +1081,16 @@ __global__ void __launch_bounds__(256, OCC) gemm_kernel(GP p) {
 #pragma unroll
     for (int s = 0; s < PF; ++s)
         if (s < nt) load_tiles_checked(sa[s], sb[s]);
+    // epilogue operands (residual, mask / GELU pre-activation) requested now, consumed after the K loop
+    // Only the data-gradient forms carry it (the registers would cost the weight-gradient kernels occupancy), and only for the fused
+    // ReLU x FrozenBN backward (two operands: block output y and the shortcut gradient): measured on MI355X -10 % there
+    // (50176x512x128: 48.3 -> 42.7 us), nothing or slightly negative for single-operand epilogues (forward residual, GELU').
+    constexpr bool EPF = sizeof(T) == 2 && BM * BN <= 128 * 64 && !LA::KROW && LB::KROW;
+    EpiPre<BM, BN> epre;
+    const bool epf_on = EPF && p.c_vec8 && p.relu_bwd;      // block-uniform
+    if constexpr (EPF) {
+        if (epf_on) epi_prefetch<T, BM, BN>(p, epre, m0, n0, tid);
+    }
     store_tiles(sa[0], sb[0], 0);
     if (PF < nt) load_tiles_checked(sa[0], sb[0]);
     __syncthreads();
@@ -1127,7 +1192,8 @@ __global__ void __launch_bounds__(256, OCC) gemm_kernel(GP p) {
             }
         }
     }
-    tile_epilogue<T, BM, BN, SMEM_BYTES>(p, acc, smem, m0, n0, tid);
+    if constexpr (EPF) tile_epilogue<T, BM, BN, SMEM_BYTES, true>(p, acc, smem, m0, n0, tid, epre, epf_on);
+    else tile_epilogue<T, BM, BN, SMEM_BYTES>(p, acc, smem, m0, n0, tid);
 }
 
 // =============================================================================================

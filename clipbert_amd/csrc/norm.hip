@@ -82,7 +82,11 @@ template <typename T, int MAXCH, int NW>
 __global__ void __launch_bounds__(NW * 64) layernorm_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
                                                                const float* rstd, T* dx, float* dgamma, float* dbeta,
                                                                int64_t rows, int D, T* dx2, float drop_p, uint64_t seed,
-                                                               const uint64_t* seed_ptr, int seg_len, int seg_stride, int seg_off) {
+                                                               const uint64_t* seed_ptr, int seg_len, int seg_stride, int seg_off,
+                                                               float* part) {
+    // part != nullptr: the block's sums go to part[blockIdx.x][gamma|beta][D] with plain stores (no atomics: the 2*D same-address
+    // memory-side atomics of ~160 blocks are the kernel's tail) and cb_ln_partials_reduce adds them up later -- for all the
+    // encoder's LayerNorms in one launch, and in a fixed order (deterministic parameter gradients).
     __shared__ float red[2][NW][256];          // [gamma|beta][wave][one 256-element chunk]
     if (dx2 && seed_ptr) seed += *seed_ptr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -166,7 +170,8 @@ __global__ void __launch_bounds__(NW * 64) layernorm_bwd_kernel(const T* dy, con
                     float sacc = 0.f;
 #pragma unroll
                     for (int w = 0; w < NW; ++w) sacc += red[kind][w][e];
-                    atomicAdd((kind ? dbeta : dgamma) + col, sacc);
+                    if (part) part[((int64_t)blockIdx.x * 2 + kind) * D + col] = sacc;
+                    else atomicAdd((kind ? dbeta : dgamma) + col, sacc);
                 }
             }
         } else {
@@ -175,11 +180,34 @@ __global__ void __launch_bounds__(NW * 64) layernorm_bwd_kernel(const T* dy, con
                 float sg = 0.f, sb = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) { sg += red[0][w][e]; sb += red[1][w][e]; }
-                atomicAdd(dgamma + col, sg);
-                atomicAdd(dbeta + col, sb);
+                if (part) {
+                    part[((int64_t)blockIdx.x * 2 + 0) * D + col] = sg;
+                    part[((int64_t)blockIdx.x * 2 + 1) * D + col] = sb;
+                } else {
+                    atomicAdd(dgamma + col, sg);
+                    atomicAdd(dbeta + col, sb);
+                }
             }
         }
     }
+}
+
+// grad[off[kind][job] + col] += sum_b part[job][b][kind][col]: block = (256-column chunk, kind, job); thread = one column; the
+// nblocks partial rows are read as coalesced 1 KiB rows, summed in block order (a fixed order: deterministic)
+__global__ void __launch_bounds__(256) ln_partials_reduce_kernel(const float* part, float* grad, const int64_t* off_gamma,
+                                                                 const int64_t* off_beta, int nblocks, int D) {
+    const int col = blockIdx.x * 256 + threadIdx.x, kind = blockIdx.y, job = blockIdx.z;
+    if (col >= D) return;
+    const float* q = part + ((int64_t)job * nblocks * 2 + kind) * D + col;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 4 <= nblocks; b += 4) {
+        s0 += q[(int64_t)(b + 0) * 2 * D]; s1 += q[(int64_t)(b + 1) * 2 * D];
+        s2 += q[(int64_t)(b + 2) * 2 * D]; s3 += q[(int64_t)(b + 3) * 2 * D];
+    }
+    for (; b < nblocks; ++b) s0 += q[(int64_t)b * 2 * D];
+    float* dst = grad + (kind ? off_beta : off_gamma)[job] + col;
+    *dst += (s0 + s1) + (s2 + s3);
 }
 
 // ---- embeddings -----------------------------------------------------------------------------------
@@ -354,7 +382,7 @@ void run_ln_fwd(hipStream_t st, const void* x, const float* gamma, const float* 
 template <typename T, int NCH>
 void run_ln_bwd(hipStream_t st, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                 float* dgamma, float* dbeta, int64_t rows, int D, void* dx2, float p, uint64_t seed, const uint64_t* seed_ptr,
-                int seg_len, int seg_stride, int seg_off) {
+                int seg_len, int seg_stride, int seg_off, float* part, int part_blocks) {
     // grid cap: every block ends with 2*D atomics, but a block per CU (one row per wave at the encoder's 2624 rows) measured faster
     // next to other kernels than 128 blocks with two rows per wave (tools/small_kernel_probe.py: 13.3 vs 16.5 us)
     static const unsigned cap = getenv("CB_LN_BWD_BLOCKS") ? (unsigned)atoi(getenv("CB_LN_BWD_BLOCKS")) : 256u;
@@ -362,15 +390,17 @@ void run_ln_bwd(hipStream_t st, const void* dy, const void* x, const float* gamm
         if (rows >= 1024) {                  // many rows: 16 waves per block (see the kernel comment)
             unsigned blocks = nblk(rows, 16);
             if (blocks > cap) blocks = cap;
+            if (part) blocks = (unsigned)part_blocks;
             hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH, 16>), dim3(blocks), dim3(1024), 0, st, (const T*)dy, (const T*)x, gamma, mean,
-                               rstd, (T*)dx, dgamma, dbeta, rows, D, (T*)dx2, p, seed, seed_ptr, seg_len, seg_stride, seg_off);
+                               rstd, (T*)dx, dgamma, dbeta, rows, D, (T*)dx2, p, seed, seed_ptr, seg_len, seg_stride, seg_off, part);
             return;
         }
     }
     unsigned blocks = nblk(rows, 4);
     if (blocks > cap) blocks = cap;          // every block ends with 2*D atomics: keep them few
+    if (part) blocks = (unsigned)part_blocks;
     hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH, 4>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd,
-                       (T*)dx, dgamma, dbeta, rows, D, (T*)dx2, p, seed, seed_ptr, seg_len, seg_stride, seg_off);
+                       (T*)dx, dgamma, dbeta, rows, D, (T*)dx2, p, seed, seed_ptr, seg_len, seg_stride, seg_off, part);
 }
 template <typename T, int NCH>
 void run_text_fwd(hipStream_t st, const int64_t* ids, const void* word, const void* pos, const void* type0, const float* gamma,
@@ -405,8 +435,27 @@ extern "C" int cb_layernorm_bwd(int32_t dtype, const void* dy, const void* x, co
     CB_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && CB_D_OK(D), "cb_layernorm_bwd: bad arguments");
     if (rows == 0) return 0;
     CB_DISPATCH(run_ln_bwd, cb_stream(stream), dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, dx2, dropout_p, dropout_seed,
-                dropout_seed_ptr, seg_len, seg_stride, seg_off);
+                dropout_seed_ptr, seg_len, seg_stride, seg_off, nullptr, 0);
     return cb_launch_status("cb_layernorm_bwd");
+}
+
+extern "C" int cb_layernorm_bwd_part(int32_t dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                                     const float* rstd, void* dx, float* part, int32_t nblocks, int64_t rows, int32_t D, void* dx2,
+                                     float dropout_p, uint64_t dropout_seed, const uint64_t* dropout_seed_ptr, int32_t seg_len,
+                                     int32_t seg_stride, int32_t seg_off, void* stream) {
+    CB_REQUIRE(dy && x && gamma && mean && rstd && dx && part && CB_D_OK(D), "cb_layernorm_bwd_part: bad arguments");
+    CB_REQUIRE(nblocks >= 1 && nblocks <= 1024 && rows > 0, "cb_layernorm_bwd_part: nblocks %d / rows out of range", nblocks);
+    CB_DISPATCH(run_ln_bwd, cb_stream(stream), dy, x, gamma, mean, rstd, dx, nullptr, nullptr, rows, D, dx2, dropout_p, dropout_seed,
+                dropout_seed_ptr, seg_len, seg_stride, seg_off, part, nblocks);
+    return cb_launch_status("cb_layernorm_bwd_part");
+}
+
+extern "C" int cb_ln_partials_reduce(const float* part, float* grad, const int64_t* off_gamma, const int64_t* off_beta,
+                                     int32_t njobs, int32_t nblocks, int32_t D, void* stream) {
+    CB_REQUIRE(part && grad && off_gamma && off_beta && njobs >= 1 && nblocks >= 1 && D >= 1, "cb_ln_partials_reduce: bad arguments");
+    hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((D + 255) / 256, 2, njobs), dim3(256), 0, cb_stream(stream), part, grad,
+                       off_gamma, off_beta, nblocks, D);
+    return cb_launch_status("cb_ln_partials_reduce");
 }
 
 extern "C" int cb_text_embed_fwd(int32_t dtype, const int64_t* ids, const void* word, const void* pos, const void* type0,

@@ -741,6 +741,27 @@ def _encoder_wgrads(model, pk, gs, M):
                 _linear_wgrad(rt, g[li], x[li], None, None, M, n, k, grad_w=gws[li], grad_b=gbs[li])
 
 
+def _ln_offsets(model, dev):
+    """(2, 2*n_layers) int64 device tensor: element offsets of the encoder LayerNorms' (weight | bias) gradients in bank.grad, in
+    the slot order encoder_backward uses (2*l: attention.output.LayerNorm, 2*l+1: output.LayerNorm); None if any is frozen."""
+    rt = model.rt
+    cached = getattr(rt, "_ln_off", None)
+    if cached is not None and cached[0] is rt.bank:
+        return cached[1]
+    bank, offs = rt.bank, ([], [])
+    for layer in model.encoder.layer:
+        for ln in (layer.attention.output.LayerNorm, layer.output.LayerNorm):
+            gw, gb = bank.grad_image(ln.weight), bank.grad_image(ln.bias)
+            if gw is None or gb is None:
+                rt._ln_off = (bank, None)
+                return None
+            offs[0].append((gw.data_ptr() - bank.grad.data_ptr()) // 4)
+            offs[1].append((gb.data_ptr() - bank.grad.data_ptr()) // 4)
+    t = torch.tensor(offs, dtype=torch.int64).to(dev)
+    rt._ln_off = (bank, t)
+    return t
+
+
 def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
     rt, cfg = model.rt, model.config
     bank, dt = rt.bank, rt.dtype
@@ -770,6 +791,18 @@ def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
     # layer-stacked buffers and ALL layers' weight (+ bias) gradients of one kind follow in one strided-batched GEMM
     # each (4 launches instead of 4 per layer: 12x the blocks per launch, 128x128 tiles, no launch tails).
     nl, stk = len(pk.layers), pk.stk
+    # LayerNorm parameter gradients: every LN backward stores per-block partial sums (no atomics); ONE launch after the layer
+    # loop adds all 2*nl of them onto the gradient buffer in a fixed order (deterministic).  Frozen LN parameters -> atomics path.
+    ln_off = _ln_offsets(model, dev)
+    nb = ops.ln_part_blocks(M)
+    ln_part = torch.empty(2 * nl, nb, 2, d, dtype=torch.float32, device=dev) if ln_off is not None else None
+
+    def ln_bwd(slot, dy, xpre, ln, mean, rstd, seed, keep):
+        if ln_part is not None:
+            return ops.layernorm_bwd_part(dy, xpre, ln.weight, mean, rstd, ln_part[slot], pk.p_h, seed, rt.seed_dev, **keep)
+        return ops.layernorm_bwd(dy, xpre, ln.weight, mean, rstd, bank.grad_image(ln.weight), bank.grad_image(ln.bias), pk.p_h, seed,
+                                 rt.seed_dev, **keep)
+
     gs = SimpleNamespace(out=torch.empty(nl, M, d, dtype=dt, device=dev), hp=torch.empty(nl, M, ff, dtype=dt, device=dev),
                          att=torch.empty(nl, M, d, dtype=dt, device=dev), qkv=torch.empty(nl, M, 3 * d, dtype=dt, device=dev))
     for li in range(nl - 1, -1, -1):
@@ -777,16 +810,14 @@ def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
         att, so, it, ou = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
         x, qkv, ctx, lse, a_pre, mean1, rstd1, a, hpre, hact, o_pre, mean2, rstd2 = pk.layers[li]
         keep = dict(dx2=gs.out[li]) if pk.p_h > 0 else dict(dx=gs.out[li])
-        d_o_pre, d_o_drop = ops.layernorm_bwd(dx, o_pre, ou.LayerNorm.weight, mean2, rstd2, bank.grad_image(ou.LayerNorm.weight),
-                                              bank.grad_image(ou.LayerNorm.bias), pk.p_h, _seed(_SITE_OUT, li, pk.fwd_i), rt.seed_dev, **keep)
+        d_o_pre, d_o_drop = ln_bwd(2 * li + 1, dx, o_pre, ou.LayerNorm, mean2, rstd2, _seed(_SITE_OUT, li, pk.fwd_i), keep)
         g = d_o_drop if d_o_drop is not None else d_o_pre
         dhp = gs.hp[li]
         ops.gemm(g, bank.compute(ou.dense.weight), M, ff, d, out=dhp, b_mode=KROW, gelu_grad_pre=hpre)   # dgrad + GELU'
         da = torch.empty(M, d, dtype=dt, device=dev)
         ops.gemm(dhp, bank.compute(it.dense.weight), M, d, ff, out=da, b_mode=KROW, residual=d_o_pre)
         keep = dict(dx2=gs.att[li]) if pk.p_h > 0 else dict(dx=gs.att[li])
-        d_a_pre, d_a_drop = ops.layernorm_bwd(da, a_pre, so.LayerNorm.weight, mean1, rstd1, bank.grad_image(so.LayerNorm.weight),
-                                              bank.grad_image(so.LayerNorm.bias), pk.p_h, _seed(_SITE_SELF_OUT, li, pk.fwd_i), rt.seed_dev, **keep)
+        d_a_pre, d_a_drop = ln_bwd(2 * li, da, a_pre, so.LayerNorm, mean1, rstd1, _seed(_SITE_SELF_OUT, li, pk.fwd_i), keep)
         g = d_a_drop if d_a_drop is not None else d_a_pre
         dctx = torch.empty(M, d, dtype=dt, device=dev)
         ops.gemm(g, bank.compute(so.dense.weight), M, d, d, out=dctx, b_mode=KROW)
@@ -795,6 +826,8 @@ def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
         wqkv = bank.compute_span(att.query.weight, att.value.weight, (3 * d, d))
         dx = torch.empty(M, d, dtype=dt, device=dev)
         ops.gemm(dqkv, wqkv, M, d, 3 * d, out=dx, b_mode=KROW, residual=d_a_pre)
+    if ln_part is not None:
+        ops.ln_partials_reduce(ln_part, bank.grad, ln_off[0], ln_off[1])
     _encoder_wgrads(model, pk, gs, M)
     # ---- embeddings -----------------------------------------------------------------------------------
     rt.join()

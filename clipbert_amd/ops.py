@@ -199,6 +199,35 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dropout_p=0.0, dropou
     return dx, dx2
 
 
+def ln_part_blocks(rows: int) -> int:
+    """blocks cb_layernorm_bwd_part is launched with for `rows` rows (one row per wave, 16 / 4 waves per block, <= 256 blocks)"""
+    per = 16 if rows >= 1024 else 4
+    return max(1, min(256, (rows + per - 1) // per))
+
+
+def layernorm_bwd_part(dy, x, gamma, mean, rstd, part, dropout_p=0.0, dropout_seed=0, seed_ptr=None, dx=None, dx2=None):
+    """LayerNorm backward whose parameter-gradient partial sums go to part (nblocks, 2, D) fp32 (plain stores; ln_partials_reduce
+    adds them to the gradients later).  returns (dx, dx_dropped|None)"""
+    d = x.shape[-1]
+    rows = x.numel() // d
+    nblocks = part.shape[0]
+    assert part.dtype == torch.float32 and part.is_contiguous() and part.shape[1:] == (2, d)
+    dx = torch.empty_like(x) if dx is None else dx
+    dx2 = (dx2 if dx2 is not None else torch.empty_like(x)) if dropout_p > 0 else None
+    _chk(_lib.get().cb_layernorm_bwd_part(dtype_code(x.dtype), _ptr(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx),
+                                          _ptr(part), nblocks, rows, d, _ptr(dx2), dropout_p, dropout_seed, _ptr(seed_ptr),
+                                          0, 0, 0, _stream(x)), "cb_layernorm_bwd_part")
+    return dx, dx2
+
+
+def ln_partials_reduce(part, grad, off_gamma, off_beta):
+    """grad[off_gamma[j] + c] += sum_b part[j, b, 0, c]; grad[off_beta[j] + c] += sum_b part[j, b, 1, c]  (fixed order)"""
+    njobs, nblocks, two, d = part.shape
+    assert two == 2 and part.is_contiguous() and off_gamma.dtype == torch.int64 and off_gamma.numel() == njobs == off_beta.numel()
+    _chk(_lib.get().cb_ln_partials_reduce(_ptr(part), _ptr(grad), _ptr(off_gamma), _ptr(off_beta), njobs, nblocks, d, _stream(part)),
+         "cb_ln_partials_reduce")
+
+
 def text_embed_fwd(ids, word, pos, type0, gamma, beta, out, pre, mean, rstd, lt, l_total, eps):
     b = ids.shape[0]
     d = word.shape[-1]

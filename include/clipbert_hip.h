@@ -157,6 +157,17 @@ int cb_layernorm_bwd(int32_t dtype, const void* dy, const void* x, const float* 
                      const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int32_t D,
                      void* dx2, float dropout_p, uint64_t dropout_seed, const uint64_t* dropout_seed_ptr,
                      int32_t seg_len, int32_t seg_stride, int32_t seg_off, void* stream);
+/* The same with DETERMINISTIC parameter gradients and no atomics: `nblocks` (1..1024) blocks are launched and block b stores
+ * its partial sums to part[b][0|1][D] (dgamma | dbeta, fp32).  cb_ln_partials_reduce then adds, for njobs such calls at
+ * once (part = [njobs][nblocks][2][D]), the partial rows in block order onto grad[off_gamma[j] ..], grad[off_beta[j] ..]
+ * (element offsets into a flat fp32 gradient buffer; device arrays).  The encoder backward issues its 24 LayerNorm backwards
+ * this way and one reduce (src/modeling/transformers.py:148,342-343 run 24 autograd nodes with their own reductions). */
+int cb_layernorm_bwd_part(int32_t dtype, const void* dy, const void* x, const float* gamma, const float* mean,
+                          const float* rstd, void* dx, float* part, int32_t nblocks, int64_t rows, int32_t D,
+                          void* dx2, float dropout_p, uint64_t dropout_seed, const uint64_t* dropout_seed_ptr,
+                          int32_t seg_len, int32_t seg_stride, int32_t seg_off, void* stream);
+int cb_ln_partials_reduce(const float* part, float* grad, const int64_t* off_gamma, const int64_t* off_beta,
+                          int32_t njobs, int32_t nblocks, int32_t D, void* stream);
 
 /* Text embedding (BertEmbeddings.forward, src/modeling/transformers.py:172-199): out row
  * (b*L_total + t) = LN(word[ids[b,t]] + pos[t] + type[0]); pre-LN sum saved in `pre` when non-null. */

@@ -313,3 +313,38 @@ def test_layernorm_bwd_row_segments(hw):
     y.backward(dy * sel.view(B * L, 1))
     torch.testing.assert_close(dx, xr.grad, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(dg, gr.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("rows", [37, 1100])
+def test_layernorm_bwd_partials_equal_atomics_path(hw, dt, rows):
+    """cb_layernorm_bwd_part + cb_ln_partials_reduce (deterministic, no atomics) vs cb_layernorm_bwd: same dx bit for bit, parameter
+    gradients equal up to summation order; two jobs reduced in one launch onto offsets of a flat buffer; repeatable bit for bit."""
+    D, p, seed = 192, 0.1, 77
+    g = 1 + rnd(D, seed=3, scale=0.1)
+    flat = zeros(5 * D + 8)
+    offs_g = torch.tensor([8, 8 + 2 * D], dtype=torch.int64, device=DEV[0])
+    offs_b = torch.tensor([8 + D, 8 + 3 * D], dtype=torch.int64, device=DEV[0])
+    nb = ops.ln_part_blocks(rows)
+    part = torch.full((2, nb, 2, D), float("nan"), dtype=torch.float32, device=DEV[0])       # every slot must be written
+    refs = []
+    for job in range(2):
+        x, dy = rnd(rows, D, seed=10 + job).to(dt), rnd(rows, D, seed=20 + job).to(dt)
+        mean, var = x.float().mean(-1), x.float().var(-1, unbiased=False)
+        rstd = (var + 1e-12).rsqrt()
+        dg, db = zeros(D), zeros(D)
+        dx_a, dx2_a = ops.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dropout_p=p, dropout_seed=seed)
+        dx_p, dx2_p = ops.layernorm_bwd_part(dy, x, g, mean, rstd, part[job], dropout_p=p, dropout_seed=seed)
+        assert torch.equal(dx_a, dx_p) and torch.equal(dx2_a, dx2_p)
+        refs.append((dg, db))
+    flat[8 + 4 * D:] = 1.0                                     # neighbours stay untouched
+    ops.ln_partials_reduce(part, flat, offs_g, offs_b)
+    ops.ln_partials_reduce(part, flat, offs_g, offs_b)         # accumulates
+    for job, (dg, db) in enumerate(refs):
+        torch.testing.assert_close(flat[8 + 2 * job * D: 8 + (2 * job + 1) * D], 2 * dg, **tol(dt, 1e-4, 5e-2))
+        torch.testing.assert_close(flat[8 + (2 * job + 1) * D: 8 + (2 * job + 2) * D], 2 * db, **tol(dt, 1e-4, 5e-2))
+    assert float(flat[:8].abs().max()) == 0 and bool((flat[8 + 4 * D:] == 1).all())
+    again = zeros(5 * D + 8)
+    ops.ln_partials_reduce(part, again, offs_g, offs_b)
+    ops.ln_partials_reduce(part, again, offs_g, offs_b)
+    assert torch.equal(again[:8 + 4 * D], flat[:8 + 4 * D])

@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
         ("sH", i64), ("sW", i64), ("flip_taps", i32), ("reserved0", i32),
         ("C", vp), ("ldc", i64), ("c_rowmap", vp), ("c_f32", i32), ("accumulate", i32),
         ("split_k", i32), ("act", i32), ("scale", vp), ("shift", vp), ("residual", vp), ("ldr", i64),
-        ("relu_after", i32), ("reserved1", i32), ("mask", vp), ("ldm", i64), ("C2", vp), ("ldc2", i64),
+        ("relu_after", i32), ("zero_fill_pitch", i32), ("mask", vp), ("ldm", i64), ("C2", vp), ("ldc2", i64),
         ("alpha", f32), ("dropout_p", f32), ("dropout_seed", u64), ("dropout_seed_ptr", vp), ("tile", i32),
         ("xcd_order", i32), ("a_bytes", i64), ("b_bytes", i64), ("gelu_grad_pre", vp), ("ld_gelu", i64), ("a_rowsum", vp),
         ("batch", i32), ("relu_bwd", i32), ("batch_stride_a", i64), ("batch_stride_b", i64), ("batch_stride_c", i64),
@@ -45,6 +45,11 @@ _SIGNATURES = {
     "cb_layernorm_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, f32, u64, vp, i32, i32, i32, vp],
     "cb_layernorm_bwd_part": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, vp, f32, u64, vp, i32, i32, i32, vp],
     "cb_ln_partials_reduce": [vp, vp, vp, vp, i32, i32, i32, vp],
+    "cb_comm_unique_id": [vp],
+    "cb_comm_init": [i32, i32, vp],
+    "cb_comm_info": [vp, vp],
+    "cb_allreduce_bucket": [vp, i64, i32, vp],
+    "cb_comm_destroy": [],
     "cb_text_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "cb_visual_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
                             i32, i32, i32, f32, vp],

@@ -91,7 +91,7 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
                    "cb_gemm: batch strides must keep 16-byte alignment");
     }
     CB_REQUIRE(!d->a_rowsum || (d->a_mode == CB_KROW && d->b_mode == CB_KROW), "cb_gemm: a_rowsum needs the weight-gradient form (A and B both CB_KROW)");
-    p.scale = d->scale; p.shift = d->shift; p.a_tab = d->a_tab; p.b_tab = d->b_tab; p.c_rowmap = d->c_rowmap;
+    p.scale = d->scale; p.shift = d->shift; p.a_tab = d->a_tab; p.b_tab = d->b_tab; p.c_rowmap = d->c_rowmap; p.zfill = d->zero_fill_pitch;
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldc2 = d->ldc2; p.ldr = d->ldr; p.ldm = d->ldm;
     p.sH = d->sH; p.sW = d->sW;
     p.M = d->M; p.N = d->N; p.K = d->K;
@@ -183,7 +183,10 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     if (d->mask) cv8 = cv8 && (d->ldm % 8 == 0) && aligned16(d->mask);
     if (d->gelu_grad_pre) cv8 = cv8 && (d->ld_gelu % 8 == 0) && aligned16(d->gelu_grad_pre);
     static const bool no_wide = getenv("CB_GEMM_NO_WIDE_EPILOGUE") != nullptr;
-    p.c_vec8 = cv8 && !no_wide;
+    p.c_vec8 = cv8 && (!no_wide || d->zero_fill_pitch > 0);
+    if (d->zero_fill_pitch != 0)
+        CB_REQUIRE(d->zero_fill_pitch > 0 && d->c_rowmap && p.c_vec8 && d->batch <= 1,
+                   "cb_gemm: zero_fill_pitch needs c_rowmap and 16-byte-aligned 8-column chunks (N, ldc %% 8 == 0)");
     // default workgroup order: XCD-compact (it won or tied on ~80 % of the round-2 sweep's shapes and lowers the fabric traffic)
     p.xcd_remap = !no_remap && xcd != 2;
 

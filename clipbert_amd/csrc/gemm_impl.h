@@ -36,6 +36,7 @@ struct GP {
     uint64_t seed;
     const uint64_t* seed_ptr;
     int c_vec, c_vec8;
+    int zfill;                 // zero_fill_pitch (see the header)
     int xcd_remap;              // 1: remap workgroup ids so that each XCD (own L2) owns a contiguous chunk of tiles
     uint32_t a_bytes, b_bytes;
     int ktiles;
@@ -747,6 +748,15 @@ __device__ __forceinline__ void store8(bf16* q, const float (&v)[8]) {
 
 // Epilogue of 8 consecutive columns n..n+7 of row m (row-contiguous: every global access is a full 16-byte lane
 // access and a wave touches whole cache lines).  sc/sh are the per-column scale/shift the thread loaded once.
+// stride-2 scatter (zero_fill_pitch): the other three pixels of output pixel m's 2x2 input patch receive zeros
+template <typename T>
+__device__ __forceinline__ void zero_patch8(T* base, int64_t ld, int64_t orow, int n, int pitch) {
+    const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    store8(base + (orow + 1) * ld + n, z);
+    store8(base + (orow + pitch) * ld + n, z);
+    store8(base + (orow + pitch + 1) * ld + n, z);
+}
+
 // EPF: the residual / (mask | GELU pre-activation) chunk was fetched before the K loop (epi_prefetch) -- rpre / apre hold it.
 template <typename T, bool EPF = false>
 __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const float (&sc)[8], const float (&sh)[8],
@@ -799,6 +809,10 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
             for (int r = 0; r < 8; ++r) v[r] *= t[r];
         }
         store8(c, v);
+        if (p.zfill) {
+            zero_patch8(reinterpret_cast<T*>(p.C), p.ldc, orow, n, p.zfill);
+            if (p.C2) zero_patch8(reinterpret_cast<T*>(p.C2), p.ldc2, orow, n, p.zfill);
+        }
         return;
     }
     if (p.scale) {
@@ -859,6 +873,11 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
             for (int r = 0; r < 8; ++r) v[r] += t[r];
         }
         store8(c, v);
+    }
+    if (p.zfill) {
+        if (p.c_f32) zero_patch8(reinterpret_cast<float*>(p.C), p.ldc, orow, n, p.zfill);
+        else zero_patch8(reinterpret_cast<T*>(p.C), p.ldc, orow, n, p.zfill);
+        if (p.C2) zero_patch8(reinterpret_cast<T*>(p.C2), p.ldc2, orow, n, p.zfill);
     }
 }
 

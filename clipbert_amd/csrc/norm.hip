@@ -192,22 +192,38 @@ __global__ void __launch_bounds__(NW * 64) layernorm_bwd_kernel(const T* dy, con
     }
 }
 
-// grad[off[kind][job] + col] += sum_b part[job][b][kind][col]: block = (256-column chunk, kind, job); thread = one column; the
-// nblocks partial rows are read as coalesced 1 KiB rows, summed in block order (a fixed order: deterministic)
-__global__ void __launch_bounds__(256) ln_partials_reduce_kernel(const float* part, float* grad, const int64_t* off_gamma,
-                                                                 const int64_t* off_beta, int nblocks, int D) {
-    const int col = blockIdx.x * 256 + threadIdx.x, kind = blockIdx.y, job = blockIdx.z;
-    if (col >= D) return;
-    const float* q = part + ((int64_t)job * nblocks * 2 + kind) * D + col;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 4 <= nblocks; b += 4) {
-        s0 += q[(int64_t)(b + 0) * 2 * D]; s1 += q[(int64_t)(b + 1) * 2 * D];
-        s2 += q[(int64_t)(b + 2) * 2 * D]; s3 += q[(int64_t)(b + 3) * 2 * D];
+// grad[off[kind][job] + col] += sum_b part[job][b][kind][col].  Block = (256-column chunk, kind, job), 16 waves: wave w sums the partial
+// rows b = w, w + 16, ... (lane = 4 consecutive columns, 1 KiB per wave per row, every load of a wave's rows in flight together), the 16
+// wave sums are then added in wave order through LDS -- a fixed order: deterministic.
+__global__ void __launch_bounds__(1024) ln_partials_reduce_kernel(const float* part, float* grad, const int64_t* off_gamma,
+                                                                  const int64_t* off_beta, int nblocks, int D) {
+    __shared__ float red[16][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kind = blockIdx.y, job = blockIdx.z;
+    const int col = blockIdx.x * 256 + lane * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (col < D) {                                   // D % 4 == 0
+        const float* q = part + ((int64_t)job * nblocks * 2 + kind) * D + col;
+        int b = wave;
+        for (; b + 48 < nblocks; b += 64) {
+            f32x4 v0 = load4(q + (int64_t)(b + 0) * 2 * D), v1 = load4(q + (int64_t)(b + 16) * 2 * D);
+            f32x4 v2 = load4(q + (int64_t)(b + 32) * 2 * D), v3 = load4(q + (int64_t)(b + 48) * 2 * D);
+            s = s + ((v0 + v1) + (v2 + v3));
+        }
+        for (; b < nblocks; b += 16) s = s + load4(q + (int64_t)b * 2 * D);
     }
-    for (; b < nblocks; ++b) s0 += q[(int64_t)b * 2 * D];
-    float* dst = grad + (kind ? off_beta : off_gamma)[job] + col;
-    *dst += (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][lane * 4 + i] = s[i];
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int c = blockIdx.x * 256 + threadIdx.x;
+        if (c < D) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) t += red[w][threadIdx.x];
+            grad[(kind ? off_beta : off_gamma)[job] + c] += t;
+        }
+    }
 }
 
 // ---- embeddings -----------------------------------------------------------------------------------
@@ -452,8 +468,8 @@ extern "C" int cb_layernorm_bwd_part(int32_t dtype, const void* dy, const void* 
 
 extern "C" int cb_ln_partials_reduce(const float* part, float* grad, const int64_t* off_gamma, const int64_t* off_beta,
                                      int32_t njobs, int32_t nblocks, int32_t D, void* stream) {
-    CB_REQUIRE(part && grad && off_gamma && off_beta && njobs >= 1 && nblocks >= 1 && D >= 1, "cb_ln_partials_reduce: bad arguments");
-    hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((D + 255) / 256, 2, njobs), dim3(256), 0, cb_stream(stream), part, grad,
+    CB_REQUIRE(part && grad && off_gamma && off_beta && njobs >= 1 && nblocks >= 1 && D >= 4 && D % 4 == 0, "cb_ln_partials_reduce: bad arguments");
+    hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((D + 255) / 256, 2, njobs), dim3(1024), 0, cb_stream(stream), part, grad,
                        off_gamma, off_beta, nblocks, D);
     return cb_launch_status("cb_ln_partials_reduce");
 }

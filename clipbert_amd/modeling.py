@@ -264,7 +264,10 @@ def _conv_dgrad(rt: Runtime, g, conv, in_shape, scale=None, mask=None, residual=
     k, s, p = conv.k, conv.stride, conv.pad
     wk = rt.bank.compute(conv.weight).view(cout, k * k * cin)
     mi = n * h * w
-    alloc = torch.zeros if s > 1 else torch.empty
+    # stride-2 1x1 convolution: only the even pixels receive a gradient.  When the 2x2 patches tile the input exactly the launch
+    # itself writes the zeros of the other three pixels (zero_fill_pitch); otherwise the output is pre-zeroed
+    zfill = w if (k == 1 and s == 2 and h % 2 == 0 and w % 2 == 0 and cin % 8 == 0) else 0
+    alloc = torch.zeros if (s > 1 and not zfill) else torch.empty
     if out is None:
         out = alloc(n, h, w, cin, dtype=g.dtype, device=g.device)
     o2 = out.view(mi, cin)
@@ -281,7 +284,8 @@ def _conv_dgrad(rt: Runtime, g, conv, in_shape, scale=None, mask=None, residual=
     if k == 1:
         rowmap = rt.strided_rowmap(n, h, w, oh, ow, s, g.device) if s > 1 else None
         ops.gemm(g.view(n * oh * ow, cout), wk, n * oh * ow, cin, cout, out=o2, b_mode=KROW_TAPS, ldb=cin, R=1, S=1,
-                 Cin=cout, c_rowmap=rowmap, scale=scale, mask=k2, residual=r2, accumulate=accumulate, **extra)
+                 Cin=cout, c_rowmap=rowmap, scale=scale, mask=k2, residual=r2, accumulate=accumulate, zero_fill_pitch=zfill if s > 1 else 0,
+                 **extra)
     else:
         assert s == 1
         tab = rt.table(n, h, w, 1, k - 1 - p, oh * ow * cout, ow * cout, cout, g.device)
@@ -793,7 +797,6 @@ def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
     nl, stk = len(pk.layers), pk.stk
     # LayerNorm parameter gradients: every LN backward stores per-block partial sums (no atomics); ONE launch after the layer
     # loop adds all 2*nl of them onto the gradient buffer in a fixed order (deterministic).  Frozen LN parameters -> atomics path.
-    ln_off = _ln_offsets(model, dev)
     nb = ops.ln_part_blocks(M)
     ln_part = torch.empty(2 * nl, nb, 2, d, dtype=torch.float32, device=dev) if ln_off is not None else None
 

@@ -52,7 +52,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch
          sH=0, sW=0, flip_taps=False, c_rowmap=None, accumulate=False, split_k=1, act=ACT_NONE,
          scale=None, shift=None, residual=None, ldr=None, relu_after=False, mask=None, ldm=None,
          out2=None, ldc2=None, alpha=1.0, dropout_p=0.0, dropout_seed=0, seed_ptr=None, tile=0, gelu_grad_pre=None, a_rowsum=None, batch=1, batch_strides=None,
-         relu_bwd=False, post_scale=None, post_scale2=None, xcd_order=0):
+         relu_bwd=False, post_scale=None, post_scale2=None, xcd_order=0, zero_fill_pitch=0):
     """C[M,N] (op)= epilogue(sum_k A(m,k) B(n,k)); see include/clipbert_hip.h cb_gemm_desc."""
     d = GemmDesc()
     d.dtype = dtype_code(a.dtype)
@@ -68,6 +68,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch
     d.C = _ptr(out)
     d.ldc = ldc if ldc is not None else out.stride(0)
     d.c_rowmap = _ptr(c_rowmap)
+    d.zero_fill_pitch = zero_fill_pitch
     d.c_f32 = int(out.dtype == torch.float32)
     d.accumulate = int(accumulate)
     d.split_k = split_k

@@ -71,7 +71,10 @@ typedef struct {
     const float* shift;       /* optional per-n addend (bias / FrozenBN shift)                       */
     const void* residual; int64_t ldr;    /* optional, added after act                               */
     int32_t relu_after;       /* ReLU after the residual add (ResNet block output)                    */
-    int32_t reserved1;
+    int32_t zero_fill_pitch;  /* > 0 with c_rowmap: the rows orow+1, orow+pitch, orow+pitch+1 of C (and C2) are written
+                               * with ZEROS -- data gradient of a stride-2 1x1 convolution: output pixel m owns a 2x2 patch
+                               * of input pixels of which only the first receives a value (pitch = input row width W);
+                               * needs 16-byte-aligned 8-column chunks (N, ldc % 8 == 0)                             */
     const void* mask; int64_t ldm;        /* optional: result zeroed where mask[m,n] <= 0 (ReLU bwd)  */
     void* C2; int64_t ldc2;   /* optional second output: value BEFORE act (GELU backward needs it)   */
     float alpha;              /* multiplies the accumulator first (1.0 if 0)                         */
@@ -274,6 +277,19 @@ int cb_elu_bn1d_bwd(int32_t dtype, const void* dy, const void* x, const float* g
 
 const char* cb_last_error(void);
 int cb_version(void);
+
+/* ---- gradient exchange (one process per GPU, RCCL over xGMI) ----------------------------------------------------
+ * Replaces Horovod's per-tensor NCCL all-reduce (src/tasks/run_video_retrieval.py:298-305, 432; src/utils/distributed.py).
+ * cb_comm_unique_id: rank 0 creates the 128-byte id and the host distributes it (any channel).  cb_comm_init: every rank,
+ * on its GPU (the calling thread's current HIP device); one communicator per process.  cb_allreduce_bucket: in-place SUM of
+ * `count` elements (CB_F32 or CB_BF16: the flat gradient buffer or its bf16 wire image) over all ranks, enqueued on
+ * `stream` -- asynchronous, ordered against other streams by HIP events, capturable into a hipGraph.  RCCL is loaded at
+ * run time (librccl.so.1); without it these calls fail with a message and everything else works. */
+int cb_comm_unique_id(void* id128);
+int cb_comm_init(int32_t rank, int32_t world, const void* id128);
+int cb_comm_info(int32_t* rank, int32_t* world);
+int cb_allreduce_bucket(void* buf, int64_t count, int32_t dtype, void* stream);
+int cb_comm_destroy(void);
 
 #ifdef __cplusplus
 }

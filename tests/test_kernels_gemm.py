@@ -180,6 +180,22 @@ def test_conv_forward_backward(hw, dt, tile, k, stride, pad, H, W, Cin, Cout):
         rowmap = (torch.arange(n).view(n, 1, 1) * H * W + (torch.arange(OH) * stride).view(1, OH, 1) * W
                   + (torch.arange(OW) * stride).view(1, 1, OW)).reshape(-1).int().to(hw.dev)
         ops.gemm(gh, wk, M, Cin, Cout, out=dx, b_mode=ops.KROW_TAPS, ldb=Cin, R=1, S=1, Cin=Cout, c_rowmap=rowmap, tile=tile)
+        if stride == 2 and H % 2 == 0 and W % 2 == 0:
+            # zero_fill_pitch: the launch also writes the zeros of the three other pixels of every 2x2 patch (no pre-zeroed output)
+            dz = torch.full((n * H * W, Cin), float("nan"), dtype=dt, device=hw.dev)
+            d2 = torch.full((n * H * W, Cin), float("nan"), dtype=dt, device=hw.dev)
+            ops.gemm(gh, wk, M, Cin, Cout, out=dz, b_mode=ops.KROW_TAPS, ldb=Cin, R=1, S=1, Cin=Cout, c_rowmap=rowmap, tile=tile,
+                     zero_fill_pitch=W)
+            assert torch.equal(dz, dx)
+            # ... also for the two outputs of the fused ReLU x FrozenBN backward, accumulating onto a first strided gradient
+            ymask = hw(rnd(n * H * W, Cin, seed=9).to(dt))
+            ps = hw(rnd(Cin, seed=10).abs() + 0.5)
+            acc = dz.clone()
+            ops.gemm(gh, wk, M, Cin, Cout, out=acc, b_mode=ops.KROW_TAPS, ldb=Cin, R=1, S=1, Cin=Cout, c_rowmap=rowmap, tile=tile,
+                     zero_fill_pitch=W, accumulate=True, mask=ymask, relu_bwd=True, post_scale=ps, out2=d2)
+            t = torch.where(ymask.float() > 0, 2 * dx.float(), torch.zeros_like(dx.float()))
+            torch.testing.assert_close(d2.float(), t, **tol(dt))
+            torch.testing.assert_close(acc.float(), t * ps, **tol(dt))
     torch.testing.assert_close(dx.float().view(n, H, W, Cin), xr.grad.permute(0, 2, 3, 1), **tol(dt))
     # wgrad: dW[co][(r,s,c)] = sum_m g[m,co] X[pix(m,r,s), c], split over the pixel reduction
     dw = torch.zeros(Cout, k * k * Cin, dtype=torch.float32, device=hw.dev)

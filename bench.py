@@ -153,7 +153,9 @@ def main():
 
     sync = opt = None
     if train:
-        sync = GradSync(bank, compress=None if os.environ.get("CB_BENCH_FP32_WIRE") == "1" else "bf16")
+        # CB_COMM=native: buckets through the library's own RCCL entry point (cb_allreduce_bucket) instead of torch.distributed
+        sync = GradSync(bank, compress=None if os.environ.get("CB_BENCH_FP32_WIRE") == "1" else "bf16",
+                        comm="native" if (os.environ.get("CB_COMM") == "native" and backend == "nccl") else "torch")
         sync.broadcast_parameters(0)
         opt = FusedAdamW(bank, lr=5e-5, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0)
     state = {"global_step": 0}

@@ -19,16 +19,72 @@ import torch.distributed as dist
 from .params import ParamBank
 
 
+class NativeComm:
+    """The C ABI's communicator (include/clipbert_hip.h: cb_comm_init / cb_allreduce_bucket): RCCL called by libclipbert_hip
+    itself on a stream the caller chooses, instead of torch.distributed's process-group call.  torch.distributed (any backend)
+    is only the channel that carries rank 0's 128-byte unique id to the other ranks.  One per process."""
+    _instance = None
+
+    def __init__(self, rank: int, world: int, unique_id: bytes):
+        import ctypes
+        from . import _lib
+        assert len(unique_id) == 128
+        self._buf = ctypes.create_string_buffer(unique_id, 128)
+        _lib.check(_lib.get().cb_comm_init(rank, world, ctypes.cast(self._buf, ctypes.c_void_p)), "cb_comm_init")
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes
+        from . import _lib
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.get().cb_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)), "cb_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls, group=None) -> "NativeComm":
+        """every rank calls this with its GPU current (torch.cuda.set_device)"""
+        if cls._instance is not None:
+            return cls._instance
+        if dist.is_initialized():
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+            box = [cls.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        else:
+            rank, world, box = 0, 1, [cls.unique_id()]
+        cls._instance = cls(rank, world, box[0])
+        return cls._instance
+
+    def all_reduce_(self, t: torch.Tensor, stream=None):
+        """in-place sum over the ranks, enqueued on `stream` (default: the current stream)"""
+        from . import _lib
+        from .ops import dtype_code
+        assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)
+        st = stream if stream is not None else torch.cuda.current_stream(t.device)
+        _lib.check(_lib.get().cb_allreduce_bucket(t.data_ptr(), t.numel(), dtype_code(t.dtype), st.cuda_stream), "cb_allreduce_bucket")
+        return t
+
+    @classmethod
+    def destroy(cls):
+        from . import _lib
+        if cls._instance is not None:
+            _lib.check(_lib.get().cb_comm_destroy(), "cb_comm_destroy")
+            cls._instance = None
+
+
 class GradSync:
     """``compress="bf16"`` sends the gradients as bf16 (half the xGMI payload: 297 MB instead of 594 MB per step; the
     reference's apex-O2 gradients are fp16 on the wire too): cast -> all-reduce -> cast back, three passes over the flat
     buffer (~0.3 ms) against ~1.5 ms of link time saved on 8 GPUs."""
 
-    def __init__(self, bank: ParamBank, group=None, bucket_bytes: int = 64 << 20, compress: Optional[str] = None):
+    def __init__(self, bank: ParamBank, group=None, bucket_bytes: int = 64 << 20, compress: Optional[str] = None, comm: str = "torch"):
         """bucket_bytes: fp32 gradient bytes per all-reduce (0 = one collective per range).  The default 64 MiB (32 MiB on
         the wire in bf16) lets the cast of bucket i+1 run while bucket i is on the links, and keeps each collective well
         past the ~8 MiB where RCCL's ring reaches its link bandwidth."""
-        assert compress in (None, "bf16")
+        assert compress in (None, "bf16") and comm in ("torch", "native")
+        # comm="native": the buckets go through cb_allreduce_bucket (RCCL called by the library) on this object's own HIP stream,
+        # ordered against the compute stream by events; "torch": torch.distributed all_reduce(async_op=True) (also the CPU / gloo path)
+        self.native = None
         self.bank = bank
         bank.clients += 1
         self.group = group
@@ -42,6 +98,10 @@ class GradSync:
         self._work: List = []
         self._pending: List = []            # (start, end) ranges whose bf16 wire image must be cast back after wait()
         self._inflight: List = []           # ranges handed to _reduce since the last wait()
+        if comm == "native" and self.world > 1:
+            assert bank.grad.is_cuda, "comm='native' needs the gradients on a GPU"
+            self.native = NativeComm.from_process_group(group)
+            self.comm_stream = torch.cuda.Stream(device=bank.grad.device)
 
     @property
     def grad_scale(self) -> float:
@@ -83,10 +143,18 @@ class GradSync:
                 if cast:
                     self.cast_range(s, e)                          # (per bucket: the cast of bucket i+1 overlaps bucket i's transfer)
                 self._ensure_wire()
-                self._work.append(dist.all_reduce(self._wire[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._work.append(self._all_reduce(self._wire[s:e]))
                 self._pending.append((s, e))
             else:
-                self._work.append(dist.all_reduce(self.bank.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._work.append(self._all_reduce(self.bank.grad[s:e]))
+
+    def _all_reduce(self, t: torch.Tensor):
+        if self.native is None:
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        # the bucket was produced on the current stream: the comm stream waits for exactly that point, then carries the collective
+        self.comm_stream.wait_stream(torch.cuda.current_stream(t.device))
+        self.native.all_reduce_(t, self.comm_stream)
+        return None
 
     def reduce_transformer(self, cast: bool = True):
         """cast=False: the wire image of the range was already produced by cast_transformer() (e.g. inside a captured graph)"""
@@ -104,7 +172,10 @@ class GradSync:
         """cast_back=False (bf16 wire only): leave the reduced gradients in the wire buffer for an optimizer that reads bf16
         (wire_gradients()); bank.grad then still holds THIS rank's un-reduced fp32 gradients."""
         for w in self._work:
-            w.wait()
+            if w is not None:
+                w.wait()
+        if self.native is not None and self._work:
+            torch.cuda.current_stream(self.bank.grad.device).wait_stream(self.comm_stream)
         self._work = []
         self._inflight = []
         if not cast_back and self.compress == "bf16":

@@ -758,17 +758,17 @@ __device__ __forceinline__ void zero_patch8(T* base, int64_t ld, int64_t orow, i
 }
 
 // EPF: the residual / (mask | GELU pre-activation) chunk was fetched before the K loop (epi_prefetch) -- rpre / apre hold it.
-template <typename T, bool EPF = false>
+template <typename T, int EPF = 0>
 __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const float (&sc)[8], const float (&sh)[8],
                                           int m, int64_t orow, int n, bf16x8 rpre = bf16x8{}, bf16x8 apre = bf16x8{}) {
     auto load_res = [&](float (&t)[8]) {
-        if constexpr (EPF) {
+        if constexpr (EPF == 2) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) t[r] = (float)rpre[r];
         } else load8(reinterpret_cast<const T*>(p.residual) + orow * p.ldr + n, t);
     };
     auto load_aux = [&](const void* base, int64_t ld, float (&t)[8]) {
-        if constexpr (EPF) {
+        if constexpr (EPF >= 1) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) t[r] = (float)apre[r];
         } else load8(reinterpret_cast<const T*>(base) + orow * ld + n, t);
@@ -887,15 +887,18 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
 // runs: for the short-K 1x1 convolutions of the ResNet (1-4 K tiles, HBM-bound) the block otherwise waits a full HBM round trip
 // between its last MFMA and its stores.  Same (row, chunk) map as tile_epilogue's c_vec8 branch.  NCH chunks x 2 operands x 4 VGPR.
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN>
+// WITH_R = false: only the second operand (mask / GELU pre-activation) is prefetched -- the 128x128 two-blocks-per-CU tile has 32
+// registers to spare, not 64.
+template <int BM, int BN, bool WITH_R = true>
 struct EpiPre {
     static constexpr int WM = BM / 2, CPR = BN / 8, ITER = WM * CPR / NTHREADS, NCH = 2 * ITER;
-    bf16x8 r[NCH], a[NCH];
+    static constexpr bool HAS_R = WITH_R;
+    bf16x8 r[WITH_R ? NCH : 1], a[NCH];
 };
 
-template <typename T, int BM, int BN>
-__device__ __forceinline__ void epi_prefetch(const GP& p, EpiPre<BM, BN>& pre, int m0, int n0, int tid) {
-    using E = EpiPre<BM, BN>;
+template <typename T, int BM, int BN, bool WITH_R>
+__device__ __forceinline__ void epi_prefetch(const GP& p, EpiPre<BM, BN, WITH_R>& pre, int m0, int n0, int tid) {
+    using E = EpiPre<BM, BN, WITH_R>;
     const int cc = tid % E::CPR, n = n0 + cc * 8;
     const void* aux = p.mask ? p.mask : p.dact_pre;
     const int64_t lda = p.mask ? p.ldm : p.ldd;
@@ -905,11 +908,13 @@ __device__ __forceinline__ void epi_prefetch(const GP& p, EpiPre<BM, BN>& pre, i
         for (int it = 0; it < E::ITER; ++it) {
             const int m = m0 + h * E::WM + (tid + it * NTHREADS) / E::CPR;
             bf16x8 z = {};
-            pre.r[h * E::ITER + it] = z;
+            if constexpr (WITH_R) pre.r[h * E::ITER + it] = z;
             pre.a[h * E::ITER + it] = z;
             if (m < p.M && n < p.N) {
                 const int64_t orow = p.c_rowmap ? (int64_t)p.c_rowmap[m] : (int64_t)m;
-                if (p.residual) pre.r[h * E::ITER + it] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(p.residual) + orow * p.ldr + n);
+                if constexpr (WITH_R) {
+                    if (p.residual) pre.r[h * E::ITER + it] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(p.residual) + orow * p.ldr + n);
+                }
                 if (aux) pre.a[h * E::ITER + it] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const T*>(aux) + orow * lda + n);
             }
         }
@@ -918,9 +923,9 @@ __device__ __forceinline__ void epi_prefetch(const GP& p, EpiPre<BM, BN>& pre, i
 // ---------------------------------------------------------------------------------------------
 // Tile epilogue shared by both kernel structures.  acc[i][j] = 4 consecutive n of row m (swapped MFMA operands).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int SMEM_BYTES, bool EPF = false>
+template <typename T, int BM, int BN, int SMEM_BYTES, int EPF = 0>
 __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 32], unsigned char* smem, int m0, int n0, int tid,
-                                              const EpiPre<BM, BN>& pre = EpiPre<BM, BN>{}, bool use_pre = false) {
+                                              const EpiPre<BM, BN, EPF != 1>& pre = EpiPre<BM, BN, EPF != 1>{}, bool use_pre = false) {
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -960,8 +965,11 @@ __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 
                     const int64_t orow = p.c_rowmap ? (int64_t)p.c_rowmap[m] : (int64_t)m;
                     float v[8];
                     load8(reinterpret_cast<const float*>(smem + rl * SROW + cc * 32), v);
-                    if constexpr (EPF) {
-                        if (use_pre) epilogue8<T, true>(p, v, sc, sh, m, orow, n, pre.r[h * ITER + it], pre.a[h * ITER + it]);
+                    if constexpr (EPF == 2) {
+                        if (use_pre) epilogue8<T, 2>(p, v, sc, sh, m, orow, n, pre.r[h * ITER + it], pre.a[h * ITER + it]);
+                        else epilogue8<T>(p, v, sc, sh, m, orow, n);
+                    } else if constexpr (EPF == 1) {
+                        if (use_pre) epilogue8<T, 1>(p, v, sc, sh, m, orow, n, bf16x8{}, pre.a[h * ITER + it]);
                         else epilogue8<T>(p, v, sc, sh, m, orow, n);
                     } else epilogue8<T>(p, v, sc, sh, m, orow, n);
                 }
@@ -1104,11 +1112,14 @@ __global__ void __launch_bounds__(256, OCC) gemm_kernel(GP p) {
     // Only the data-gradient forms carry it (the registers would cost the weight-gradient kernels occupancy), and only for the fused
     // ReLU x FrozenBN backward (two operands: block output y and the shortcut gradient): measured on MI355X -10 % there
     // (50176x512x128: 48.3 -> 42.7 us), nothing or slightly negative for single-operand epilogues (forward residual, GELU').
-    constexpr bool EPF = sizeof(T) == 2 && BM * BN <= 128 * 64 && !LA::KROW && LB::KROW;
-    EpiPre<BM, BN> epre;
-    const bool epf_on = EPF && p.c_vec8 && p.relu_bwd;      // block-uniform
-    if constexpr (EPF) {
-        if (epf_on) epi_prefetch<T, BM, BN>(p, epre, m0, n0, tid);
+    // The 128x128 two-blocks-per-CU data-gradient kernel prefetches ONE operand, for the GELU' epilogue (dgrad of BertOutput.dense: the
+    // 16 MB pre-activation would otherwise be requested by all blocks at once after their last MFMA).
+    constexpr bool DGRAD = sizeof(T) == 2 && !LA::KROW && LB::KROW;
+    constexpr int EPF = !DGRAD ? 0 : (BM * BN <= 128 * 64 ? 2 : (OCC >= 2 ? 1 : 0));
+    EpiPre<BM, BN, EPF != 1> epre;
+    const bool epf_on = EPF != 0 && p.c_vec8 && (EPF == 2 ? p.relu_bwd != 0 : (p.dact_pre != nullptr && !p.relu_bwd));      // block-uniform
+    if constexpr (EPF != 0) {
+        if (epf_on) epi_prefetch<T, BM, BN, EPF != 1>(p, epre, m0, n0, tid);
     }
     store_tiles(sa[0], sb[0], 0);
     if (PF < nt) load_tiles_checked(sa[0], sb[0]);
@@ -1211,7 +1222,7 @@ __global__ void __launch_bounds__(256, OCC) gemm_kernel(GP p) {
             }
         }
     }
-    if constexpr (EPF) tile_epilogue<T, BM, BN, SMEM_BYTES, true>(p, acc, smem, m0, n0, tid, epre, epf_on);
+    if constexpr (EPF != 0) tile_epilogue<T, BM, BN, SMEM_BYTES, EPF>(p, acc, smem, m0, n0, tid, epre, epf_on);
     else tile_epilogue<T, BM, BN, SMEM_BYTES>(p, acc, smem, m0, n0, tid);
 }
 

@@ -797,6 +797,7 @@ def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
     nl, stk = len(pk.layers), pk.stk
     # LayerNorm parameter gradients: every LN backward stores per-block partial sums (no atomics); ONE launch after the layer
     # loop adds all 2*nl of them onto the gradient buffer in a fixed order (deterministic).  Frozen LN parameters -> atomics path.
+    ln_off = _ln_offsets(model, dev)
     nb = ops.ln_part_blocks(M)
     ln_part = torch.empty(2 * nl, nb, 2, d, dtype=torch.float32, device=dev) if ln_off is not None else None
 

@@ -136,10 +136,18 @@ def _worker(rank, world, port, out_path, compress=None, fn="one_step"):
         dist.destroy_process_group()
 
 
+def _spawn_all(jobs):
+    """start every (world, out_path, compress, fn) job at once (independent rendezvous ports) and join them all: the runs are
+    dominated by process start-up and model construction, so they overlap well on the test host's cores"""
+    ctxs = [mp.spawn(_worker, args=(world, _free_port(), out, compress, fn), nprocs=world, join=False) for world, out, compress, fn in jobs]
+    for c in ctxs:
+        while not c.join():
+            pass
+
+
 def test_dp2_multi_clip_loop_with_accumulation(tmp_path):
     p2, p1 = str(tmp_path / "dp2.pt"), str(tmp_path / "dp1.pt")
-    mp.spawn(_worker, args=(2, _free_port(), p2, None, "multi"), nprocs=2, join=True)
-    mp.spawn(_worker, args=(1, _free_port(), p1, None, "multi"), nprocs=1, join=True)
+    _spawn_all([(2, p2, None, "multi"), (1, p1, None, "multi")])
     a, b = torch.load(p2), torch.load(p1)
     # accumulated gradients are SUMS over micro-steps of per-rank mean losses: DP=2 averages two half-size means
     assert abs(a["norm"] - b["norm"]) / b["norm"] < 1e-3
@@ -148,10 +156,8 @@ def test_dp2_multi_clip_loop_with_accumulation(tmp_path):
 
 def test_dp2_equals_dp1_on_the_global_batch(tmp_path):
     p2, p2c, p2d, p1 = str(tmp_path / "dp2.pt"), str(tmp_path / "dp2c.pt"), str(tmp_path / "dp2d.pt"), str(tmp_path / "dp1.pt")
-    mp.spawn(_worker, args=(2, _free_port(), p2), nprocs=2, join=True)
-    mp.spawn(_worker, args=(2, _free_port(), p2c, "bf16"), nprocs=2, join=True)       # bf16 gradients on the wire
-    mp.spawn(_worker, args=(2, _free_port(), p2d, "bf16direct"), nprocs=2, join=True)  # ... consumed by AdamW without the cast back
-    mp.spawn(_worker, args=(1, _free_port(), p1), nprocs=1, join=True)
+    # p2c: bf16 gradients on the wire; p2d: ... consumed by AdamW without the cast back
+    _spawn_all([(2, p2, None, "one_step"), (2, p2c, "bf16", "one_step"), (2, p2d, "bf16direct", "one_step"), (1, p1, None, "one_step")])
     a, c, b = torch.load(p2), torch.load(p2c), torch.load(p1)
     d = torch.load(p2d)
     torch.testing.assert_close(d["master"], c["master"], rtol=0, atol=0)            # same values as cast-back + fp32 AdamW, bit for bit
@@ -167,8 +173,7 @@ def test_dp2_equals_dp1_on_the_global_batch(tmp_path):
 
 def test_sharded_retrieval_inference_gathers_all_rows(tmp_path):
     p2, p1 = str(tmp_path / "inf2.pt"), str(tmp_path / "inf1.pt")
-    mp.spawn(_worker, args=(2, _free_port(), p2, None, "infer"), nprocs=2, join=True)
-    mp.spawn(_worker, args=(1, _free_port(), p1, None, "infer"), nprocs=1, join=True)
+    _spawn_all([(2, p2, None, "infer"), (1, p1, None, "infer")])
     a, b = torch.load(p2), torch.load(p1)
     assert a["rows"] == b["rows"]                        # same (vid, txt, score) rows, scores rounded to 4 places
     assert a["metrics"] == b["metrics"] and set(a["metrics"]) == {"text2video", "video2text"}

@@ -154,8 +154,11 @@ def main():
     sync = opt = None
     if train:
         # CB_COMM=native: buckets through the library's own RCCL entry point (cb_allreduce_bucket) instead of torch.distributed
+        # CB_BENCH_DRY_DP=N (single process): the N-rank replay plan with every collective skipped -- times what data parallelism
+        # costs a rank besides link time (three graphs instead of one, wire casts, bf16-direct AdamW).  A diagnostic, not the metric.
+        dry_dp = int(os.environ.get("CB_BENCH_DRY_DP", "0")) if world == 1 else 0
         sync = GradSync(bank, compress=None if os.environ.get("CB_BENCH_FP32_WIRE") == "1" else "bf16",
-                        comm="native" if (os.environ.get("CB_COMM") == "native" and backend == "nccl") else "torch")
+                        comm="native" if (os.environ.get("CB_COMM") == "native" and backend == "nccl") else "torch", pretend_world=dry_dp)
         sync.broadcast_parameters(0)
         opt = FusedAdamW(bank, lr=5e-5, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0)
     state = {"global_step": 0}
@@ -184,6 +187,7 @@ def main():
     # diagnostic (CB_BENCH_CHAINS=2): the videos split into two independent forward+backward chains on two HIP streams, so that
     # the launch ramps / tails of one chain's kernels overlap the other's main loops
     chains = int(os.environ.get("CB_BENCH_CHAINS", "1"))
+    assert chains == 1 or (world == 1 and train), "CB_BENCH_CHAINS is a single-GPU training diagnostic"
     chain_streams = [torch.cuda.Stream() for _ in range(chains)] if chains > 1 else []
 
     def device_step_chains():
@@ -310,7 +314,7 @@ def main():
     elif use_graph and not train:
         g1, loss = capture(forward_only_step)
         run, plan = g1.replay, "one hipGraph"
-    elif use_graph and world == 1:
+    elif use_graph and world == 1 and not (train and sync.dry):
         g1, loss = capture(device_step_chains if chains > 1 else device_step_single)
 
         def run_single():
@@ -425,7 +429,8 @@ def main():
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": workload, "mode": args.mode, "videos_per_gpu": bv, "n_clips": nclip, "n_frames": T, "img_size": args.size,
                    "txt_len": args.txt_len, "texts_per_video": rep, "pairs_per_gpu": pairs, "score_agg_func": args.pool, "clips_folded": fold,
-                   "input": "uint8 frames in HBM", "parallelism": f"dp{world}", "hip_graph": use_graph, "replay_plan": plan,
+                   "input": "uint8 frames in HBM",
+                   "parallelism": f"dp{world}" + (f" (DRY RUN of the dp{sync.world} plan on one GPU: no collectives)" if (train and sync is not None and sync.dry) else ""), "hip_graph": use_graph, "replay_plan": plan,
                    "dropout": bool(train), "final_loss": None if final_loss is None else round(final_loss, 5)},
     }
     if dp_check is not None:

@@ -77,7 +77,8 @@ class GradSync:
     reference's apex-O2 gradients are fp16 on the wire too): cast -> all-reduce -> cast back, three passes over the flat
     buffer (~0.3 ms) against ~1.5 ms of link time saved on 8 GPUs."""
 
-    def __init__(self, bank: ParamBank, group=None, bucket_bytes: int = 64 << 20, compress: Optional[str] = None, comm: str = "torch"):
+    def __init__(self, bank: ParamBank, group=None, bucket_bytes: int = 64 << 20, compress: Optional[str] = None, comm: str = "torch",
+                 pretend_world: int = 0):
         """bucket_bytes: fp32 gradient bytes per all-reduce (0 = one collective per range).  The default 64 MiB (32 MiB on
         the wire in bf16) lets the cast of bucket i+1 run while bucket i is on the links, and keeps each collective well
         past the ~8 MiB where RCCL's ring reaches its link bandwidth."""
@@ -89,6 +90,11 @@ class GradSync:
         bank.clients += 1
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # pretend_world > 1 (single process, no process group): everything a rank of an N-rank job does EXCEPT the collectives --
+        # wire casts, bucket bookkeeping, 1/N scaling, bf16-direct AdamW -- so the non-link overhead of the DP plan can be timed on one GPU
+        self.dry = pretend_world > 1 and self.world == 1
+        if self.dry:
+            self.world = pretend_world
         t_end = bank.group_range[3][1]
         self.t_range = (0, t_end)
         self.c_range = (t_end, bank.n_train)
@@ -149,6 +155,8 @@ class GradSync:
                 self._work.append(self._all_reduce(self.bank.grad[s:e]))
 
     def _all_reduce(self, t: torch.Tensor):
+        if self.dry:
+            return None
         if self.native is None:
             return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         # the bucket was produced on the current stream: the comm stream waits for exactly that point, then carries the collective
@@ -191,7 +199,7 @@ class GradSync:
 
     def broadcast_parameters(self, src: int = 0):
         """hvd.broadcast_parameters equivalent (run_video_retrieval.py:304): one flat buffer per kind."""
-        if self.world == 1:
+        if self.world == 1 or self.dry:
             return
         dist.broadcast(self.bank.master, src, group=self.group)
         dist.broadcast(self.bank.f_master, src, group=self.group)

@@ -68,6 +68,12 @@ def lse_train_loss(logits_bnc: torch.Tensor, labels: torch.Tensor) -> torch.Tens
     return _LseLossFn.apply(st, labels.view(-1)).view(-1, 1)
 
 
+def lse_stack_train_loss(logits, labels: torch.Tensor) -> torch.Tensor:
+    """aggregate_clip_logits(logits, "lse") followed by lse_train_loss, without materialising the (B, n_clips, C) transpose and
+    its inverse (two copies forward, two backward): the kernel reads the (n_clips, B, C) stack as the forwards produced it."""
+    return _LseLossFn.apply(_stack(logits), labels.view(-1)).view(-1, 1)
+
+
 def lse_inference_logits(logits_bnc: torch.Tensor) -> torch.Tensor:
     """run_video_retrieval.py:674-676: logsumexp over the clips -> (B, C)."""
     st = logits_bnc.permute(1, 0, 2).contiguous().float()

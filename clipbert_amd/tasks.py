@@ -72,10 +72,10 @@ def forward_clips(model, batch: Dict, num_clips: int, num_frm: int, fold: bool =
 def training_loss(model, logits, labels, n_examples_list, pool_method: str) -> torch.Tensor:
     """:402-419: pool the clips (``logits``: list of per-clip logits or their (n_clips, B', C) stack) and take the mean
     per-pair loss."""
-    pooled = clips.aggregate_clip_logits(logits, pool_method)
     if pool_method == "lse":
-        loss = clips.lse_train_loss(pooled, labels)
-    elif getattr(model, "retrieval", False):
+        return clips.lse_stack_train_loss(logits, labels).mean()
+    pooled = clips.aggregate_clip_logits(logits, pool_method)
+    if getattr(model, "retrieval", False):
         _, loss = model.transformer.calc_loss(pooled, labels, sample_size=len(n_examples_list))
     else:                                                   # QA heads (run_video_qa.py:417-419)
         _, loss = model.transformer.calc_loss(pooled, labels)

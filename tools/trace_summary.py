@@ -92,7 +92,7 @@ def main():
     text = "\n".join(lines)
     print(text)
     if len(sys.argv) > 2:
-        open(sys.argv[2], "a").write(text + "\n")
+        open(sys.argv[2], "w").write(text + "\n")
 
 
 if __name__ == "__main__":

@@ -177,7 +177,7 @@ def main():
     def device_step_single():
         """everything a 1-GPU step enqueues (capturable)"""
         opt.zero_grad(lazy=True)
-        model.rt.pending_encoder_nodes = 0
+        model.rt.pending_encoder_nodes = model.rt.pending_cnn_nodes = 0
         loss = forward_loss()
         loss.backward()
         model.rt.seed_dev.add_(1)
@@ -218,9 +218,10 @@ def main():
             return device_step_chains()
         host_prepare()
         opt.zero_grad(lazy=True)
-        model.rt.pending_encoder_nodes = 0
+        model.rt.pending_encoder_nodes = model.rt.pending_cnn_nodes = 0
         loss = forward_loss()
-        loss.backward()                         # (N > 1: the transformer buckets leave from inside the encoder backward)
+        loss.backward()                         # (N > 1: the transformer buckets leave from inside the encoder backward,
+                                                #  grid_encoder + res5 from inside the ResNet backward)
         if model.rt.after_encoder_backward is None:
             sync.reduce_transformer()
         sync.reduce_cnn()
@@ -266,8 +267,10 @@ def main():
     elif not train:
         eager_fn = forward_only_step
     else:
+        sync.set_cnn_split(M.cnn_early_split(model))           # grid_encoder + res5 gradients can leave before res4 / res3 are done
         if world > 1:
             model.rt.after_encoder_backward = sync.reduce_transformer
+            model.rt.after_res5_backward = sync.reduce_cnn_early
         eager_fn = train_step_eager
 
     log("inputs ready")
@@ -325,11 +328,12 @@ def main():
         # The backward is cut at the grid features: autograd.grad(loss, grid) runs the heads' and the encoder's backward
         # (parameter gradients land in the flat buffer as a side effect), grid.backward(dgrid) runs the CNN trunk's.
         model.rt.after_encoder_backward = None                 # collectives are issued between the graphs, eagerly
+        model.rt.after_res5_backward = None
         cut = {}
 
         def part_a():
             opt.zero_grad(lazy=True)
-            model.rt.pending_encoder_nodes = 0
+            model.rt.pending_encoder_nodes = model.rt.pending_cnn_nodes = 0
             vis = frames.view(bv * nclip, T, *frames.shape[2:]) if (fold and nclip > 1) else frames
             assert fold or nclip == 1, "the split replay plan needs the folded clip forward (one encoder node)"
             grid = model.grid_features(vis)
@@ -348,24 +352,52 @@ def main():
             cut["grid"].backward(cut["dgrid"])
             sync.cast_cnn()
 
+        # The ResNet backward in two graphs: [grid_encoder + res5] -> their buckets leave -> [res4, res3] -> the rest.  The
+        # generator (modeling.cnn_backward_steps) is driven by hand with the saved activations of the grid-feature autograd node.
+        def part_b1():
+            node = cut["grid"].grad_fn
+            cut["cnn_steps"] = M.cnn_backward_steps(node.bb, node.pack, cut["dgrid"].contiguous())
+            if next(cut["cnn_steps"], None) is None:
+                cut["cnn_steps"] = None                            # nothing after res5: the generator already ran to its end
+            sync.cast_cnn_early()
+
+        def part_b2():
+            if cut["cnn_steps"] is not None:
+                for _ in cut["cnn_steps"]:
+                    pass
+            cut["cnn_steps"] = None
+            sync.cast_cnn(late_only=True)
+
         def part_c():
             model.rt.seed_dev.add_(1)
             opt.launch(grad16=sync.wire_gradients())
 
         wire16 = sync.wire_gradients() is not None
+        split_cnn = bool(sync.c_early) and wire16 and os.environ.get("CB_BENCH_CNN_SPLIT", "1") != "0"
         ga, loss = capture(part_a)
-        gb, _ = capture(part_b)
+        if split_cnn:
+            gb1, _ = capture(part_b1)
+            gb2, _ = capture(part_b2)
+        else:
+            gb, _ = capture(part_b)
         gc, _ = capture(part_c)
 
         def run_split():
             host_prepare()
             ga.replay()
             sync.reduce_transformer(cast=not wire16)       # only the collectives are issued eagerly
-            gb.replay()
-            sync.reduce_cnn(cast=not wire16)
+            if split_cnn:
+                gb1.replay()
+                sync.reduce_cnn_early(cast=False)          # grid_encoder + res5 cross xGMI while res4 / res3 run
+                gb2.replay()
+                sync.reduce_cnn(cast=False)                # the remaining middle of the CNN range
+            else:
+                gb.replay()
+                sync.reduce_cnn(cast=not wire16)
             sync.wait(cast_back=not wire16)
             gc.replay()
-        run, plan = run_split, "three hipGraphs, eager bucketed bf16 all-reduces (transformer buckets overlap the ResNet backward)"
+        run, plan = run_split, (("four" if split_cnn else "three") + " hipGraphs, eager bucketed bf16 all-reduces (transformer buckets overlap the ResNet "
+                                "backward" + ("; grid_encoder + res5 buckets leave after res5, overlapping res4 / res3" if split_cnn else "") + ")")
     log(f"replay plan: {plan}")
 
     # clock / power-state settling (untimed, before the W warm-up steps): right after process start the first replays run

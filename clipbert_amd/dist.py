@@ -104,6 +104,7 @@ class GradSync:
         self._work: List = []
         self._pending: List = []            # (start, end) ranges whose bf16 wire image must be cast back after wait()
         self._inflight: List = []           # ranges handed to _reduce since the last wait()
+        self.c_early: List = []             # set_cnn_split(): sub-ranges of the CNN range whose gradients are final early
         if comm == "native" and self.world > 1:
             assert bank.grad.is_cuda, "comm='native' needs the gradients on a GPU"
             self.native = NativeComm.from_process_group(group)
@@ -129,11 +130,44 @@ class GradSync:
         else:
             self._wire[a:b].copy_(self.bank.grad[a:b])
 
+    def set_cnn_split(self, res5_start: Optional[int]):
+        """The CNN range is [grid_encoder | res3 | res4 | res5] (the reference's parameter-group order); its two ends -- grid_encoder
+        and res5, ~3/4 of the bytes -- are final when the ResNet backward has passed res5 (modeling.cnn_backward_steps yields there).
+        ``res5_start`` = modeling.cnn_early_split(model); None switches the split off."""
+        self.c_early = []
+        if res5_start is None:
+            return
+        lo, hi = self.c_range
+        mid = self.bank.group_range[6][0]           # end of the grid_encoder groups = start of the backbone group
+        assert lo <= mid <= res5_start <= hi, (lo, mid, res5_start, hi)
+        self.c_early = [r for r in ((lo, mid), (res5_start, hi)) if r[1] > r[0]]
+
+    def _cnn_late(self):
+        """the part of the CNN range that set_cnn_split() does not declare early"""
+        out, cur = [], self.c_range[0]
+        for a, b in sorted(self.c_early):
+            if a > cur:
+                out.append((cur, a))
+            cur = max(cur, b)
+        if cur < self.c_range[1]:
+            out.append((cur, self.c_range[1]))
+        return out
+
+    def cast_cnn_early(self):
+        for a, b in self.c_early:
+            self.cast_range(a, b)
+
+    def reduce_cnn_early(self, cast: bool = True):
+        """issue the exchange of grid_encoder + res5 (call where cnn_backward_steps yields / from rt.after_res5_backward)"""
+        for a, b in self.c_early:
+            self._reduce(a, b, cast=cast)
+
     def cast_transformer(self):
         self.cast_range(*self.t_range)
 
-    def cast_cnn(self):
-        self.cast_range(*self.c_range)
+    def cast_cnn(self, late_only: bool = False):
+        for a, b in (self._cnn_late() if late_only else [self.c_range]):
+            self.cast_range(a, b)
 
     def _reduce(self, a: int, b: int, cast: bool = True):
         if self.world == 1 or b <= a:
@@ -169,7 +203,10 @@ class GradSync:
         self._reduce(*self.t_range, cast=cast)
 
     def reduce_cnn(self, cast: bool = True):
-        self._reduce(*self.c_range, cast=cast)
+        """whatever of the CNN range is not already in flight (reduce_cnn_early may have sent its two ends)"""
+        early_sent = bool(self.c_early) and all(r in self._inflight for r in self.c_early)
+        for a, b in (self._cnn_late() if early_sent else [self.c_range]):
+            self._reduce(a, b, cast=cast)
 
     def wire_gradients(self) -> Optional[torch.Tensor]:
         """The flat bf16 gradient image (valid after wait(cast_back=False) once BOTH ranges were reduced): hand it to

@@ -176,6 +176,9 @@ class Runtime:
         self.after_encoder_backward = None               # hook: launch the transformer-bucket all-reduce
         self.pending_encoder_nodes = 0                   # encoder autograd nodes created and not yet run backward: the hook
                                                          # fires when the LAST of them finished (multi-clip loops run several)
+        self.after_res5_backward = None                  # hook: every gradient of grid_encoder + res5 is enqueued (fires inside the
+                                                         # LAST ResNet backward of a step): their all-reduce can start while res4 / res3 run
+        self.pending_cnn_nodes = 0
         self.forward_count = 0                           # host counter folded into every dropout seed: each forward (each
                                                          # clip of a clip loop) draws its own masks; kept in the saved pack
         self.side_stream = None                          # second HIP stream: weight-gradient GEMMs run beside the dgrad chain
@@ -371,6 +374,20 @@ def cnn_forward(bb: "GridFeatBackbone", x5: torch.Tensor, save: bool):
 
 
 def cnn_backward(bb: "GridFeatBackbone", saved_pack, dgrid: torch.Tensor):
+    """the whole ResNet backward; rt.after_res5_backward (if set) is called at the point cnn_backward_steps yields, when this is the
+    last pending ResNet backward of the step"""
+    rt = bb.rt
+    for _ in cnn_backward_steps(bb, saved_pack, dgrid):
+        hook = rt.after_res5_backward
+        if hook is not None and rt.pending_cnn_nodes <= 1:
+            hook()
+
+
+def cnn_backward_steps(bb: "GridFeatBackbone", saved_pack, dgrid: torch.Tensor):
+    """Generator over the ResNet backward.  Yields ONCE, when every launch that writes a gradient of grid_encoder or res5 (the tail
+    of the CNN range of the flat gradient buffer, and ~3/4 of its bytes) has been enqueued and earlier stages remain: a
+    data-parallel caller starts that part of the exchange there (hook above, or between two captured graphs: bench.py).  Exhausting
+    it without looking at the yield is the plain backward."""
     rt = bb.rt
     saved, res5, gy, grid = saved_pack
     gconv = bb.grid_encoder[0]
@@ -380,6 +397,9 @@ def cnn_backward(bb: "GridFeatBackbone", saved_pack, dgrid: torch.Tensor):
     if not saved:
         rt.join()
         return
+    res5_ids = {id(b) for b in bb.feature.backbone.res5}
+    first_res5 = min((i for i, rec in enumerate(saved) if id(rec[0]) in res5_ids), default=None)
+
     def fuse_spec(i):
         """the ReLU x FrozenBN-scale backward of block i, done by the launch that produces d(output of block i)"""
         b, _x, _y1, _y2, o = saved[i]
@@ -405,6 +425,9 @@ def cnn_backward(bb: "GridFeatBackbone", saved_pack, dgrid: torch.Tensor):
         g1 = _conv_dgrad(rt, g2, blk.conv2, y1.shape, scale=s1, mask=y1)
         with rt.side(g1, x):
             _conv_wgrad(rt, g1, x, blk.conv1)
+        if idx == first_res5 and idx > 0:
+            rt.join()
+            yield "grid_encoder+res5"
         if need_dx:
             spec = fuse_spec(idx - 1)
             if blk.shortcut is None:
@@ -421,6 +444,8 @@ class _CnnFn(torch.autograd.Function):
         save = ctx.needs_input_grad[0] and bb.has_trainable()    # anchor: True iff autograd is recording
         grid, pack = cnn_forward(bb, x5, save)
         ctx.bb, ctx.pack = bb, pack
+        if pack is not None:
+            bb.rt.pending_cnn_nodes += 1
         return grid
 
     @staticmethod
@@ -428,6 +453,7 @@ class _CnnFn(torch.autograd.Function):
         if ctx.pack is not None:
             cnn_backward(ctx.bb, ctx.pack, dgrid.contiguous())
             ctx.pack = None
+            ctx.bb.rt.pending_cnn_nodes = max(0, ctx.bb.rt.pending_cnn_nodes - 1)
         return None, None, None
 
 
@@ -1360,6 +1386,22 @@ class ClipBert(nn.Module):
             p.requires_grad = False
         if self.rt is not None:
             self.prepare(dtype=self.rt.dtype, device=self.rt.bank.device)
+
+
+def cnn_early_split(model: "ClipBert") -> Optional[int]:
+    """Element offset in the flat gradient buffer where res5's parameters start (they are the tail of the CNN range: same module
+    order as the reference's parameter groups); None when res5 is frozen or not contiguous at the end.  GradSync.set_cnn_split."""
+    bank = model.rt.bank
+    ps = [p for p in model.cnn.feature.backbone.res5.parameters() if bank.is_trainable(p)]
+    if not ps:
+        return None
+    start = min(bank.offset[id(p)] for p in ps)
+    g6 = bank.group_range[6]
+    others = [bank.offset[id(p)] for n, p in model.cnn.feature.backbone.named_parameters()
+              if bank.is_trainable(p) and not n.startswith("res5.")]
+    if not (g6[0] <= start < g6[1]) or any(o >= start for o in others):
+        return None
+    return start
 
 
 def load_state_dict_with_mismatch(model: nn.Module, loaded_state_dict_or_path) -> int:

@@ -111,23 +111,27 @@ def train_step(model, optimizer, batch: Dict, cfg, global_step: int, sync=None, 
     all-reduce (``sync`` = clipbert_amd.dist.GradSync or None), the LR schedule and clip + AdamW.  Gradients of the
     micro-steps add up un-scaled, as in the reference; the exchange happens once per group (the sum is linear).
 
-    With ``sync.overlap`` the transformer buckets are issued from inside the LAST encoder backward of the group (the model
-    counts its pending encoder nodes, so an un-folded clip loop does not fire early) and travel during the ResNet backward."""
+    With ``rt.after_encoder_backward = sync.reduce_transformer`` the transformer buckets are issued from inside the LAST encoder
+    backward of the group (the model counts its pending encoder nodes, so an un-folded clip loop does not fire early) and travel
+    during the ResNet backward; with ``rt.after_res5_backward = sync.reduce_cnn_early`` (after ``sync.set_cnn_split``) the
+    grid_encoder + res5 part of the CNN range follows from inside the last ResNet backward, while res4 / res3 still run."""
     acc = max(1, int(_get(cfg, "gradient_accumulation_steps", 1) or 1))
     first, last = micro_step % acc == 0, (micro_step + 1) % acc == 0
     if first:
         optimizer.zero_grad(lazy=True)                      # a backward always follows: the encoder weight gradients are overwritten
     rt = model.rt
     rt.pending_encoder_nodes = 0
-    hook = rt.after_encoder_backward
+    rt.pending_cnn_nodes = 0
+    hook, hook5 = rt.after_encoder_backward, rt.after_res5_backward
     if not last:
         rt.after_encoder_backward = None                    # no exchange before the group is complete
+        rt.after_res5_backward = None
     try:
         stack = forward_clips_stack(model, batch, _get(cfg, "train_n_clips", 1), _get(cfg, "num_frm"), fold=fold_clips, cfg=cfg)
         loss = training_loss(model, stack, batch["labels"], batch["n_examples_list"], _get(cfg, "score_agg_func", "mean"))
         loss.backward()
     finally:
-        rt.after_encoder_backward = hook
+        rt.after_encoder_backward, rt.after_res5_backward = hook, hook5
     if not last:
         return loss.detach()
     scale, g16 = 1.0, None

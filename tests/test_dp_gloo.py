@@ -48,12 +48,18 @@ def _train_one_step(rank, world, out_path, compress=None):
     bank = model.rt.bank
     sync = GradSync(bank, compress="bf16" if compress == "bf16direct" else compress)
     sync.broadcast_parameters(0)
-    calls = []
+    calls, calls5 = [], []
     model.rt.after_encoder_backward = lambda: (calls.append(1), sync.reduce_transformer())
+    # the two ends of the CNN range (grid_encoder, res5) leave from inside the ResNet backward, the middle after it
+    from clipbert_amd import modeling as M
+    sync.set_cnn_split(M.cnn_early_split(model))
+    assert len(sync.c_early) == 2 and sync._cnn_late()
+    model.rt.after_res5_backward = lambda: (calls5.append(1), sync.reduce_cnn_early())
     opt = FusedAdamW(bank, lr=1e-3, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0)
     opt.zero_grad()
     out = model(batch)
     out["loss"].mean().backward()
+    assert calls5 == [1]
     sync.reduce_cnn()
     g16 = sync.wire_gradients() if compress == "bf16direct" else None     # the optimizer reads the reduced bf16 image itself
     sync.wait(cast_back=g16 is None)
@@ -82,8 +88,11 @@ def _train_multi_clip_accumulated(rank, world, out_path, compress=None):
     bank = model.rt.bank
     sync = GradSync(bank, compress=compress, bucket_bytes=1 << 16)       # several buckets per range
     sync.broadcast_parameters(0)
-    calls = []
+    calls, calls5 = [], []
     model.rt.after_encoder_backward = lambda: (calls.append(1), sync.reduce_transformer())
+    from clipbert_amd import modeling as M
+    sync.set_cnn_split(M.cnn_early_split(model))
+    model.rt.after_res5_backward = lambda: (calls5.append(1), sync.reduce_cnn_early())
     opt = FusedAdamW(bank, lr=1e-3, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0)
     tcfg = SimpleNamespace(train_n_clips=2, num_frm=2, score_agg_func="lse", gradient_accumulation_steps=2, learning_rate=1e-3,
                            cnn_learning_rate=1e-3, decay="constant", cnn_lr_decay="constant", num_train_steps=10, warmup_ratio=0.0)
@@ -94,6 +103,7 @@ def _train_multi_clip_accumulated(rank, world, out_path, compress=None):
                      text_input_mask=full["text_input_mask"][idx].contiguous(), n_examples_list=[1] * per, labels=full["labels"][idx])
         tasks.train_step(model, opt, batch, tcfg, global_step=0, sync=sync, micro_step=micro, fold_clips=False)
     assert calls == [1], calls               # one exchange: last encoder backward of the last micro-step
+    assert calls5 == [1], calls5             # ... and the early CNN part once, from the last ResNet backward of the last micro-step
     if rank == 0:
         torch.save(dict(master=bank.master.clone(), norm=opt.grad_norm()), out_path)
 

@@ -105,6 +105,7 @@ class GradSync:
         self._pending: List = []            # (start, end) ranges whose bf16 wire image must be cast back after wait()
         self._inflight: List = []           # ranges handed to _reduce since the last wait()
         self.c_early: List = []             # set_cnn_split(): sub-ranges of the CNN range whose gradients are final early
+        self.late_ranges = 0                # ranges wait() had to send itself because nobody reduced them (diagnostic)
         if comm == "native" and self.world > 1:
             assert bank.grad.is_cuda, "comm='native' needs the gradients on a GPU"
             self.native = NativeComm.from_process_group(group)
@@ -188,6 +189,17 @@ class GradSync:
             else:
                 self._work.append(self._all_reduce(self.bank.grad[s:e]))
 
+    def _uncovered(self):
+        """parts of [0, n_train) not handed to _reduce since the last wait()"""
+        out, cur = [], 0
+        for a, b in sorted(self._inflight):
+            if a > cur:
+                out.append((cur, a))
+            cur = max(cur, b)
+        if cur < self.bank.n_train:
+            out.append((cur, self.bank.n_train))
+        return out
+
     def _all_reduce(self, t: torch.Tensor):
         if self.dry:
             return None
@@ -216,6 +228,12 @@ class GradSync:
     def wait(self, cast_back: bool = True):
         """cast_back=False (bf16 wire only): leave the reduced gradients in the wire buffer for an optimizer that reads bf16
         (wire_gradients()); bank.grad then still holds THIS rank's un-reduced fp32 gradients."""
+        # safety net: a hook that did not fire (e.g. a forward whose backward never ran left a pending-node count behind) must not
+        # leave part of the gradient buffer un-exchanged -- whatever is missing goes out now, late but correct
+        if self._inflight and self.world > 1:
+            for a, b in self._uncovered():
+                self.late_ranges += 1
+                self._reduce(a, b)
         for w in self._work:
             if w is not None:
                 w.wait()

@@ -56,3 +56,38 @@ def test_single_rank_sync_is_a_no_op():
     assert sync.world == 1 and not sync.dry and sync.wire_gradients() is None
     sync.reduce_transformer(); sync.reduce_cnn(); sync.wait()
     assert float(bank.grad.min()) == 1.0
+
+
+def test_wait_sends_whatever_was_forgotten():
+    """a hook that never fired must not leave a range un-exchanged: wait() reduces the uncovered parts itself"""
+    bank = _toy_bank()
+    bank.grad.normal_(generator=torch.Generator().manual_seed(1))
+    g0 = bank.grad.clone()
+    sync = GradSync(bank, compress="bf16", pretend_world=2)
+    sync.reduce_cnn()                                     # the transformer hook "did not fire"
+    assert sync._uncovered() == [sync.t_range]
+    sync.wait()
+    assert sync.late_ranges == 1
+    torch.testing.assert_close(bank.grad[:bank.n_train], g0[:bank.n_train].bfloat16().float(), rtol=0, atol=0)   # every range went through the wire
+    sync.wait()                                           # nothing in flight: nothing to do, no new late range
+    assert sync.late_ranges == 1
+
+
+def test_cnn_range_in_two_parts():
+    bank = _toy_bank()
+    sync = GradSync(bank, compress=None, pretend_world=2)
+    lo, hi = sync.c_range
+    mid = bank.group_range[6][0]
+    split = mid + (hi - mid) // 2 // 64 * 64
+    sync.set_cnn_split(split)
+    assert sync.c_early == [r for r in ((lo, mid), (split, hi)) if r[1] > r[0]] and sync._cnn_late() == [(mid, split)]
+    sync.reduce_transformer()
+    sync.reduce_cnn_early()
+    sync.reduce_cnn()                                     # only the middle is left
+    assert sorted(sync._inflight) == sorted([sync.t_range] + sync.c_early + [(mid, split)]) and not sync._uncovered()
+    sync.wait()
+    assert sync.late_ranges == 0
+    sync.reduce_transformer()
+    sync.reduce_cnn()                                     # early part not sent this step: the whole CNN range at once
+    assert sync.c_range in sync._inflight
+    sync.wait()

@@ -176,6 +176,26 @@ def test_backward_cut_at_grid_features(hw):
     torch.testing.assert_close(bank.grad, ref, rtol=1e-5, atol=1e-7)
     t_end = bank.group_range[3][1]
     assert enc_only[t_end:].abs().max() == 0 and (bank.grad[t_end:].abs().max() > 0)      # the CNN part came from phase two
+    # ... and the ResNet backward itself in two steps (bench.py's four-graph plan drives modeling.cnn_backward_steps by hand): at
+    # its single yield every gradient of grid_encoder and res5 is FINAL -- the data-parallel exchange of those ranges may start --
+    # while res3 / res4 have not been touched yet
+    bank.zero_grad()
+    b = to_dev(dict(batch, n_examples_list=[2, 2]), hw.dev)
+    grid = model.grid_features(b["visual_inputs"])
+    b["visual_inputs"] = grid
+    out = model.forward_from_grid(b)
+    (dgrid,) = torch.autograd.grad(out["loss"].mean(), [grid])
+    node = grid.grad_fn
+    steps = M.cnn_backward_steps(node.bb, node.pack, dgrid.contiguous())
+    assert next(steps) == "grid_encoder+res5"
+    split = M.cnn_early_split(model)
+    mid = bank.group_range[6][0]
+    assert t_end < mid < split < bank.n_train
+    torch.testing.assert_close(bank.grad[t_end:mid], ref[t_end:mid], rtol=1e-5, atol=1e-7)          # grid_encoder
+    torch.testing.assert_close(bank.grad[split:], ref[split:], rtol=1e-5, atol=1e-7)              # res5
+    assert bank.grad[mid:split].abs().max() == 0 and ref[mid:split].abs().max() > 0                # res3 + res4: still to come
+    assert next(steps, None) is None
+    torch.testing.assert_close(bank.grad, ref, rtol=1e-5, atol=1e-7)
 
 
 def test_uint8_frames_equal_prenormalised_input(hw):

@@ -143,6 +143,17 @@ class GradSync:
         assert lo <= mid <= res5_start <= hi, (lo, mid, res5_start, hi)
         self.c_early = [r for r in ((lo, mid), (res5_start, hi)) if r[1] > r[0]]
 
+    def attach(self, model):
+        """Arm the overlap hooks of a prepared ClipBert: the transformer buckets leave from the end of the last encoder backward of a
+        step, grid_encoder + res5 from inside the last ResNet backward (what INTEGRATION.md spells out line by line)."""
+        from .modeling import cnn_early_split
+        rt = model.rt
+        assert rt is not None and rt.bank is self.bank, "GradSync.attach: the model is not prepared on this sync's parameter bank"
+        rt.after_encoder_backward = self.reduce_transformer
+        self.set_cnn_split(cnn_early_split(model))
+        rt.after_res5_backward = self.reduce_cnn_early if self.c_early else None
+        return self
+
     def _cnn_late(self):
         """the part of the CNN range that set_cnn_split() does not declare early"""
         out, cur = [], self.c_range[0]

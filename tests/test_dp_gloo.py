@@ -49,12 +49,13 @@ def _train_one_step(rank, world, out_path, compress=None):
     sync = GradSync(bank, compress="bf16" if compress == "bf16direct" else compress)
     sync.broadcast_parameters(0)
     calls, calls5 = [], []
-    model.rt.after_encoder_backward = lambda: (calls.append(1), sync.reduce_transformer())
-    # the two ends of the CNN range (grid_encoder, res5) leave from inside the ResNet backward, the middle after it
-    from clipbert_amd import modeling as M
-    sync.set_cnn_split(M.cnn_early_split(model))
+    # attach(): transformer buckets from the end of the encoder backward; the two ends of the CNN range (grid_encoder, res5) from
+    # inside the ResNet backward, the middle after it.  (wrapped here only to count the calls)
+    sync.attach(model)
     assert len(sync.c_early) == 2 and sync._cnn_late()
-    model.rt.after_res5_backward = lambda: (calls5.append(1), sync.reduce_cnn_early())
+    h_enc, h_r5 = model.rt.after_encoder_backward, model.rt.after_res5_backward
+    model.rt.after_encoder_backward = lambda: (calls.append(1), h_enc())
+    model.rt.after_res5_backward = lambda: (calls5.append(1), h_r5())
     opt = FusedAdamW(bank, lr=1e-3, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0)
     opt.zero_grad()
     out = model(batch)

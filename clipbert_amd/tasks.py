@@ -187,13 +187,16 @@ def validate_retrieval(model, val_loader, eval_videos, cfg, gt_txt_id2vid_id=Non
 
 
 def start_training(model, optimizer, train_loader, cfg, sync=None, validate_fn=None, model_saver=None, restorer=None,
-                   total_n_examples: Optional[int] = None, fold_clips: bool = True, log_fn=None) -> int:
+                   total_n_examples: Optional[int] = None, fold_clips: bool = True, log_fn=None, overlap: bool = True) -> int:
     """The loop of start_training (run_video_retrieval.py:379-516 / run_video_qa.py:457-560) around train_step: infinite
     iteration over ``train_loader`` until cfg.num_train_steps optimizer steps, gradient accumulation, LR schedules with the
     multi-step epoch counter, validation + ``model_step_N.pt`` every cfg.valid_steps (and once at the end), restorer.step()
     after every optimizer step.  ``train_loader`` yields collated batches (clipbert_amd.data.PrefetchLoader delivers them with
-    uint8 frames already in HBM).  Returns the final global step."""
+    uint8 frames already in HBM).  With several ranks and ``overlap`` the gradient exchange is armed to leave from inside the
+    backward (GradSync.attach).  Returns the final global step."""
     from .data import InfiniteIterator
+    if sync is not None and sync.world > 1 and overlap and model.rt is not None and model.rt.after_encoder_backward is None:
+        sync.attach(model)
     acc = max(1, int(_get(cfg, "gradient_accumulation_steps", 1) or 1))
     global_step = restorer.global_step if restorer is not None else 0
     num_train_steps, valid_steps = int(_get(cfg, "num_train_steps")), int(_get(cfg, "valid_steps", 0) or 0)

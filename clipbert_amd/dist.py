@@ -45,6 +45,9 @@ class NativeComm:
     def from_process_group(cls, group=None) -> "NativeComm":
         """every rank calls this with its GPU current (torch.cuda.set_device)"""
         if cls._instance is not None:
+            if dist.is_initialized():
+                assert (cls._instance.rank, cls._instance.world) == (dist.get_rank(group), dist.get_world_size(group)), \
+                    "NativeComm: one communicator per process -- destroy() it before creating one for another group"
             return cls._instance
         if dist.is_initialized():
             rank, world = dist.get_rank(group), dist.get_world_size(group)

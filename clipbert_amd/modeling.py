@@ -179,6 +179,7 @@ class Runtime:
         self.after_res5_backward = None                  # hook: every gradient of grid_encoder + res5 is enqueued (fires inside the
                                                          # LAST ResNet backward of a step): their all-reduce can start while res4 / res3 run
         self.pending_cnn_nodes = 0
+        self._ln_off = None                              # (bank, offsets of the encoder LayerNorm gradients): cache of _ln_offsets
         self.forward_count = 0                           # host counter folded into every dropout seed: each forward (each
                                                          # clip of a clip loop) draws its own masks; kept in the saved pack
         self.side_stream = None                          # second HIP stream: weight-gradient GEMMs run beside the dgrad chain
@@ -775,7 +776,7 @@ def _ln_offsets(model, dev):
     """(2, 2*n_layers) int64 device tensor: element offsets of the encoder LayerNorms' (weight | bias) gradients in bank.grad, in
     the slot order encoder_backward uses (2*l: attention.output.LayerNorm, 2*l+1: output.LayerNorm); None if any is frozen."""
     rt = model.rt
-    cached = getattr(rt, "_ln_off", None)
+    cached = rt._ln_off
     if cached is not None and cached[0] is rt.bank:
         return cached[1]
     bank, offs = rt.bank, ([], [])

@@ -284,7 +284,8 @@ int cb_version(void);
  * on its GPU (the calling thread's current HIP device); one communicator per process.  cb_allreduce_bucket: in-place SUM of
  * `count` elements (CB_F32 or CB_BF16: the flat gradient buffer or its bf16 wire image) over all ranks, enqueued on
  * `stream` -- asynchronous, ordered against other streams by HIP events, capturable into a hipGraph.  RCCL is loaded at
- * run time (librccl.so.1); without it these calls fail with a message and everything else works. */
+ * run time (librccl.so.1); without it these calls fail with a message and everything else works.  The communicator is process-
+ * global state: call cb_comm_* from one host thread (the one that owns the GPU), as the rest of the ABI is used. */
 int cb_comm_unique_id(void* id128);
 int cb_comm_init(int32_t rank, int32_t world, const void* id128);
 int cb_comm_info(int32_t* rank, int32_t* world);

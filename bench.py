@@ -304,7 +304,7 @@ def main():
         return g, out
 
     plan_env = os.environ.get("CB_BENCH_PLAN", "")
-    run, plan = eager_fn, "eager"
+    run, plan, n_graphs = eager_fn, "eager", 0
     use_graph = not args.no_graph and plan_env != "eager"
     if use_graph and args.mode == "infer16":
         g1, _ = capture(infer_device_step)
@@ -313,17 +313,17 @@ def main():
             g1.replay()
             sc = [round(x, 4) for x in state["scores"].tolist()]           # D2H of the 64 scores: the step's result
             infer_rows.extend(dict(vid_id=f"r{rank}v{len(infer_rows) // rep}", txt_id=j, score=x) for j, x in enumerate(sc))
-        run, plan = run_infer, "one hipGraph per (video, caption mini-batch) + score read-back"
+        run, plan, n_graphs = run_infer, "one hipGraph per (video, caption mini-batch) + score read-back", 1
     elif use_graph and not train:
         g1, loss = capture(forward_only_step)
-        run, plan = g1.replay, "one hipGraph"
+        run, plan, n_graphs = g1.replay, "one hipGraph", 1
     elif use_graph and world == 1 and not (train and sync.dry):
         g1, loss = capture(device_step_chains if chains > 1 else device_step_single)
 
         def run_single():
             host_prepare()
             g1.replay()
-        run, plan = run_single, "eager hyper-parameter upload + one hipGraph"
+        run, plan, n_graphs = run_single, "eager hyper-parameter upload + one hipGraph", 1
     elif use_graph:
         # The backward is cut at the grid features: autograd.grad(loss, grid) runs the heads' and the encoder's backward
         # (parameter gradients land in the flat buffer as a side effect), grid.backward(dgrid) runs the CNN trunk's.
@@ -396,6 +396,7 @@ def main():
                 sync.reduce_cnn(cast=not wire16)
             sync.wait(cast_back=not wire16)
             gc.replay()
+        n_graphs = 4 if split_cnn else 3
         run, plan = run_split, (("four" if split_cnn else "three") + " hipGraphs, eager bucketed bf16 all-reduces (transformer buckets overlap the ResNet "
                                 "backward" + ("; grid_encoder + res5 buckets leave after res5, overlapping res4 / res3" if split_cnn else "") + ")")
     log(f"replay plan: {plan}")
@@ -462,7 +463,7 @@ def main():
         "config": {"workload": workload, "mode": args.mode, "videos_per_gpu": bv, "n_clips": nclip, "n_frames": T, "img_size": args.size,
                    "txt_len": args.txt_len, "texts_per_video": rep, "pairs_per_gpu": pairs, "score_agg_func": args.pool, "clips_folded": fold,
                    "input": "uint8 frames in HBM",
-                   "parallelism": f"dp{world}" + (f" (DRY RUN of the dp{sync.world} plan on one GPU: no collectives)" if (train and sync is not None and sync.dry) else ""), "hip_graph": use_graph, "replay_plan": plan,
+                   "parallelism": f"dp{world}" + (f" (DRY RUN of the dp{sync.world} plan on one GPU: no collectives)" if (train and sync is not None and sync.dry) else ""), "hip_graph": use_graph, "replay_plan": plan, "n_graphs": n_graphs,
                    "dropout": bool(train), "final_loss": None if final_loss is None else round(final_loss, 5)},
     }
     if dp_check is not None:

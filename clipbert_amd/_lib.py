@@ -100,6 +100,7 @@ def load(path: str = LIB_PATH):
         raise RuntimeError(
             f"{path} not found: the HIP library is required (no fallback path exists). "
             "Build it with `python -m clipbert_amd.build`.")
+    import torch  # noqa: F401  (its bundled HIP runtime must be loaded FIRST: the library then binds the same libamdhip64)
     return bind(C.CDLL(path))
 
 

@@ -10,7 +10,13 @@
   torchvision ResNet-50 state dict (renamed as convert_torchvision_ckpt_to_detectron2 does, load_save.py:315-363).
 
 Host code only; weights land in the fp32 masters of the parameter bank and the bf16 compute copies are refreshed by the
-model's load_state_dict hook."""
+model's load_state_dict hook.
+
+Ranks (the reference: restore on EVERY rank, then saver / restorer replaced by NoOp on ranks != 0, run_video_retrieval.py:
+329-346): build ``ModelSaver`` and ``E2E_TrainingRestorer`` on every rank; both write on rank 0 only, the restorer reads on
+all ranks.  File formats: ``model_step_N.pt`` is interchangeable with the reference; ``*_train_state.pt`` / ``restore.pt``
+hold clipbert_amd.optim.FusedAdamW's own state dict (moments keyed by parameter NAME) plus the dropout counters of the
+runtime -- not loadable by the reference's AdamW, and vice versa."""
 import os
 import pickle
 from typing import Any, Dict, Optional
@@ -86,6 +92,11 @@ def load_detectron2_backbone(cnn, path_or_state) -> int:
     return len(ok)
 
 
+def _rank() -> int:
+    import torch.distributed as dist
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
 def _cpu(obj):
     if torch.is_tensor(obj):
         return obj.detach().cpu()
@@ -98,12 +109,16 @@ def _cpu(obj):
 
 class ModelSaver:
     """src/utils/load_save.py:43-68: ``{prefix}_step_{step}.pt`` (+ ``_train_state.pt`` with the optimizer)."""
-    def __init__(self, output_dir: str):
+    def __init__(self, output_dir: str, rank: Optional[int] = None):
         self.output_dir = output_dir
-        os.makedirs(output_dir, exist_ok=True)
+        self.rank = _rank() if rank is None else rank          # every rank may hold one: only rank 0 writes
+        if self.rank == 0:
+            os.makedirs(output_dir, exist_ok=True)
 
-    def save(self, step: int, model, optimizer=None, prefix: str = "model") -> str:
+    def save(self, step: int, model, optimizer=None, prefix: str = "model") -> Optional[str]:
         model_path = os.path.join(self.output_dir, f"{prefix}_step_{step}.pt")
+        if self.rank != 0:
+            return None
         # contiguous OIHW copies: the file must not depend on our channels_last memory image
         sd = {k: (v.detach().cpu().contiguous() if torch.is_tensor(v) else v) for k, v in model.state_dict().items()}
         torch.save(sd, model_path)
@@ -116,10 +131,12 @@ class ModelSaver:
 class E2E_TrainingRestorer:
     """src/utils/load_save.py:245-312: ``restore.pt`` (+ ``restore_backup.pt``) with global step, model and optimizer;
     resumes if one exists.  ``opts`` needs output_dir, num_train_steps, save_steps_ratio."""
-    def __init__(self, opts, model, optimizer):
+    def __init__(self, opts, model, optimizer, rank: Optional[int] = None):
         get = (lambda k, d=None: opts.get(k, d)) if isinstance(opts, dict) else (lambda k, d=None: getattr(opts, k, d))
         out = get("output_dir")
-        os.makedirs(out, exist_ok=True)
+        self.rank = _rank() if rank is None else rank          # restore() runs on every rank, save() on rank 0 only
+        if self.rank == 0:
+            os.makedirs(out, exist_ok=True)
         self.save_path = os.path.join(out, "restore.pt")
         self.backup_path = os.path.join(out, "restore_backup.pt")
         self.model, self.optimizer = model, optimizer
@@ -134,8 +151,14 @@ class E2E_TrainingRestorer:
             self.save()
 
     def save(self):
+        if self.rank != 0:
+            return
         ckpt = {"global_step": self.global_step, "model_state_dict": _cpu(self.model.state_dict()),
                 "optim_state_dict": _cpu(self.optimizer.state_dict())}
+        rt = getattr(self.model, "rt", None)
+        if rt is not None:                      # dropout masks are a function of these two counters: a resumed run continues the sequence
+            ckpt["dropout_state"] = {"forward_count": int(rt.forward_count),
+                                     "seed_dev": int(rt.seed_dev.item()) if rt.seed_dev is not None else 0}
         if os.path.exists(self.save_path):
             os.replace(self.save_path, self.backup_path)
         torch.save(ckpt, self.save_path)
@@ -148,3 +171,8 @@ class E2E_TrainingRestorer:
         self.global_step = ckpt["global_step"]
         self.model.load_state_dict(ckpt["model_state_dict"])
         self.optimizer.load_state_dict(ckpt["optim_state_dict"])
+        rt, ds = getattr(self.model, "rt", None), ckpt.get("dropout_state")
+        if rt is not None and ds is not None:
+            rt.forward_count = int(ds["forward_count"])
+            if rt.seed_dev is not None:
+                rt.seed_dev.fill_(int(ds["seed_dev"]))

@@ -109,6 +109,7 @@ class GradSync:
         self._inflight: List = []           # ranges handed to _reduce since the last wait()
         self.c_early: List = []             # set_cnn_split(): sub-ranges of the CNN range whose gradients are final early
         self.late_ranges = 0                # ranges wait() had to send itself because nobody reduced them (diagnostic)
+        self._epoch_done = getattr(bank, "grad_epoch", 0)    # bank.grad_epoch (one per zero_grad) of the last completed exchange
         if comm == "native" and self.world > 1:
             assert bank.grad.is_cuda, "comm='native' needs the gradients on a GPU"
             self.native = NativeComm.from_process_group(group)
@@ -244,10 +245,14 @@ class GradSync:
         (wire_gradients()); bank.grad then still holds THIS rank's un-reduced fp32 gradients."""
         # safety net: a hook that did not fire (e.g. a forward whose backward never ran left a pending-node count behind) must not
         # leave part of the gradient buffer un-exchanged -- whatever is missing goes out now, late but correct
-        if self._inflight and self.world > 1:
+        # -- including a step for which NO reduce_* was called at all (hooks not armed, caller forgot): the gradient epoch of the
+        # bank (one per zero_grad) tells that case from a repeated wait() with nothing left to do
+        epoch = getattr(self.bank, "grad_epoch", 0)
+        if self.world > 1 and (self._inflight or epoch != self._epoch_done):
             for a, b in self._uncovered():
                 self.late_ranges += 1
                 self._reduce(a, b)
+        self._epoch_done = epoch
         for w in self._work:
             if w is not None:
                 w.wait()

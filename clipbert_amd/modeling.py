@@ -179,6 +179,7 @@ class Runtime:
         self.after_res5_backward = None                  # hook: every gradient of grid_encoder + res5 is enqueued (fires inside the
                                                          # LAST ResNet backward of a step): their all-reduce can start while res4 / res3 run
         self.pending_cnn_nodes = 0
+        self.prepare_args = None                         # keyword arguments of the prepare() call that built this runtime
         self._ln_off = None                              # (bank, offsets of the encoder LayerNorm gradients): cache of _ln_offsets
         self.forward_count = 0                           # host counter folded into every dropout seed: each forward (each
                                                          # clip of a clip loop) draws its own masks; kept in the saved pack
@@ -1270,7 +1271,8 @@ class ClipBert(nn.Module):
         # nn.Module.load_state_dict copies into the fp32 master views of a prepared model: everything derived from them
         # (bf16 compute copies, folded FrozenBN vectors, packed stem filter) is refreshed afterwards -- also when only
         # a sub-module is loaded (load_state_dict_with_mismatch(model.transformer, ...), load_separate_ckpt)
-        for mod in (self, self.cnn, self.transformer):
+        # (post-hooks fire for the module load_state_dict was CALLED on only: cnn.feature is what load_detectron2_backbone loads)
+        for mod in (self, self.cnn, self.cnn.feature, self.transformer, self.transformer.bert):
             mod.register_load_state_dict_post_hook(lambda _m, _keys, owner=self: owner.refresh_compute())
 
     def refresh_compute(self):
@@ -1293,6 +1295,9 @@ class ClipBert(nn.Module):
                 buf_owner.to(device)
         rt = Runtime()
         rt.dtype = dtype
+        # re-preparing (freeze_cnn_backbone on a prepared model) must rebuild the SAME parameter-group layout
+        rt.prepare_args = dict(dtype=dtype, device=device, transformer_lr_mul_prefix=transformer_lr_mul_prefix,
+                               cnn_lr_mul_prefix=cnn_lr_mul_prefix, overlap_wgrad=overlap_wgrad)
         rt.bank = ParamBank(self, device, dtype, transformer_lr_mul_prefix, cnn_lr_mul_prefix)
         rt.seed_dev = torch.zeros(1, dtype=torch.int64, device=device)
         rt.anchor = torch.zeros(1, dtype=torch.float32, device=device, requires_grad=True)
@@ -1376,6 +1381,7 @@ class ClipBert(nn.Module):
             n = load_state_dict_with_mismatch(self.transformer, bert_weights_path)
             if n == 0:
                 raise RuntimeError(f"{bert_weights_path}: no key of the checkpoint matches {type(self.transformer).__name__}")
+        self.refresh_compute()                  # (the load hooks already did it; kept explicit: masters -> compute copies)
 
     def freeze_cnn_backbone(self):
         """e2e_model.py:49-51.  Changes which parameters are trainable, i.e. the layout of the flat buffers: call it
@@ -1386,7 +1392,7 @@ class ClipBert(nn.Module):
         for _n, p in self.cnn.feature.named_parameters():
             p.requires_grad = False
         if self.rt is not None:
-            self.prepare(dtype=self.rt.dtype, device=self.rt.bank.device)
+            self.prepare(**self.rt.prepare_args)
 
 
 def cnn_early_split(model: "ClipBert") -> Optional[int]:

@@ -186,7 +186,8 @@ class ParamBank:
     def zero_grad(self, lazy: bool = False):
         """lazy=True: the caller guarantees that a full backward follows before the gradients are read; the lazy span (see
         set_lazy_span) is then left as it is and marked fresh -- its producer stores instead of accumulating."""
-        span = getattr(self, "lazy_span", None)
+        self.grad_epoch = getattr(self, "grad_epoch", 0) + 1       # one per gradient group: GradSync.wait() tells a repeated wait()
+        span = getattr(self, "lazy_span", None)                   # (nothing to do) from a step whose exchange was never issued
         if lazy and span is not None:
             a, b = span
             if a > 0:

@@ -147,6 +147,15 @@ def train_step(model, optimizer, batch: Dict, cfg, global_step: int, sync=None, 
     return loss.detach()
 
 
+def _all_gather_scalar(x, group=None) -> list:
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [x]
+    parts = [None] * dist.get_world_size(group)
+    dist.all_gather_object(parts, x, group=group)
+    return parts
+
+
 def _all_sum(x: float, group=None) -> float:
     """sum of a host scalar over the ranks (the reference's sum(all_gather_list(x)), :254-256)"""
     import torch.distributed as dist
@@ -193,12 +202,24 @@ def start_training(model, optimizer, train_loader, cfg, sync=None, validate_fn=N
     multi-step epoch counter, validation + ``model_step_N.pt`` every cfg.valid_steps (and once at the end), restorer.step()
     after every optimizer step.  ``train_loader`` yields collated batches (clipbert_amd.data.PrefetchLoader delivers them with
     uint8 frames already in HBM).  With several ranks and ``overlap`` the gradient exchange is armed to leave from inside the
-    backward (GradSync.attach).  Returns the final global step."""
+    backward (GradSync.attach).  Returns the final global step.
+
+    Ranks: pass ``model_saver`` / ``restorer`` on EVERY rank (clipbert_amd.checkpoint: both write on rank 0 only, the restorer
+    restores on all ranks -- the reference's order, run_video_retrieval.py:329-346).  All ranks must run the same number of
+    optimizer steps: the resumed global step is agreed on across the ranks (max), and when the ranks did not all restore the
+    same step, rank 0's parameters are broadcast again before the first step."""
     from .data import InfiniteIterator
     if sync is not None and sync.world > 1 and overlap and model.rt is not None and model.rt.after_encoder_backward is None:
         sync.attach(model)
     acc = max(1, int(_get(cfg, "gradient_accumulation_steps", 1) or 1))
     global_step = restorer.global_step if restorer is not None else 0
+    if sync is not None and sync.world > 1 and not sync.dry:
+        steps = _all_gather_scalar(global_step)
+        if len(set(steps)) > 1:                             # e.g. a restorer on rank 0 only: the others follow rank 0
+            global_step = int(max(steps))
+            if restorer is not None:
+                restorer.global_step = global_step
+            sync.broadcast_parameters(0)
     num_train_steps, valid_steps = int(_get(cfg, "num_train_steps")), int(_get(cfg, "valid_steps", 0) or 0)
     n_gpu = sync.world if sync is not None else 1
     total_bsz = n_gpu * int(_get(cfg, "train_batch_size", 1)) * acc * int(_get(cfg, "max_n_example_per_group", 1) or 1)

@@ -12,8 +12,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Collection order under `-m gpu -x`: kernel parity first, then whole-model / golden parity, then the host-logic rows on the
+# GPU, and subprocess / control-flow tests LAST -- a brittle late test must never mask the parity rows behind it.
+_ORDER = ["test_abi", "test_kernels_gemm", "test_kernels_misc", "test_gemm_fuzz", "test_model_small", "test_gpu_full", "test_parity_record",
+          "test_clips", "test_tasks", "test_checkpoint", "test_loops", "test_comm"]
+
+
+def _rank(item):
+    name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    if name.startswith("test_zz"):
+        return len(_ORDER) + 1
+    return _ORDER.index(name) if name in _ORDER else len(_ORDER)
+
+
 def pytest_collection_modifyitems(config, items):
     import torch
+    items.sort(key=_rank)                      # stable: the order inside a file is kept
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU visible")

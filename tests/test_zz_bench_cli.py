@@ -51,6 +51,6 @@ def test_two_rank_dry_run_on_one_gpu(mode):
     assert out["config"]["parallelism"] == "dp2" and out["config"]["n_clips"] == (2 if mode == "train" else 16)
     if mode == "train":
         assert out["config"]["dp_self_check"].startswith("ok"), out["config"]["dp_self_check"]
-        assert "three hipGraphs" in out["config"]["replay_plan"]
+        assert out["config"]["n_graphs"] in (1, 2, 3, 4) and out["config"]["hip_graph"] is True      # machine fields only: never prose
     else:
         assert out["config"]["rows_gathered"] == 2 * 2 * 64       # 2 ranks x 2 timed steps x 64 captions

@@ -91,3 +91,18 @@ def test_cnn_range_in_two_parts():
     sync.reduce_cnn()                                     # early part not sent this step: the whole CNN range at once
     assert sync.c_range in sync._inflight
     sync.wait()
+
+
+def test_wait_without_any_reduce_exchanges_the_whole_buffer():
+    """ADVICE r2: a step for which no reduce_* was called (hooks not armed) must not pass un-reduced gradients to the optimizer;
+    a repeated wait() in the same step stays a no-op."""
+    bank = _toy_bank()
+    sync = GradSync(bank, compress="bf16", pretend_world=2)
+    bank.zero_grad()                                      # a new gradient group begins
+    bank.grad.normal_(generator=torch.Generator().manual_seed(2))
+    g0 = bank.grad.clone()
+    sync.wait()                                           # nobody reduced anything: everything goes out late
+    assert sync.late_ranges == 1
+    torch.testing.assert_close(bank.grad[:bank.n_train], g0[:bank.n_train].bfloat16().float(), rtol=0, atol=0)
+    sync.wait()
+    assert sync.late_ranges == 1

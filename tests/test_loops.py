@@ -154,3 +154,32 @@ def test_prefetch_loader_pinned_double_buffer_gpu():
     ref = [int(b["visual_inputs"].long().sum() + b["text_input_ids"].sum()) for b in batches]
     assert [int(a) for a in acc] == ref
     assert len({k for k in loader._pinned}) == 4                        # two tensor keys x two pinned slots, reused across batches
+
+
+def test_backbone_load_after_prepare_refreshes_compute_copies(emul):
+    """load_detectron2_backbone goes through cnn.feature.load_state_dict -- the bf16 compute copies, folded FrozenBN
+    vectors and the packed stem filter of a PREPARED model must follow the new masters."""
+    cfg, sd, model = build("retrieval", RET, torch.bfloat16, CPU)
+    bank = model.rt.bank
+    own = model.cnn.feature.state_dict()
+    d2 = {"model": {k: np.full(tuple(v.shape), 0.5, dtype=np.float32) for k, v in own.items()}}
+    assert C.load_detectron2_backbone(model.cnn, d2) == len(own)
+    p = model.cnn.feature.backbone.res4[0].conv2.weight
+    assert float(p.float().mean()) == 0.5
+    assert bank.is_trainable(p)
+    off = bank.offset[id(p)]
+    torch.testing.assert_close(bank.w16[off:off + p.numel()].float(), torch.full((p.numel(),), 0.5))      # compute copy == master
+    assert model.rt.stem_w is None and all(m._ss is None for m in model.modules() if isinstance(m, M.Conv2d))
+
+
+def test_freeze_after_prepare_keeps_the_group_layout(emul):
+    """re-preparing inside freeze_cnn_backbone() reuses the arguments of the first prepare()."""
+    cfg = dict(SMALL, **RET)
+    model = M.ClipBert(cfg, detectron2_model_cfg="R-50-grid.yaml", transformer_cls=HEAD_CLS["retrieval"])
+    model.prepare(dtype=torch.float32, device=CPU, transformer_lr_mul_prefix="classifier", cnn_lr_mul_prefix="grid_encoder")
+    g0 = model.rt.bank.group_range[0]
+    assert g0[1] > g0[0]                                  # the 'new transformer' group holds the classifier
+    model.freeze_cnn_backbone()
+    assert model.rt.prepare_args["transformer_lr_mul_prefix"] == "classifier"
+    g0b = model.rt.bank.group_range[0]
+    assert g0b[1] - g0b[0] == g0[1] - g0[0]

@@ -22,14 +22,14 @@ class GemmDesc(C.Structure):
         ("dtype", i32), ("M", i32), ("N", i32), ("K", i32), ("a_mode", i32), ("b_mode", i32),
         ("A", vp), ("B", vp), ("lda", i64), ("ldb", i64), ("a_tab", vp), ("b_tab", vp),
         ("R", i32), ("S", i32), ("Cin", i32), ("H", i32), ("W", i32),
-        ("sH", i64), ("sW", i64), ("flip_taps", i32), ("reserved0", i32),
+        ("sH", i64), ("sW", i64), ("flip_taps", i32), ("schedule", i32),
         ("C", vp), ("ldc", i64), ("c_rowmap", vp), ("c_f32", i32), ("accumulate", i32),
         ("split_k", i32), ("act", i32), ("scale", vp), ("shift", vp), ("residual", vp), ("ldr", i64),
         ("relu_after", i32), ("zero_fill_pitch", i32), ("mask", vp), ("ldm", i64), ("C2", vp), ("ldc2", i64),
         ("alpha", f32), ("dropout_p", f32), ("dropout_seed", u64), ("dropout_seed_ptr", vp), ("tile", i32),
         ("xcd_order", i32), ("a_bytes", i64), ("b_bytes", i64), ("gelu_grad_pre", vp), ("ld_gelu", i64), ("a_rowsum", vp),
         ("batch", i32), ("relu_bwd", i32), ("batch_stride_a", i64), ("batch_stride_b", i64), ("batch_stride_c", i64),
-        ("batch_stride_rowsum", i64), ("post_scale", vp), ("post_scale2", vp),
+        ("batch_stride_rowsum", i64), ("post_scale", vp), ("post_scale2", vp), ("splitk_ws", vp), ("splitk_ws_bytes", i64),
     ]
 
 

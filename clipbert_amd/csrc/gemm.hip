@@ -23,7 +23,8 @@
 // * bf16: v_mfma_f32_16x16x32_bf16; fp32 parity mode: v_mfma_f32_16x16x4_f32 (exact fp32).
 // * Measured bound: L2 -> LDS bandwidth of the tile (profiles/r01_gemm_l2_analysis.md).
 
-#include "gemm_impl.h"
+#include "gemm8_impl.h"
+#include <stdio.h>
 
 using namespace cbgemm;
 
@@ -34,6 +35,15 @@ extern template int launch_gemm<bf16, 128, 128, 2>(const GP&, bool, hipStream_t)
 extern template int launch_gemm<bf16, 128, 64, 2>(const GP&, bool, hipStream_t);
 extern template int launch_gemm<bf16, 64, 64, 3>(const GP&, bool, hipStream_t);
 extern template int launch_gemm<bf16, 128, 128, 1, 2>(const GP&, bool, hipStream_t);
+// 8-wave LDS-DMA structure (gemm8_impl.h), instantiated in gemm8_inst_*.hip
+#define CB_G8_DECL(BM, BN, WGM, WGN, NST)                                                             \
+    extern template int launch_gemm8_fwd<BM, BN, WGM, WGN, NST>(const GP&, int, float*, hipStream_t);   \
+    extern template int launch_gemm8_dgrad<BM, BN, WGM, WGN, NST>(const GP&, int, float*, hipStream_t); \
+    extern template int launch_gemm8_wgrad<BM, BN, WGM, WGN, NST>(const GP&, int, float*, hipStream_t);
+CB_G8_DECL(256, 256, 2, 4, 2)
+CB_G8_DECL(128, 256, 2, 4, 3)
+CB_G8_DECL(256, 128, 4, 2, 3)
+#undef CB_G8_DECL
 }
 
 // Per-shape launch configurations measured on MI355X (tools/tune_gemm.py sweeps every cb_gemm call of the benchmark
@@ -55,6 +65,52 @@ __global__ void __launch_bounds__(256) pixel_table_kernel(cb_pixel* tab, int tot
     px.ih0 = (int16_t)ih0;
     px.iw0 = (int16_t)iw0;
     tab[m] = px;
+}
+
+// K-split partial products -> result: sums the S slabs of the workspace in index order (deterministic) and applies the epilogue.
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(GP p, const float* ws, int S) {
+    using T = bf16;
+    const int cpr = p.N >> 3;
+    const int64_t total = (int64_t)p.M * cpr;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p.batch > 1) {
+        const int b = blockIdx.y;
+        p.C = reinterpret_cast<unsigned char*>(p.C) + b * p.bs_c;
+        ws += (int64_t)b * S * p.M * p.N;
+    }
+    if (idx >= total) return;
+    if (p.dropout_p > 0.f && p.seed_ptr) p.seed += *p.seed_ptr;
+    const int m = (int)(idx / cpr), n = (int)(idx - (int64_t)m * cpr) * 8;
+    float v[8], t[8], sc[8], sh[8];
+    const float* src = ws + (int64_t)m * p.N + n;
+    load8(src, v);
+    for (int s = 1; s < S; ++s) {
+        load8(src + (int64_t)s * p.M * p.N, t);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += t[r];
+    }
+    if (p.scale) load8(p.scale + n, sc);
+    if (p.shift) load8(p.shift + n, sh);
+    const int64_t orow = p.c_rowmap ? (int64_t)p.c_rowmap[m] : (int64_t)m;
+    epilogue8<T>(p, v, sc, sh, m, orow, n);
+}
+
+// which of the 8-wave kernel's forms (0 none, 1 forward, 2 data gradient, 3 weight gradient) covers this problem
+int gemm8_form(const cb_gemm_desc* d, const GP& p, bool fast) {
+    if (!fast || d->dtype != CB_BF16) return 0;
+    const int taps = p.R * p.S;
+    if ((d->a_mode == CB_ROWK || d->a_mode == CB_ROWK_GATHER) && d->b_mode == CB_ROWK) return 1;
+    if (d->a_mode == CB_ROWK && (d->b_mode == CB_KROW || (d->b_mode == CB_KROW_TAPS && taps == 1))) return 2;
+    if (d->a_mode == CB_ROWK_GATHER && d->b_mode == CB_KROW_TAPS && p.Ct % 64 == 0) return 2;
+    if (d->a_mode == CB_KROW && (d->b_mode == CB_KROW || d->b_mode == CB_KROW_GATHER)) return 3;
+    return 0;
+}
+
+template <int BM, int BN, int WGM, int WGN, int NST>
+int launch8(int form, const GP& p, int mode, float* ws, hipStream_t st) {
+    if (form == 1) return launch_gemm8_fwd<BM, BN, WGM, WGN, NST>(p, mode, ws, st);
+    if (form == 2) return launch_gemm8_dgrad<BM, BN, WGM, WGN, NST>(p, mode, ws, st);
+    return launch_gemm8_wgrad<BM, BN, WGM, WGN, NST>(p, mode, ws, st);
 }
 
 }  // namespace
@@ -146,26 +202,18 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     p.b_bytes = (uint32_t)(fast ? d->b_bytes : 0);
     static const bool no_remap = getenv("CB_GEMM_NO_XCD_REMAP") != nullptr;
     static const bool no_tuned = getenv("CB_GEMM_NO_TUNED") != nullptr;
-    CB_REQUIRE(d->tile >= 0 && d->tile <= 4, "cb_gemm: bad tile %d", d->tile);
+    CB_REQUIRE(d->tile >= 0 && d->tile <= 7, "cb_gemm: bad tile %d", d->tile);
     CB_REQUIRE(d->xcd_order >= 0 && d->xcd_order <= 2, "cb_gemm: bad xcd_order %d", d->xcd_order);
+    CB_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "cb_gemm: dropout_p out of range");
     int tile = d->tile, xcd = d->xcd_order;
+    const int split_caller = p.split_k;
+    int split_tuned = 0;                       // K split measured best for the table's tile (0: none recorded)
     if (d->dtype == CB_BF16 && !no_tuned && (tile == 0 || xcd == 0)) {
         if (const cbgemm::TunedEntry* e = cbgemm::tuned_lookup(d->a_mode, d->b_mode, d->M, d->N, d->K, p.batch, p.R * p.S, p.split_k)) {
-            if (tile == 0) tile = e->tile;
+            if (tile == 0) { tile = e->tile; split_tuned = e->new_split; }
             if (xcd == 0) xcd = e->xcd;
-            // weight-gradient form only (plain epilogue, fp32 C accumulated in place: any K split is valid): the measured best split
-            if (e->new_split > 0 && d->tile == 0 && d->a_mode == CB_KROW && d->c_f32 && d->accumulate && !d->C2 && !d->residual &&
-                !d->mask && !d->gelu_grad_pre && d->act == CB_ACT_NONE && !d->relu_after && !d->shift && d->dropout_p <= 0.f)
-                p.split_k = e->new_split;
         }
     }
-    if (p.split_k > 1) {
-        CB_REQUIRE(d->c_f32, "cb_gemm: split_k > 1 needs an fp32 output");
-        CB_REQUIRE(!d->C2 && !d->residual && !d->mask && !d->gelu_grad_pre && d->act == CB_ACT_NONE && !d->relu_after && !d->shift && d->dropout_p <= 0.f,
-                   "cb_gemm: split_k > 1 supports only scale/alpha in the epilogue");
-        if (p.split_k > p.ktiles) p.split_k = p.ktiles;
-    }
-    CB_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "cb_gemm: dropout_p out of range");
     // vector epilogue: every touched row pointer must be 16-byte (fp32) / 8-byte (bf16) aligned at n%4==0
     const int cesz = d->c_f32 ? 4 : esz;
     bool cv = (d->ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->C) % (4 * cesz)) == 0);
@@ -176,12 +224,67 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     if (d->scale) cv = cv && aligned16(d->scale);
     if (d->shift) cv = cv && aligned16(d->shift);
     p.c_vec = cv;
-    // row-contiguous epilogue: 8-wide chunks must be 16-byte aligned everywhere; atomics (split-K) keep the 4-wide path
-    bool cv8 = cv && p.split_k == 1 && (d->N % 8 == 0) && (d->ldc % 8 == 0) && aligned16(d->C);
+    // row-contiguous epilogue: 8-wide chunks must be 16-byte aligned everywhere
+    bool cv8 = cv && (d->N % 8 == 0) && (d->ldc % 8 == 0) && aligned16(d->C);
     if (d->C2) cv8 = cv8 && (d->ldc2 % 8 == 0) && aligned16(d->C2);
     if (d->residual) cv8 = cv8 && (d->ldr % 8 == 0) && aligned16(d->residual);
     if (d->mask) cv8 = cv8 && (d->ldm % 8 == 0) && aligned16(d->mask);
     if (d->gelu_grad_pre) cv8 = cv8 && (d->ld_gelu % 8 == 0) && aligned16(d->gelu_grad_pre);
+
+    // ---- 8-wave LDS-DMA tiles (5: 256x256, 6: 128x256, 7: 256x128), bf16 fast path, row-contiguous epilogue.  Their K split
+    // writes fp32 partial slabs into the caller's workspace and a second kernel adds them in index order and applies the FULL
+    // epilogue: deterministic, no atomics, any epilogue.  Without a (large enough) workspace the problem runs unsplit.
+    const int form8 = (tile >= 5 && cv8) ? gemm8_form(d, p, fast) : 0;
+    float* ws8 = nullptr;
+    if (tile >= 5 && form8 == 0) tile = 0;                       // not covered: the 4-wave kernels decide
+    if (tile >= 5) {
+        int split = d->tile == 0 ? (split_tuned > 0 ? split_tuned : 1) : split_caller;       // (table entry: its own measured split)
+        if (split > p.ktiles) split = p.ktiles;
+        bool no_ws = false;
+        if (split > 1) {
+            const int per = (p.ktiles + split - 1) / split;
+            split = (p.ktiles + per - 1) / per;                  // every split owns at least one K tile
+            const int64_t need = (int64_t)split * p.batch * d->M * d->N * 4;
+            if (d->splitk_ws && d->splitk_ws_bytes >= need && aligned16(d->splitk_ws)) ws8 = reinterpret_cast<float*>(d->splitk_ws);
+            else { split = 1; no_ws = true; }
+        }
+        if (no_ws && d->tile != 0) tile = 0;                     // explicit tile + split but no workspace: 4-wave atomics path
+        else p.split_k = split;
+    }
+    static const bool trace = getenv("CB_GEMM_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "cb_gemm: M=%d N=%d K=%d modes=%d/%d tile=%d (asked %d) form8=%d split=%d ws=%d\n", d->M, d->N, d->K, d->a_mode, d->b_mode,
+                       tile, d->tile, form8, tile >= 5 ? p.split_k : split_caller, ws8 != nullptr);
+    if (tile >= 5) {
+        static const int mode8_env = getenv("CB_GEMM8_MODE") ? atoi(getenv("CB_GEMM8_MODE")) : 2;
+        CB_REQUIRE(d->schedule >= 0 && d->schedule <= 3, "cb_gemm: bad schedule %d", d->schedule);
+        const int mode8 = d->schedule > 0 ? d->schedule - 1 : mode8_env;
+        p.c_vec8 = 1;
+        p.xcd_remap = !no_remap && xcd != 2;
+        hipStream_t st8 = cb_stream(stream);
+        int rc;
+        if (tile == 5) rc = launch8<256, 256, 2, 4, 2>(form8, p, mode8, ws8, st8);
+        else if (tile == 6) rc = launch8<128, 256, 2, 4, 3>(form8, p, mode8, ws8, st8);
+        else rc = launch8<256, 128, 4, 2, 3>(form8, p, mode8, ws8, st8);
+        if (rc != 0 || !ws8) return rc;
+        GP q = p;
+        q.split_k = 1;
+        const int64_t chunks = (int64_t)d->M * (d->N / 8);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((chunks + 255) / 256), (unsigned)p.batch), dim3(256), 0, st8, q, ws8, p.split_k);
+        return cb_launch_status("cb_gemm (split-K reduce)");
+    }
+
+    // ---- 4-wave kernels
+    p.split_k = split_caller;
+    if (split_tuned > 0 && d->tile == 0 && d->a_mode == CB_KROW && d->c_f32 && d->accumulate && !d->C2 && !d->residual &&
+        !d->mask && !d->gelu_grad_pre && d->act == CB_ACT_NONE && !d->relu_after && !d->shift && d->dropout_p <= 0.f)
+        p.split_k = split_tuned;       // weight-gradient form (plain epilogue, fp32 C accumulated in place: any K split is valid): the measured best
+    if (p.split_k > 1) {
+        CB_REQUIRE(d->c_f32, "cb_gemm: split_k > 1 needs an fp32 output");
+        CB_REQUIRE(!d->C2 && !d->residual && !d->mask && !d->gelu_grad_pre && d->act == CB_ACT_NONE && !d->relu_after && !d->shift && d->dropout_p <= 0.f,
+                   "cb_gemm: split_k > 1 supports only scale/alpha in the epilogue");
+        if (p.split_k > p.ktiles) p.split_k = p.ktiles;
+    }
+    cv8 = cv8 && p.split_k == 1;                                  // (atomics keep the 4-wide path)
     static const bool no_wide = getenv("CB_GEMM_NO_WIDE_EPILOGUE") != nullptr;
     p.c_vec8 = cv8 && (!no_wide || d->zero_fill_pitch > 0);
     if (d->zero_fill_pitch != 0)

@@ -52,8 +52,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch
          sH=0, sW=0, flip_taps=False, c_rowmap=None, accumulate=False, split_k=1, act=ACT_NONE,
          scale=None, shift=None, residual=None, ldr=None, relu_after=False, mask=None, ldm=None,
          out2=None, ldc2=None, alpha=1.0, dropout_p=0.0, dropout_seed=0, seed_ptr=None, tile=0, gelu_grad_pre=None, a_rowsum=None, batch=1, batch_strides=None,
-         relu_bwd=False, post_scale=None, post_scale2=None, xcd_order=0, zero_fill_pitch=0):
-    """C[M,N] (op)= epilogue(sum_k A(m,k) B(n,k)); see include/clipbert_hip.h cb_gemm_desc."""
+         relu_bwd=False, post_scale=None, post_scale2=None, xcd_order=0, zero_fill_pitch=0, splitk_ws=None, schedule=0):
+    """C[M,N] (op)= epilogue(sum_k A(m,k) B(n,k)); see include/clipbert_hip.h cb_gemm_desc.  ``splitk_ws``: fp32 scratch for
+    the K split of the 8-wave tiles (default: the per-device workspace of ``splitk_workspace``)."""
     d = GemmDesc()
     d.dtype = dtype_code(a.dtype)
     assert b.dtype == a.dtype
@@ -86,6 +87,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch
     d.dropout_seed = dropout_seed
     d.dropout_seed_ptr = _ptr(seed_ptr)
     d.tile = tile
+    d.schedule = schedule
     d.xcd_order = xcd_order
     d.a_bytes = _extent_bytes(a)
     d.b_bytes = _extent_bytes(b)
@@ -100,8 +102,29 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch
     if batch > 1:
         d.batch = batch
         d.batch_stride_a, d.batch_stride_b, d.batch_stride_c, d.batch_stride_rowsum = batch_strides
+    if splitk_ws is None and d.dtype == CB_BF16:
+        splitk_ws = splitk_workspace(a.device)
+    if splitk_ws is not None:
+        d.splitk_ws, d.splitk_ws_bytes = _ptr(splitk_ws), splitk_ws.numel() * splitk_ws.element_size()
     _chk(_lib.get().cb_gemm(C.byref(d), _stream(a)), "cb_gemm")
     return out
+
+
+_SPLITK_WS = {}
+SPLITK_WS_BYTES = 128 << 20
+
+
+def splitk_workspace(device) -> torch.Tensor:
+    """One fp32 scratch buffer per device for the K-split partial products of cb_gemm's 8-wave tiles (allocated once, outside
+    any hipGraph capture: launches on one stream use it one after the other)."""
+    key = str(device)
+    ws = _SPLITK_WS.get(key)
+    if ws is None:
+        if torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return None
+        ws = torch.empty(SPLITK_WS_BYTES // 4, dtype=torch.float32, device=device)
+        _SPLITK_WS[key] = ws
+    return ws
 
 
 def build_pixel_table(n: int, oh: int, ow: int, stride: int, pad: int, sN: int, sH: int, sW: int,

@@ -59,7 +59,8 @@ typedef struct {
     int32_t H, W;             /* bounds of the gathered image                                        */
     int64_t sH, sW;           /* element strides of one image row / one pixel                        */
     int32_t flip_taps;        /* CB_KROW_TAPS: read weight tap (R-1-r, S-1-s) (transposed conv)      */
-    int32_t reserved0;
+    int32_t schedule;         /* tiles 5-7 only: 0 = default K-loop schedule, 1 / 2 / 3 = force schedule 0 / 1 / 2 of
+                                 csrc/gemm8_impl.h (diagnostic: tools/gemm8_probe.py, tests)                          */
     /* output */
     void* C; int64_t ldc;
     const int32_t* c_rowmap;  /* optional: output row m is written at row c_rowmap[m]                */
@@ -83,7 +84,9 @@ typedef struct {
     const uint64_t* dropout_seed_ptr;  /* optional DEVICE word added to the seed (varies per hipGraph replay) */
     int32_t tile;             /* 0 auto (tuned table, then heuristics), 1 = 128x128, 2 = 64x64, 3 = 128x64,
                                  4 = 128x128 with its registers capped so that two blocks share a CU  (bf16; fp32 parity mode
-                                 always runs 64x64)                                                   */
+                                 always runs 64x64); 5 = 256x256, 6 = 128x256, 7 = 256x128: the 8-wave LDS-DMA kernels
+                                 (bf16, 16-byte-aligned operands and 8-column output chunks; anything else falls back
+                                 to auto)                                                             */
     int32_t xcd_order;        /* workgroup -> tile order: 0 auto, 1 = XCD-compact (each XCD, with its own L2, owns a
                                  contiguous run of tiles), 2 = dispatch order (consecutive tiles round-robin over XCDs) */
     int64_t a_bytes, b_bytes; /* sizes of the A / B buffers in bytes (0 = unknown).  When both are known, < 2 GiB
@@ -104,6 +107,10 @@ typedef struct {
                                  that consumes its result (F.relu_ + FrozenBatchNorm2d under autograd, grid_feat.py:95) */
     int64_t batch_stride_a, batch_stride_b, batch_stride_c, batch_stride_rowsum;
     const float* post_scale; const float* post_scale2;
+    void* splitk_ws;          /* optional scratch for the K split of tiles 5-7: split_k * batch * M * N fp32 partial products
+                                 (one slab per split), summed in index order by a second kernel that applies the whole
+                                 epilogue -- deterministic, no atomics, every epilogue allowed.  Too small / null: no split. */
+    int64_t splitk_ws_bytes;
 } cb_gemm_desc;
 
 /* GEMM / implicit-GEMM convolution, all forms.  Replaces torch.nn.Linear / F.conv2d (+ apex-amp

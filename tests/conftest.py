@@ -14,7 +14,7 @@ def pytest_configure(config):
 
 # Collection order under `-m gpu -x`: kernel parity first, then whole-model / golden parity, then the host-logic rows on the
 # GPU, and subprocess / control-flow tests LAST -- a brittle late test must never mask the parity rows behind it.
-_ORDER = ["test_abi", "test_kernels_gemm", "test_kernels_misc", "test_gemm_fuzz", "test_model_small", "test_gpu_full", "test_parity_record",
+_ORDER = ["test_abi", "test_kernels_gemm", "test_kernels_gemm8", "test_kernels_misc", "test_gemm_fuzz", "test_model_small", "test_gpu_full", "test_parity_record",
           "test_clips", "test_tasks", "test_checkpoint", "test_loops", "test_comm"]
 
 

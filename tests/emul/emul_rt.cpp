@@ -56,6 +56,7 @@ thread_local WorkerReaper reaper;
 
 void fiber_entry() {
     (*W->body)();
+    if (cur->dma_n) { fprintf(stderr, "emul: kernel ended with %d LDS-DMAs never waited for\n", cur->dma_n); abort(); }
     cur->done = true;
     // give the barrier bookkeeping a chance: a finished thread never arrives again
     emul_switch(&cur->sp, W->sched_sp);
@@ -88,6 +89,7 @@ void run_block(Block& b, const std::function<void()>& body) {
         Fiber& f = w->fibers[t];
         f.tid = dim3(t % b.bdim.x, (t / b.bdim.x) % b.bdim.y, t / (b.bdim.x * b.bdim.y));
         f.lane = t % kWave; f.wave = t / kWave; f.done = false;
+        f.dma_head = 0; f.dma_n = 0;
         uintptr_t top = (uintptr_t)(w->stacks + kStack * (t + 1));
         top &= ~(uintptr_t)15;
         void** sp = (void**)(top - 64);

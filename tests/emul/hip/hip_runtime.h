@@ -43,12 +43,17 @@ struct Wave {
     int nlanes = 64;
     alignas(16) unsigned char buf[2][kWave][64];
 };
+// one lane's share of an LDS-DMA instruction that was issued and has not been retired by an s_waitcnt vmcnt(N) yet
+struct PendingDma { unsigned char* dst; const unsigned char* src; unsigned size; };
+constexpr int kMaxDma = 64;
 struct Fiber {
     void* sp = nullptr;
     dim3 tid;
     int lane = 0;
     int wave = 0;
     bool done = false;
+    PendingDma dma[kMaxDma];
+    int dma_head = 0, dma_n = 0;
 };
 struct Block {
     dim3 bid, bdim, gdim;
@@ -62,6 +67,33 @@ extern thread_local Block* blk;
 void yield();
 // run `body` once per thread of every block of the grid
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+
+// EMUL_DMA_LAZY=1: an LDS-DMA's bytes reach LDS only when the issuing lane's s_waitcnt vmcnt(N) retires it (the latest
+// moment the hardware allows): a ds_read placed before the covering wait + barrier then sees stale data -- deterministically.
+// Default (eager): the bytes land at issue, the earliest moment: exposes a stage that is re-filled while still being read.
+inline bool dma_lazy() {
+    static const bool v = [] { const char* e = getenv("EMUL_DMA_LAZY"); return e && atoi(e) != 0; }();
+    return v;
+}
+inline void dma_apply(const PendingDma& d) {
+    if (d.src) memcpy(d.dst, d.src, d.size); else memset(d.dst, 0, d.size);
+}
+inline void dma_retire(int keep) {              // oldest first, until at most `keep` are outstanding
+    Fiber* f = cur;
+    while (f->dma_n > keep) {
+        dma_apply(f->dma[f->dma_head]);
+        f->dma_head = (f->dma_head + 1) % kMaxDma;
+        --f->dma_n;
+    }
+}
+inline void dma_issue(unsigned char* dst, const unsigned char* src, unsigned size) {
+    PendingDma d{dst, src, size};
+    if (!dma_lazy()) { dma_apply(d); return; }
+    Fiber* f = cur;
+    if (f->dma_n == kMaxDma) { fprintf(stderr, "emul: more than %d LDS-DMAs in flight (vmcnt is a 6-bit counter)\n", kMaxDma); abort(); }
+    f->dma[(f->dma_head + f->dma_n) % kMaxDma] = d;
+    ++f->dma_n;
+}
 
 inline void block_barrier() {
     Block* b = blk;
@@ -197,10 +229,11 @@ static inline emul_u32x4 emul_raw_buffer_load_b128(emul_rsrc r, uint32_t voff, u
 static inline void emul_buffer_load_lds(emul_rsrc r, void* lds_base, unsigned size, uint32_t voff, uint32_t soff, uint32_t, uint32_t) {
     unsigned char* dst = (unsigned char*)lds_base + emul::cur->lane * size;
     uint64_t o = (uint64_t)voff + soff;
-    if (o + size <= r.n) memcpy(dst, r.base + o, size); else memset(dst, 0, size);
+    emul::dma_issue(dst, (o + size <= r.n) ? r.base + o : nullptr, size);
 }
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, p, sz, vo, so, off, aux) emul_buffer_load_lds((r), (void*)(p), (sz), (vo), (so), (off), (aux))
-static inline void __builtin_amdgcn_s_waitcnt(int) {}
+// s_waitcnt: only the vmcnt field matters to the emulator (imm[3:0] | imm[15:14] << 4): retires this lane's oldest LDS-DMAs
+static inline void __builtin_amdgcn_s_waitcnt(int imm) { emul::dma_retire((imm & 15) | (((imm >> 14) & 3) << 4)); }
 
 // v_perm_b32: result byte i = byte sel[i] of the 8 bytes {s1 (0..3), s0 (4..7)}
 static inline uint32_t emul_perm(uint32_t s0, uint32_t s1, uint32_t sel) {

@@ -27,19 +27,20 @@ def test_gemm_desc_layout_matches_header():
     import subprocess
     import tempfile
     from clipbert_amd import _lib
-    src = '#include "clipbert_hip.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu", sizeof(cb_gemm_desc), ' \
+    src = '#include "clipbert_hip.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu", sizeof(cb_gemm_desc), ' \
           'offsetof(cb_gemm_desc, C), offsetof(cb_gemm_desc, dropout_seed_ptr), offsetof(cb_gemm_desc, tile), sizeof(cb_pixel), ' \
           'offsetof(cb_gemm_desc, a_rowsum), offsetof(cb_gemm_desc, batch), offsetof(cb_gemm_desc, relu_bwd), ' \
-          'offsetof(cb_gemm_desc, post_scale2));return 0;}'
+          'offsetof(cb_gemm_desc, post_scale2), offsetof(cb_gemm_desc, splitk_ws_bytes));return 0;}'
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
         open(c, "w").write(src)
         exe = os.path.join(d, "t")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
-        size, off_c, off_seed, off_tile, px, off_rs, off_batch, off_rb, off_ps2 = map(int, subprocess.check_output([exe]).split())
+        size, off_c, off_seed, off_tile, px, off_rs, off_batch, off_rb, off_ps2, off_ws = map(int, subprocess.check_output([exe]).split())
     G = _lib.GemmDesc
     assert (ctypes.sizeof(G), G.C.offset, G.dropout_seed_ptr.offset, G.tile.offset, px) == (size, off_c, off_seed, off_tile, 8)
     assert (G.a_rowsum.offset, G.batch.offset, G.relu_bwd.offset, G.post_scale2.offset) == (off_rs, off_batch, off_rb, off_ps2)
+    assert G.splitk_ws_bytes.offset == off_ws
 
 
 def test_product_loader_has_no_fallback(tmp_path):

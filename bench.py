@@ -113,6 +113,7 @@ def main():
     torch.cuda.set_device(dev)
 
     from clipbert_amd import modeling as M
+    from clipbert_amd import ops
     from clipbert_amd import synthetic as S
     from clipbert_amd import tasks
     from clipbert_amd.dist import GradSync
@@ -162,6 +163,7 @@ def main():
         sync.broadcast_parameters(0)
         opt = FusedAdamW(bank, lr=5e-5, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0)
     state = {"global_step": 0}
+    one = torch.ones((), dtype=torch.float32, device=dev)          # d(loss)/d(loss): persistent, so that backward() launches no fill
 
     # ---- the pieces of a step ------------------------------------------------------------------------------------------
     def forward_loss():
@@ -179,8 +181,8 @@ def main():
         opt.zero_grad(lazy=True)
         model.rt.pending_encoder_nodes = model.rt.pending_cnn_nodes = 0
         loss = forward_loss()
-        loss.backward()
-        model.rt.seed_dev.add_(1)
+        loss.backward(one)
+        ops.counter_add(model.rt.seed_dev)
         opt.launch()
         return loss
 
@@ -208,7 +210,7 @@ def main():
                 total = loss_h.detach()
         for st in chain_streams:
             cur.wait_stream(st)
-        model.rt.seed_dev.add_(1)
+        ops.counter_add(model.rt.seed_dev)
         opt.launch()
         return total
 
@@ -227,7 +229,7 @@ def main():
         sync.reduce_cnn()
         g16 = sync.wire_gradients()             # N > 1, bf16 wire: AdamW reads the reduced image directly (no cast back to fp32)
         sync.wait(cast_back=g16 is None)
-        model.rt.seed_dev.add_(1)
+        ops.counter_add(model.rt.seed_dev)
         opt.launch(grad16=g16)
         return loss
 
@@ -337,8 +339,7 @@ def main():
             vis = frames.view(bv * nclip, T, *frames.shape[2:]) if (fold and nclip > 1) else frames
             assert fold or nclip == 1, "the split replay plan needs the folded clip forward (one encoder node)"
             grid = model.grid_features(vis)
-            mini = dict(visual_inputs=grid, text_input_ids=ids.repeat(nclip, 1) if nclip > 1 else ids,
-                        text_input_mask=mask.repeat(nclip, 1) if nclip > 1 else mask, labels=None,
+            mini = dict(visual_inputs=grid, text_input_ids=ids, text_input_mask=mask, labels=None,
                         n_examples_list=tasks._pair_counts(tcfg, counts))
             lg = model.forward_from_grid(mini, clip_fold=nclip)["logits"]
             stack = lg.reshape(nclip, lg.shape[0] // nclip, *lg.shape[1:])
@@ -369,7 +370,7 @@ def main():
             sync.cast_cnn(late_only=True)
 
         def part_c():
-            model.rt.seed_dev.add_(1)
+            ops.counter_add(model.rt.seed_dev)
             opt.launch(grad16=sync.wire_gradients())
 
         wire16 = sync.wire_gradients() is not None

@@ -50,10 +50,13 @@ _SIGNATURES = {
     "cb_comm_info": [vp, vp],
     "cb_allreduce_bucket": [vp, i64, i32, vp],
     "cb_comm_destroy": [],
-    "cb_text_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "cb_text_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp],
     "cb_visual_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
-                            i32, i32, i32, f32, vp],
-    "cb_text_embed_bwd": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, vp],
+                            i32, i32, i32, f32, vp, vp],
+    "cb_text_embed_bwd": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i32, vp],
+    "cb_mean_fwd": [vp, i64, vp, vp],
+    "cb_mean_bwd": [vp, i64, vp, vp],
+    "cb_counter_add": [vp, i64, vp],
     "cb_visual_embed_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "cb_attention_fwd": [i32, vp, vp, vp, vp, i32, i32, i32, f32, u64, vp, vp],
     "cb_attention_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, u64, vp, vp],

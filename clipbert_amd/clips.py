@@ -43,6 +43,27 @@ class _LseLossFn(torch.autograd.Function):
         return dx, None
 
 
+class _MeanFn(torch.autograd.Function):
+    """loss.mean() of the runners (run_video_retrieval.py:422) as a library kernel (a captured step then holds no framework-side
+    reduction / fill kernels); the upstream gradient stays on the device (a scalar tensor)."""
+    @staticmethod
+    def forward(ctx, x):
+        ctx.n, ctx.shape = x.numel(), x.shape
+        return ops.mean_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dmean):
+        return ops.mean_bwd(dmean.float().contiguous(), ctx.n, dmean).view(ctx.shape)
+
+
+def mean_loss(per_example: torch.Tensor) -> torch.Tensor:
+    """scalar mean of the per-example losses (cb_mean_fwd / cb_mean_bwd)"""
+    x = per_example.float().contiguous()
+    if x.numel() == 0:
+        return x.sum() * float("nan")                   # mean of nothing, as torch defines it
+    return _MeanFn.apply(x)
+
+
 def _stack(logits) -> torch.Tensor:
     """list of per-clip logits, or their (n_clips, B, C) stack (a folded forward returns it directly), as fp32"""
     if torch.is_tensor(logits):

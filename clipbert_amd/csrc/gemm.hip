@@ -207,10 +207,11 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     CB_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "cb_gemm: dropout_p out of range");
     int tile = d->tile, xcd = d->xcd_order;
     const int split_caller = p.split_k;
-    int split_tuned = 0;                       // K split measured best for the table's tile (0: none recorded)
+    int split_tuned = 0, sched_tuned = 0;      // K split / K-loop schedule measured best for the table's tile (0: none recorded)
     if (d->dtype == CB_BF16 && !no_tuned && (tile == 0 || xcd == 0)) {
         if (const cbgemm::TunedEntry* e = cbgemm::tuned_lookup(d->a_mode, d->b_mode, d->M, d->N, d->K, p.batch, p.R * p.S, p.split_k)) {
-            if (tile == 0) { tile = e->tile; split_tuned = e->new_split; }
+            static const bool no8w = getenv("CB_GEMM_NO8W") != nullptr;          // diagnostic: ignore the table's 8-wave entries
+            if (tile == 0 && !(no8w && e->tile >= 5)) { tile = e->tile; split_tuned = e->new_split; sched_tuned = e->sched; }
             if (xcd == 0) xcd = e->xcd;
         }
     }
@@ -233,7 +234,8 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
 
     // ---- 8-wave LDS-DMA tiles (5: 256x256, 6: 128x256, 7: 256x128), bf16 fast path, row-contiguous epilogue.  Their K split
     // writes fp32 partial slabs into the caller's workspace and a second kernel adds them in index order and applies the FULL
-    // epilogue: deterministic, no atomics, any epilogue.  Without a (large enough) workspace the problem runs unsplit.
+    // epilogue: deterministic, no atomics, any epilogue.  Without a (large enough) workspace a split configuration is not run at all
+    // (an unsplit large tile would leave most CUs idle): the 4-wave kernels take the problem.
     const int form8 = (tile >= 5 && cv8) ? gemm8_form(d, p, fast) : 0;
     float* ws8 = nullptr;
     if (tile >= 5 && form8 == 0) tile = 0;                       // not covered: the 4-wave kernels decide
@@ -248,7 +250,7 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
             if (d->splitk_ws && d->splitk_ws_bytes >= need && aligned16(d->splitk_ws)) ws8 = reinterpret_cast<float*>(d->splitk_ws);
             else { split = 1; no_ws = true; }
         }
-        if (no_ws && d->tile != 0) tile = 0;                     // explicit tile + split but no workspace: 4-wave atomics path
+        if (no_ws) tile = 0;                                     // the configuration needs its split: without a workspace the 4-wave kernels decide
         else p.split_k = split;
     }
     static const bool trace = getenv("CB_GEMM_TRACE") != nullptr;
@@ -257,7 +259,7 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     if (tile >= 5) {
         static const int mode8_env = getenv("CB_GEMM8_MODE") ? atoi(getenv("CB_GEMM8_MODE")) : 2;
         CB_REQUIRE(d->schedule >= 0 && d->schedule <= 3, "cb_gemm: bad schedule %d", d->schedule);
-        const int mode8 = d->schedule > 0 ? d->schedule - 1 : mode8_env;
+        const int mode8 = d->schedule > 0 ? d->schedule - 1 : (sched_tuned > 0 ? sched_tuned - 1 : mode8_env);
         p.c_vec8 = 1;
         p.xcd_remap = !no_remap && xcd != 2;
         hipStream_t st8 = cb_stream(stream);

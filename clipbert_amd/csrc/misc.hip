@@ -378,3 +378,37 @@ extern "C" int cb_elu_bn1d_bwd(int32_t dtype, const void* dy, const void* x, con
     else return cb_fail("cb_elu_bn1d_bwd: bad dtype");
     return cb_launch_status("cb_elu_bn1d_bwd");
 }
+
+// ---- scalar plumbing of a training step (so that a captured step holds no framework-side elementwise kernels) ------------------
+namespace {
+__global__ void __launch_bounds__(256) mean_fwd_kernel(const float* x, int64_t n, float* out) {
+    __shared__ float part[4];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += x[i];           // fixed order per thread + fixed tree: deterministic
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (part[0] + part[1] + part[2] + part[3]) / (float)n;
+}
+__global__ void __launch_bounds__(256) mean_bwd_kernel(const float* dmean, int64_t n, float* dx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dx[i] = *dmean / (float)n;
+}
+__global__ void counter_add_kernel(int64_t* c, int64_t inc) { *c += inc; }
+}  // namespace
+
+extern "C" int cb_mean_fwd(const float* x, int64_t n, float* out, void* stream) {
+    CB_REQUIRE(x && out && n > 0, "cb_mean_fwd: bad arguments");
+    hipLaunchKernelGGL(mean_fwd_kernel, dim3(1), dim3(256), 0, cb_stream(stream), x, n, out);
+    return cb_launch_status("cb_mean_fwd");
+}
+extern "C" int cb_mean_bwd(const float* dmean, int64_t n, float* dx, void* stream) {
+    CB_REQUIRE(dmean && dx && n > 0, "cb_mean_bwd: bad arguments");
+    hipLaunchKernelGGL(mean_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cb_stream(stream), dmean, n, dx);
+    return cb_launch_status("cb_mean_bwd");
+}
+extern "C" int cb_counter_add(int64_t* counter, int64_t inc, void* stream) {
+    CB_REQUIRE(counter, "cb_counter_add: null counter");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, cb_stream(stream), counter, inc);
+    return cb_launch_status("cb_counter_add");
+}

@@ -231,13 +231,15 @@ template <typename T, int MAXCH>
 __global__ void __launch_bounds__(256) text_embed_fwd_kernel(const int64_t* ids, const T* word, const T* pos, const T* type0,
                                                              const float* gamma, const float* beta, T* out, T* pre,
                                                              float* mean_out, float* rstd_out, int B, int Lt, int Ltot, int D,
-                                                             float eps) {
+                                                             float eps, const int64_t* attn_mask, float* key_mask, int period) {
     const int lane = threadIdx.x & 63;
     const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= (int64_t)B * Lt) return;
     const int b = (int)(tok / Lt), t = (int)(tok % Lt);
     const int64_t orow = (int64_t)b * Ltot + t;
-    const int64_t id = ids[tok];
+    const int64_t irow = (int64_t)(b % period) * Lt + t;         // the text batch repeats with this period (folded clips)
+    const int64_t id = ids[irow];
+    if (key_mask && lane == 0) key_mask[orow] = attn_mask ? (float)attn_mask[irow] : 1.0f;
     f32x4 v[MAXCH], a[MAXCH];
     load_row(word + id * D, D, lane, v);
     load_row(pos + (int64_t)t * D, D, lane, a);
@@ -264,7 +266,7 @@ __global__ void __launch_bounds__(256) visual_embed_fwd_kernel(const T* grid, co
                                                                const T* row_emb, const T* col_emb, const T* type0,
                                                                const float* gamma, const float* beta, T* out, T* pre,
                                                                float* mean_out, float* rstd_out, int B, int Tf, int Hg, int Wg,
-                                                               int Lv, int Lt, int Ltot, int D, float eps) {
+                                                               int Lv, int Lt, int Ltot, int D, float eps, float* key_mask) {
     const int lane = threadIdx.x & 63;
     const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= (int64_t)B * Lv) return;
@@ -273,6 +275,7 @@ __global__ void __launch_bounds__(256) visual_embed_fwd_kernel(const T* grid, co
     const int h = q / Wg, w = q % Wg;
     const int64_t src = src_row ? src_row[b] : b;
     const int64_t orow = (int64_t)b * Ltot + Lt + pidx;
+    if (key_mask && lane == 0) key_mask[orow] = 1.0f;            // visual tokens are never masked (modeling.py:217-220)
     f32x4 v[MAXCH], a[MAXCH];
 #pragma unroll
     for (int c = 0; c < MAXCH; ++c) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; v[c] = z; }
@@ -313,7 +316,7 @@ constexpr int EMB_BSLICES = 4;
 
 template <typename T>
 __global__ void __launch_bounds__(256) text_embed_bwd_kernel(const T* dpre, const int64_t* ids, float* dword, float* dpos,
-                                                             float* dtype0, int B, int Lt, int Ltot, int D, int64_t pad_id) {
+                                                             float* dtype0, int B, int Lt, int Ltot, int D, int64_t pad_id, int period) {
     const int t = blockIdx.x;
     const int per = (B + gridDim.y - 1) / gridDim.y;
     const int b0 = blockIdx.y * per, b1 = (b0 + per < B) ? b0 + per : B;
@@ -321,7 +324,7 @@ __global__ void __launch_bounds__(256) text_embed_bwd_kernel(const T* dpre, cons
         f32x4 sum = {0.f, 0.f, 0.f, 0.f};
         for (int b = b0; b < b1; ++b) {
             const f32x4 g = load4(dpre + ((int64_t)b * Ltot + t) * D + e);
-            const int64_t id = ids[(int64_t)b * Lt + t];
+            const int64_t id = ids[(int64_t)(b % period) * Lt + t];
             sum = sum + g;
             if (id != pad_id) {
 #pragma unroll
@@ -420,17 +423,19 @@ void run_ln_bwd(hipStream_t st, const void* dy, const void* x, const float* gamm
 }
 template <typename T, int NCH>
 void run_text_fwd(hipStream_t st, const int64_t* ids, const void* word, const void* pos, const void* type0, const float* gamma,
-                  const float* beta, void* out, void* pre, float* mean, float* rstd, int B, int Lt, int Ltot, int D, float eps) {
+                  const float* beta, void* out, void* pre, float* mean, float* rstd, int B, int Lt, int Ltot, int D, float eps,
+                  const int64_t* attn_mask, float* key_mask, int period) {
     hipLaunchKernelGGL((text_embed_fwd_kernel<T, NCH>), dim3(nblk((int64_t)B * Lt, 4)), dim3(256), 0, st, ids, (const T*)word,
-                       (const T*)pos, (const T*)type0, gamma, beta, (T*)out, (T*)pre, mean, rstd, B, Lt, Ltot, D, eps);
+                       (const T*)pos, (const T*)type0, gamma, beta, (T*)out, (T*)pre, mean, rstd, B, Lt, Ltot, D, eps, attn_mask, key_mask,
+                       period);
 }
 template <typename T, int NCH>
 void run_vis_fwd(hipStream_t st, const void* grid, const int32_t* src_row, const int32_t* sel, const void* row_emb,
                  const void* col_emb, const void* type0, const float* gamma, const float* beta, void* out, void* pre, float* mean,
-                 float* rstd, int B, int Tf, int Hg, int Wg, int Lv, int Lt, int Ltot, int D, float eps) {
+                 float* rstd, int B, int Tf, int Hg, int Wg, int Lv, int Lt, int Ltot, int D, float eps, float* key_mask) {
     hipLaunchKernelGGL((visual_embed_fwd_kernel<T, NCH>), dim3(nblk((int64_t)B * Lv, 4)), dim3(256), 0, st, (const T*)grid, src_row,
                        sel, (const T*)row_emb, (const T*)col_emb, (const T*)type0, gamma, beta, (T*)out, (T*)pre, mean, rstd, B, Tf,
-                       Hg, Wg, Lv, Lt, Ltot, D, eps);
+                       Hg, Wg, Lv, Lt, Ltot, D, eps, key_mask);
 }
 
 }  // namespace
@@ -476,10 +481,14 @@ extern "C" int cb_ln_partials_reduce(const float* part, float* grad, const int64
 
 extern "C" int cb_text_embed_fwd(int32_t dtype, const int64_t* ids, const void* word, const void* pos, const void* type0,
                                  const float* gamma, const float* beta, void* out, void* pre, float* mean, float* rstd,
-                                 int32_t B, int32_t Lt, int32_t L_total, int32_t D, float eps, void* stream) {
+                                 int32_t B, int32_t Lt, int32_t L_total, int32_t D, float eps, const int64_t* attn_mask,
+                                 float* key_mask, int32_t rows_period, void* stream) {
     CB_REQUIRE(ids && word && pos && type0 && gamma && beta && out && CB_D_OK(D) && Lt <= L_total, "cb_text_embed_fwd: bad arguments");
+    CB_REQUIRE(rows_period >= 0 && rows_period <= B, "cb_text_embed_fwd: rows_period %d out of range", rows_period);
     if ((int64_t)B * Lt == 0) return 0;
-    CB_DISPATCH(run_text_fwd, cb_stream(stream), ids, word, pos, type0, gamma, beta, out, pre, mean, rstd, B, Lt, L_total, D, eps);
+    const int period = rows_period > 0 ? rows_period : B;
+    CB_DISPATCH(run_text_fwd, cb_stream(stream), ids, word, pos, type0, gamma, beta, out, pre, mean, rstd, B, Lt, L_total, D, eps,
+                attn_mask, key_mask, period);
     return cb_launch_status("cb_text_embed_fwd");
 }
 
@@ -487,23 +496,24 @@ extern "C" int cb_visual_embed_fwd(int32_t dtype, const void* grid, const int32_
                                    const void* row_emb, const void* col_emb, const void* type0, const float* gamma,
                                    const float* beta, void* out, void* pre, float* mean, float* rstd, int32_t B, int32_t T,
                                    int32_t Hg, int32_t Wg, int32_t Lv, int32_t Lt, int32_t L_total, int32_t D, float eps,
-                                   void* stream) {
+                                   float* key_mask, void* stream) {
     CB_REQUIRE(grid && row_emb && col_emb && type0 && gamma && beta && out && CB_D_OK(D) && T > 0 && Lt + Lv <= L_total,
                "cb_visual_embed_fwd: bad arguments");
     CB_REQUIRE(sel || Lv == Hg * Wg, "cb_visual_embed_fwd: Lv must equal Hg*Wg without a selection");
     if ((int64_t)B * Lv == 0) return 0;
     CB_DISPATCH(run_vis_fwd, cb_stream(stream), grid, src_row, sel, row_emb, col_emb, type0, gamma, beta, out, pre, mean, rstd, B, T,
-                Hg, Wg, Lv, Lt, L_total, D, eps);
+                Hg, Wg, Lv, Lt, L_total, D, eps, key_mask);
     return cb_launch_status("cb_visual_embed_fwd");
 }
 
 extern "C" int cb_text_embed_bwd(int32_t dtype, const void* dpre, const int64_t* ids, float* dword, float* dpos, float* dtype0,
-                                 int32_t B, int32_t Lt, int32_t L_total, int32_t D, int64_t pad_id, void* stream) {
-    CB_REQUIRE(dpre && ids && dword && dpos && dtype0 && D % 4 == 0, "cb_text_embed_bwd: bad arguments");
+                                 int32_t B, int32_t Lt, int32_t L_total, int32_t D, int64_t pad_id, int32_t rows_period, void* stream) {
+    CB_REQUIRE(dpre && ids && dword && dpos && dtype0 && D % 4 == 0 && rows_period >= 0 && rows_period <= B, "cb_text_embed_bwd: bad arguments");
     if ((int64_t)B * Lt == 0) return 0;
+    const int period = rows_period > 0 ? rows_period : B;
     dim3 g((unsigned)Lt, (unsigned)(B < EMB_BSLICES ? B : EMB_BSLICES)), b(256);
-    if (dtype == CB_BF16) hipLaunchKernelGGL((text_embed_bwd_kernel<bf16>), g, b, 0, cb_stream(stream), (const bf16*)dpre, ids, dword, dpos, dtype0, B, Lt, L_total, D, pad_id);
-    else if (dtype == CB_F32) hipLaunchKernelGGL((text_embed_bwd_kernel<float>), g, b, 0, cb_stream(stream), (const float*)dpre, ids, dword, dpos, dtype0, B, Lt, L_total, D, pad_id);
+    if (dtype == CB_BF16) hipLaunchKernelGGL((text_embed_bwd_kernel<bf16>), g, b, 0, cb_stream(stream), (const bf16*)dpre, ids, dword, dpos, dtype0, B, Lt, L_total, D, pad_id, period);
+    else if (dtype == CB_F32) hipLaunchKernelGGL((text_embed_bwd_kernel<float>), g, b, 0, cb_stream(stream), (const float*)dpre, ids, dword, dpos, dtype0, B, Lt, L_total, D, pad_id, period);
     else return cb_fail("cb_text_embed_bwd: bad dtype");
     return cb_launch_status("cb_text_embed_bwd");
 }

@@ -161,6 +161,20 @@ class _GridConv(nn.Module):
         return None, None
 
 
+class _SideStream:
+    """torch.cuda.stream(side) + no K-split workspace for the launches inside (it belongs to the main stream's launches)"""
+    def __init__(self, stream):
+        self.ctx = torch.cuda.stream(stream)
+
+    def __enter__(self):
+        self.prev, ops._SPLITK_OFF = ops._SPLITK_OFF, True
+        return self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        ops._SPLITK_OFF = self.prev
+        return self.ctx.__exit__(*exc)
+
+
 # =================================================================================================
 # execution context shared by all modules of one ClipBert instance
 # =================================================================================================
@@ -197,7 +211,7 @@ class Runtime:
         ev.record()
         self.side_stream.wait_event(ev)
         self._side_refs.extend(tensors)
-        return torch.cuda.stream(self.side_stream)
+        return _SideStream(self.side_stream)
 
     def join(self):
         if self.side_stream is not None:
@@ -597,12 +611,14 @@ class ClipBertBaseModel(nn.Module):
     def get_input_embeddings(self):
         return self.embeddings.word_embeddings
 
-    def forward(self, text_input_ids, visual_inputs, attention_mask, src_row=None, pooled_dropout=False):
+    def forward(self, text_input_ids, visual_inputs, attention_mask, src_row=None, pooled_dropout=False, text_repeat=1):
         """visual_inputs: grid (Bv, n_frm, H', W', d); src_row maps each text row to its grid row
-        (the fused form of repeat_tensor_rows).  Returns (sequence_output (B, L, d), pooled (B, d))."""
+        (the fused form of repeat_tensor_rows).  Returns (sequence_output (B, L, d), pooled (B, d)).
+        text_repeat = n: the (P, Lt) text batch stands for n*P rows (row b = text row b % P: the captions of a folded clip loop,
+        read in place by the embedding kernels instead of from n repeated copies)."""
         seq, pooled = _EncoderFn.apply(self.rt.anchor, visual_inputs, self, text_input_ids, attention_mask, src_row,
-                                       pooled_dropout)
-        b = text_input_ids.shape[0]
+                                       pooled_dropout, text_repeat)
+        b = text_input_ids.shape[0] * text_repeat
         return seq.view(b, -1, self.config.hidden_size), pooled
 
 
@@ -610,7 +626,7 @@ def _drop_p(model, training, key="hidden_dropout_prob"):
     return float(_cfg_get(model.config, key, 0.0)) if training else 0.0
 
 
-def encoder_forward(model: ClipBertBaseModel, grid, ids, mask, src_row, pooled_dropout, save):
+def encoder_forward(model: ClipBertBaseModel, grid, ids, mask, src_row, pooled_dropout, save, text_repeat=1):
     rt, cfg = model.rt, model.config
     bank, dt, dev = rt.bank, rt.dtype, ids.device
     d, nh, eps = cfg.hidden_size, cfg.num_attention_heads, cfg.layer_norm_eps
@@ -621,7 +637,7 @@ def encoder_forward(model: ClipBertBaseModel, grid, ids, mask, src_row, pooled_d
     if p_h > 0 or p_a > 0:                    # every training forward draws its own dropout masks (the reference's
         fwd_i = rt.forward_count              # nn.Dropout does); the backward regenerates them from pack.fwd_i
         rt.forward_count += 1
-    bsz, lt = ids.shape
+    bsz, lt = ids.shape[0] * text_repeat, ids.shape[1]
     bv, t, hg, wg, _ = grid.shape
     # optional random pixel sub-sampling: training phase of pre-training only (modeling.py:80-88)
     sel = None
@@ -635,8 +651,8 @@ def encoder_forward(model: ClipBertBaseModel, grid, ids, mask, src_row, pooled_d
     M = bsz * L
     if src_row is None:
         assert bv == bsz, "visual batch and text batch differ: pass src_row (n_examples_list)"
-    key_mask = torch.ones(bsz, L, dtype=torch.float32, device=dev)
-    key_mask[:, :lt] = mask.to(torch.float32)
+    key_mask = torch.empty(bsz, L, dtype=torch.float32, device=dev)        # filled by the two embedding kernels
+    mask_c = mask if (mask.dtype == torch.int64 and mask.is_contiguous()) else mask.to(torch.int64).contiguous()
     nl, ff = len(model.encoder.layer), cfg.intermediate_size
     # The operands of the weight-gradient GEMMs are kept LAYER-STACKED ([layer, M, *]): the backward then computes the
     # weight gradients of all layers of one kind in a single strided-batched launch (encoder_backward).
@@ -652,11 +668,11 @@ def encoder_forward(model: ClipBertBaseModel, grid, ids, mask, src_row, pooled_d
     ids_c = ids.contiguous()
     ops.text_embed_fwd(ids_c, bank.compute(emb.word_embeddings.weight), bank.compute(emb.position_embeddings.weight),
                        bank.compute(emb.token_type_embeddings.weight)[0], emb.LayerNorm.weight, emb.LayerNorm.bias, x, pre,
-                       mean0, rstd0, lt, L, eps)
+                       mean0, rstd0, lt, L, eps, attn_mask=mask_c, key_mask=key_mask, repeat=text_repeat)
     grid_c = grid.contiguous()
     ops.visual_embed_fwd(grid_c, src_row, sel, bank.compute(vemb.row_position_embeddings.weight),
                          bank.compute(vemb.col_position_embeddings.weight), bank.compute(vemb.token_type_embeddings.weight)[0],
-                         vemb.LayerNorm.weight, vemb.LayerNorm.bias, x, pre, mean0, rstd0, bsz, lv, lt, L, eps)
+                         vemb.LayerNorm.weight, vemb.LayerNorm.bias, x, pre, mean0, rstd0, bsz, lv, lt, L, eps, key_mask=key_mask)
     if p_h > 0:
         ops.dropout(x, p_h, _seed(_SITE_EMB, 0, fwd_i), rt.seed_dev, out=x)
     layers = []
@@ -698,7 +714,7 @@ def encoder_forward(model: ClipBertBaseModel, grid, ids, mask, src_row, pooled_d
     if save:
         pack = SimpleNamespace(layers=layers, x_final=x, pooled=pooled, pooled_raw=pooled_raw, p_pool=p_pool, pre=pre,
                                mean0=mean0, rstd0=rstd0, ids=ids_c, key_mask=key_mask, src_row=src_row, sel=sel, bsz=bsz,
-                               lt=lt, lv=lv, L=L, grid_shape=tuple(grid.shape), p_h=p_h, p_a=p_a, stk=stk, fwd_i=fwd_i)
+                               lt=lt, lv=lv, L=L, grid_shape=tuple(grid.shape), p_h=p_h, p_a=p_a, stk=stk, fwd_i=fwd_i, text_repeat=text_repeat)
     return x, pooled, pack
 
 
@@ -874,7 +890,7 @@ def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
     we = emb.word_embeddings
     ops.text_embed_bwd(dpre, pk.ids, bank.grad_image(we.weight), bank.grad_image(emb.position_embeddings.weight),
                        bank.grad_image(emb.token_type_embeddings.weight)[0], lt, L,
-                       we.padding_idx if we.padding_idx is not None else -1)
+                       we.padding_idx if we.padding_idx is not None else -1, repeat=pk.text_repeat)
     dgrid = torch.zeros(pk.grid_shape, dtype=torch.float32, device=dev)
     ops.visual_embed_bwd(dpre, pk.src_row, pk.sel, dgrid, bank.grad_image(vemb.row_position_embeddings.weight),
                          bank.grad_image(vemb.col_position_embeddings.weight), bank.grad_image(vemb.token_type_embeddings.weight)[0],
@@ -886,10 +902,10 @@ def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
 
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, grid, model, ids, mask, src_row, pooled_dropout):
+    def forward(ctx, anchor, grid, model, ids, mask, src_row, pooled_dropout, text_repeat=1):
         save = ctx.needs_input_grad[0]
         ctx.set_materialize_grads(False)
-        seq, pooled, pack = encoder_forward(model, grid, ids, mask, src_row, pooled_dropout, save)
+        seq, pooled, pack = encoder_forward(model, grid, ids, mask, src_row, pooled_dropout, save, text_repeat)
         ctx.model, ctx.pack = model, pack
         if save:
             model.rt.pending_encoder_nodes += 1
@@ -906,7 +922,7 @@ class _EncoderFn(torch.autograd.Function):
         # transformer gradients are complete -- and may start their all-reduce -- only after the last of them
         if hook is not None and rt.pending_encoder_nodes == 0:
             hook()
-        return None, dgrid, None, None, None, None, None
+        return None, dgrid, None, None, None, None, None, None
 
 
 # =================================================================================================
@@ -1045,8 +1061,8 @@ class ClipBertForVideoTextRetrieval(_ClipBertHead):
         self.classifier = _make_mlp(self.config.hidden_size, self.config.num_labels)
         self.margin = _cfg_get(self.config, "margin", 0.0)
 
-    def forward(self, text_input_ids, visual_inputs, text_input_mask, labels=None, sample_size=-1, src_row=None):
-        _, pooled = self.bert(text_input_ids, visual_inputs, text_input_mask, src_row, pooled_dropout=True)
+    def forward(self, text_input_ids, visual_inputs, text_input_mask, labels=None, sample_size=-1, src_row=None, text_repeat=1):
+        _, pooled = self.bert(text_input_ids, visual_inputs, text_input_mask, src_row, pooled_dropout=True, text_repeat=text_repeat)
         logits = self._mlp(pooled, self.classifier)
         logits, loss = self.calc_loss(logits, labels, sample_size=sample_size)
         return dict(logits=logits, loss=loss)
@@ -1072,8 +1088,8 @@ class ClipBertForMultipleChoice(_ClipBertHead):
         super().__init__(config)
         self.classifier = _make_mlp(self.config.hidden_size, 1)
 
-    def forward(self, text_input_ids, visual_inputs, text_input_mask, labels=None, src_row=None):
-        _, pooled = self.bert(text_input_ids, visual_inputs, text_input_mask, src_row, pooled_dropout=True)
+    def forward(self, text_input_ids, visual_inputs, text_input_mask, labels=None, src_row=None, text_repeat=1):
+        _, pooled = self.bert(text_input_ids, visual_inputs, text_input_mask, src_row, pooled_dropout=True, text_repeat=text_repeat)
         logits = self._mlp(pooled, self.classifier)
         logits, loss = self.calc_loss(logits, labels)
         return dict(logits=logits, loss=loss)
@@ -1100,8 +1116,8 @@ class ClipBertForSequenceClassification(_ClipBertHead):
         super().__init__(config)
         self.classifier = _make_mlp(self.config.hidden_size, self.config.num_labels)
 
-    def forward(self, text_input_ids, visual_inputs, text_input_mask, labels=None, src_row=None):
-        _, pooled = self.bert(text_input_ids, visual_inputs, text_input_mask, src_row, pooled_dropout=True)
+    def forward(self, text_input_ids, visual_inputs, text_input_mask, labels=None, src_row=None, text_repeat=1):
+        _, pooled = self.bert(text_input_ids, visual_inputs, text_input_mask, src_row, pooled_dropout=True, text_repeat=text_repeat)
         logits = self._mlp(pooled, self.classifier)
         logits, loss = self.calc_loss(logits, labels)
         return dict(logits=logits, loss=loss)
@@ -1159,9 +1175,9 @@ class ClipBertForRegression(_ClipBertHead):
         d = self.config.hidden_size
         self.regressor = nn.ModuleList([Linear(d, d), nn.Identity(), BatchNorm1d(d), nn.Identity(), Linear(d, 1)])
 
-    def forward(self, text_input_ids, visual_inputs, text_input_mask, labels=None, src_row=None):
+    def forward(self, text_input_ids, visual_inputs, text_input_mask, labels=None, src_row=None, text_repeat=1):
         rt = self.rt
-        _, pooled = self.bert(text_input_ids, visual_inputs, text_input_mask, src_row, pooled_dropout=True)
+        _, pooled = self.bert(text_input_ids, visual_inputs, text_input_mask, src_row, pooled_dropout=True, text_repeat=text_repeat)
         reg = self.regressor
         h = _LinearFn.apply(rt.anchor, pooled, rt, reg[0].weight, reg[0].bias, ACT_NONE, False, None)
         h = _EluBnFn.apply(rt.anchor, h, rt, reg[2], self.training)
@@ -1301,6 +1317,8 @@ class ClipBert(nn.Module):
         rt.bank = ParamBank(self, device, dtype, transformer_lr_mul_prefix, cnn_lr_mul_prefix)
         rt.seed_dev = torch.zeros(1, dtype=torch.int64, device=device)
         rt.anchor = torch.zeros(1, dtype=torch.float32, device=device, requires_grad=True)
+        if dtype == torch.bfloat16 and (device.type == "cuda" or ops._ALLOW_HOST_POINTERS):
+            ops.splitk_workspace(device)            # scratch of cb_gemm's K-split: allocated here, before any hipGraph capture
         if device.type == "cuda" and overlap_wgrad:
             rt.side_stream = torch.cuda.Stream(device=device)
         for m in self.modules():
@@ -1361,9 +1379,12 @@ class ClipBert(nn.Module):
                 src_row = torch.tensor([i for i, r in enumerate(repeat_counts) for _ in range(r)], dtype=torch.int32,
                                        device=vis.device)
                 self._src_cache[key] = src_row
-        if src_row is not None and src_row.numel() != batch["text_input_ids"].shape[0]:
+        n_txt = batch["text_input_ids"].shape[0]
+        if clip_fold > 1 and src_row is not None and n_txt * clip_fold == src_row.numel():
+            batch["text_repeat"] = clip_fold           # the captions of ONE clip: every clip reads them in place (no repeated copies)
+        elif src_row is not None and src_row.numel() != n_txt:
             raise ValueError(f"n_examples_list describes {src_row.numel()} (video, text) pairs but the text batch has "
-                             f"{batch['text_input_ids'].shape[0]} rows")
+                             f"{n_txt} rows")
         if self.retrieval:
             batch["sample_size"] = len(repeat_counts)
         return self.transformer(src_row=src_row, **batch)

@@ -102,7 +102,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch
     if batch > 1:
         d.batch = batch
         d.batch_stride_a, d.batch_stride_b, d.batch_stride_c, d.batch_stride_rowsum = batch_strides
-    if splitk_ws is None and d.dtype == CB_BF16:
+    if splitk_ws is None and d.dtype == CB_BF16 and not _SPLITK_OFF:
         splitk_ws = splitk_workspace(a.device)
     if splitk_ws is not None:
         d.splitk_ws, d.splitk_ws_bytes = _ptr(splitk_ws), splitk_ws.numel() * splitk_ws.element_size()
@@ -111,16 +111,19 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch
 
 
 _SPLITK_WS = {}
+_SPLITK_OFF = False                    # set while launches go to a SIDE stream (Runtime.side): the buffer belongs to the main stream's launches
 SPLITK_WS_BYTES = 128 << 20
 
 
 def splitk_workspace(device) -> torch.Tensor:
-    """One fp32 scratch buffer per device for the K-split partial products of cb_gemm's 8-wave tiles (allocated once, outside
-    any hipGraph capture: launches on one stream use it one after the other)."""
-    key = str(device)
+    """One fp32 scratch buffer per device for the K-split partial products of cb_gemm's 8-wave tiles.  Launches that follow one
+    another on a stream (or on streams ordered by events, as a hipGraph capture after an eager warm-up) share it; launches on a
+    concurrent side stream must not (ops._SPLITK_OFF).  Allocated on first use / by ClipBert.prepare(), never inside a capture."""
+    dev = torch.device(device)
+    key = str(dev)
     ws = _SPLITK_WS.get(key)
     if ws is None:
-        if torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing():
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
             return None
         ws = torch.empty(SPLITK_WS_BYTES // 4, dtype=torch.float32, device=device)
         _SPLITK_WS[key] = ws
@@ -252,28 +255,52 @@ def ln_partials_reduce(part, grad, off_gamma, off_beta):
          "cb_ln_partials_reduce")
 
 
-def text_embed_fwd(ids, word, pos, type0, gamma, beta, out, pre, mean, rstd, lt, l_total, eps):
-    b = ids.shape[0]
+def text_embed_fwd(ids, word, pos, type0, gamma, beta, out, pre, mean, rstd, lt, l_total, eps, attn_mask=None, key_mask=None,
+                   repeat=1):
+    """``repeat`` = n: the (P, Lt) ids / attn_mask are the text batch of ONE clip; n*P output rows are produced (row b reads row
+    b % P).  ``key_mask`` (B, L_total) fp32 receives the text columns of the attention key mask."""
+    b = ids.shape[0] * repeat
     d = word.shape[-1]
     _chk(_lib.get().cb_text_embed_fwd(dtype_code(word.dtype), _ptr(ids), _ptr(word), _ptr(pos), _ptr(type0),
                                       _ptr(gamma), _ptr(beta), _ptr(out), _ptr(pre), _ptr(mean), _ptr(rstd), b, lt,
-                                      l_total, d, eps, _stream(out)), "cb_text_embed_fwd")
+                                      l_total, d, eps, _ptr(attn_mask), _ptr(key_mask), ids.shape[0] if repeat > 1 else 0,
+                                      _stream(out)), "cb_text_embed_fwd")
 
 
 def visual_embed_fwd(grid, src_row, sel, row_emb, col_emb, type0, gamma, beta, out, pre, mean, rstd, b, lv, lt,
-                     l_total, eps):
+                     l_total, eps, key_mask=None):
     _, t, hg, wg, d = grid.shape
     _chk(_lib.get().cb_visual_embed_fwd(dtype_code(grid.dtype), _ptr(grid), _ptr(src_row), _ptr(sel), _ptr(row_emb),
                                         _ptr(col_emb), _ptr(type0), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(pre),
-                                        _ptr(mean), _ptr(rstd), b, t, hg, wg, lv, lt, l_total, d, eps, _stream(out)),
-         "cb_visual_embed_fwd")
+                                        _ptr(mean), _ptr(rstd), b, t, hg, wg, lv, lt, l_total, d, eps, _ptr(key_mask),
+                                        _stream(out)), "cb_visual_embed_fwd")
 
 
-def text_embed_bwd(dpre, ids, dword, dpos, dtype0, lt, l_total, pad_id):
-    b = ids.shape[0]
+def text_embed_bwd(dpre, ids, dword, dpos, dtype0, lt, l_total, pad_id, repeat=1):
+    b = ids.shape[0] * repeat
     d = dword.shape[-1]
     _chk(_lib.get().cb_text_embed_bwd(dtype_code(dpre.dtype), _ptr(dpre), _ptr(ids), _ptr(dword), _ptr(dpos),
-                                      _ptr(dtype0), b, lt, l_total, d, pad_id, _stream(dpre)), "cb_text_embed_bwd")
+                                      _ptr(dtype0), b, lt, l_total, d, pad_id, ids.shape[0] if repeat > 1 else 0, _stream(dpre)),
+         "cb_text_embed_bwd")
+
+
+def mean_fwd(x: torch.Tensor) -> torch.Tensor:
+    """scalar mean of a contiguous fp32 vector (the runners' loss.mean())"""
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    _chk(_lib.get().cb_mean_fwd(_ptr(x), x.numel(), _ptr(out), _stream(x)), "cb_mean_fwd")
+    return out
+
+
+def mean_bwd(dmean: torch.Tensor, n: int, like: torch.Tensor) -> torch.Tensor:
+    dx = torch.empty(n, dtype=torch.float32, device=like.device)
+    _chk(_lib.get().cb_mean_bwd(_ptr(dmean), n, _ptr(dx), _stream(like)), "cb_mean_bwd")
+    return dx
+
+
+def counter_add(counter: torch.Tensor, inc: int = 1):
+    """*counter += inc on a device int64 word (the dropout seed word: advanced inside a captured step)"""
+    assert counter.dtype == torch.int64 and counter.numel() == 1
+    _chk(_lib.get().cb_counter_add(_ptr(counter), inc, _stream(counter)), "cb_counter_add")
 
 
 def visual_embed_bwd(dpre, src_row, sel, dgrid, drow, dcol, dtype0, b, lv, lt, l_total):

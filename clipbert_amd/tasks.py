@@ -51,8 +51,8 @@ def forward_clips_stack(model, batch: Dict, num_clips: int, num_frm: int, fold: 
     ids, mask = batch["text_input_ids"], batch["text_input_mask"]
     if fold and num_clips > 1:
         grid = model.grid_features(vis.view(bsz * num_clips, num_frm, *vis.shape[2:]))
-        mini = dict(extra, visual_inputs=grid, text_input_ids=ids.repeat(num_clips, 1), text_input_mask=mask.repeat(num_clips, 1),
-                    labels=None, n_examples_list=counts)
+        # (the text rows are NOT repeated: forward_from_grid(clip_fold=n) lets every clip read the one caption batch in place)
+        mini = dict(extra, visual_inputs=grid, text_input_ids=ids, text_input_mask=mask, labels=None, n_examples_list=counts)
         lg = model.forward_from_grid(mini, clip_fold=num_clips)["logits"]
         return lg.reshape(num_clips, lg.shape[0] // num_clips, *lg.shape[1:])
     vis = vis.view(bsz, num_clips, num_frm, *vis.shape[2:])
@@ -73,13 +73,13 @@ def training_loss(model, logits, labels, n_examples_list, pool_method: str) -> t
     """:402-419: pool the clips (``logits``: list of per-clip logits or their (n_clips, B', C) stack) and take the mean
     per-pair loss."""
     if pool_method == "lse":
-        return clips.lse_stack_train_loss(logits, labels).mean()
+        return clips.mean_loss(clips.lse_stack_train_loss(logits, labels))
     pooled = clips.aggregate_clip_logits(logits, pool_method)
     if getattr(model, "retrieval", False):
         _, loss = model.transformer.calc_loss(pooled, labels, sample_size=len(n_examples_list))
     else:                                                   # QA heads (run_video_qa.py:417-419)
         _, loss = model.transformer.calc_loss(pooled, labels)
-    return loss.mean()
+    return clips.mean_loss(loss)
 
 
 def set_learning_rates(optimizer, cfg, global_step: int, n_epoch: int = 0):

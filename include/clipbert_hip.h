@@ -180,10 +180,15 @@ int cb_ln_partials_reduce(const float* part, float* grad, const int64_t* off_gam
                           int32_t njobs, int32_t nblocks, int32_t D, void* stream);
 
 /* Text embedding (BertEmbeddings.forward, src/modeling/transformers.py:172-199): out row
- * (b*L_total + t) = LN(word[ids[b,t]] + pos[t] + type[0]); pre-LN sum saved in `pre` when non-null. */
+ * (b*L_total + t) = LN(word[ids[b,t]] + pos[t] + type[0]); pre-LN sum saved in `pre` when non-null.
+ * rows_period = P > 0: the text batch is P rows repeated B/P times (the folded clip loop: every clip sees the same captions) --
+ * ids / attn_mask hold P rows and row b reads row b % P (no repeated copy is materialised); 0: B distinct rows.
+ * key_mask (optional, fp32 B x L_total): the attention key mask of ClipBertBaseModel.forward (src/modeling/modeling.py:217-220)
+ * -- this call writes its text columns (attn_mask, or ones when attn_mask is null), cb_visual_embed_fwd the visual ones. */
 int cb_text_embed_fwd(int32_t dtype, const int64_t* ids, const void* word, const void* pos, const void* type0,
                       const float* gamma, const float* beta, void* out, void* pre, float* mean, float* rstd,
-                      int32_t B, int32_t Lt, int32_t L_total, int32_t D, float eps, void* stream);
+                      int32_t B, int32_t Lt, int32_t L_total, int32_t D, float eps, const int64_t* attn_mask,
+                      float* key_mask, int32_t rows_period, void* stream);
 /* Visual embedding (VisualInputEmbedding.forward, src/modeling/modeling.py:62-101,124-153) fused
  * with repeat_tensor_rows (src/datasets/data_utils.py:344-357): out row (b*L_total + Lt + p) =
  * LN(mean_t grid[src_row[b], t, sel[p]] + row_emb[h] + col_emb[w] + type[0]).  sel (optional) is the
@@ -192,12 +197,12 @@ int cb_visual_embed_fwd(int32_t dtype, const void* grid, const int32_t* src_row,
                         const void* row_emb, const void* col_emb, const void* type0, const float* gamma,
                         const float* beta, void* out, void* pre, float* mean, float* rstd, int32_t B,
                         int32_t T, int32_t Hg, int32_t Wg, int32_t Lv, int32_t Lt, int32_t L_total, int32_t D,
-                        float eps, void* stream);
+                        float eps, float* key_mask, void* stream);
 /* Backward of both embeddings given d(pre) rows in a (B, L_total, D) buffer: scatter-adds (fp32
  * atomics) into the embedding-table gradients and into dgrid (fp32, zero-initialised by caller). */
 int cb_text_embed_bwd(int32_t dtype, const void* dpre, const int64_t* ids, float* dword, float* dpos,
                       float* dtype0, int32_t B, int32_t Lt, int32_t L_total, int32_t D, int64_t pad_id,
-                      void* stream);   /* rows with ids == pad_id get no word gradient (padding_idx) */
+                      int32_t rows_period, void* stream);   /* rows with ids == pad_id get no word gradient (padding_idx) */
 int cb_visual_embed_bwd(int32_t dtype, const void* dpre, const int32_t* src_row, const int32_t* sel,
                         float* dgrid, float* drow, float* dcol, float* dtype0, int32_t B, int32_t T,
                         int32_t Hg, int32_t Wg, int32_t Lv, int32_t Lt, int32_t L_total, int32_t D,
@@ -258,6 +263,11 @@ int cb_clip_aggregate_bwd(const float* dout, const float* logits, const float* o
  * clip-major logits [n_clips][B][C]; `dlogits` (optional) receives dloss[b] (1 if null) times its gradient. */
 int cb_lse_loss(const float* logits, const int64_t* labels, int32_t n_clips, int32_t B, int32_t C, float* loss, const float* dloss,
                 float* dlogits, void* stream);
+/* Mean of n per-example losses (the runners' loss.mean(), run_video_retrieval.py:422) and its backward
+ * dx[i] = *dmean / n; `*counter += inc` on a device word (the dropout seed word a captured step advances). */
+int cb_mean_fwd(const float* x, int64_t n, float* out, void* stream);
+int cb_mean_bwd(const float* dmean, int64_t n, float* dx, void* stream);
+int cb_counter_add(int64_t* counter, int64_t inc, void* stream);
 int cb_sq_sum(const float* g, int64_t n, float* out_accum, void* stream);
 /* The same sum with a result that does not depend on the order in which workgroups retire (fixed grid of <= min(1024, ws_floats)
  * blocks -> `ws` partials -> one block adds them in index order): data-parallel ranks holding bit-identical all-reduced

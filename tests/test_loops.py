@@ -30,7 +30,9 @@ def _batches(cfg, n, seed0=50, n_clips=2):
     return out
 
 
-def test_start_training_validates_saves_and_resumes(emul, tmp_path):
+def test_start_training_validates_saves_and_resumes(hw, tmp_path):
+    """row N2 + N3 on both backends (host emulator / MI355X): loop, validation, model_step_N.pt, restore.pt, resume"""
+    CPU = hw.dev                                             # (name kept: every tensor below lives on the backend's device)
     cfg, sd, model = build("retrieval", RET, torch.float32, CPU)
     opt = optim.FusedAdamW(model.rt.bank, lr=1e-3, betas=(0.9, 0.98), weight_decay=1e-3, cnn_lr=1e-3, max_grad_norm=5.0)
     tcfg = SimpleNamespace(train_n_clips=2, num_frm=2, score_agg_func="lse", gradient_accumulation_steps=2, learning_rate=1e-3,
@@ -62,14 +64,28 @@ def test_start_training_validates_saves_and_resumes(emul, tmp_path):
     assert r2.global_step == 3 and opt2.step_count == 3
     torch.testing.assert_close(model2.rt.bank.master, model.rt.bank.master, rtol=0, atol=0)
     torch.testing.assert_close(model2.rt.bank.exp_avg_sq, model.rt.bank.exp_avg_sq, rtol=0, atol=0)
+    # the dropout counters travel with restore.pt: the resumed run continues the mask sequence
+    assert model2.rt.forward_count == model.rt.forward_count > 0
+    # the checkpoint the loop wrote, loaded into the ORACLE, gives the logits the trained model computes (eval mode)
+    model.eval()
+    b = _batches(cfg, 1, seed0=90, n_clips=1)[0]
+    vis = b["visual_inputs"]
+    ob = dict(visual_inputs=O.image_norm(vis, S.PIXEL_MEAN, S.PIXEL_STD), text_input_ids=b["text_input_ids"], text_input_mask=b["text_input_mask"],
+              n_examples_list=[2, 2])
+    with torch.no_grad():
+        ref = O.clipbert_forward({k: v.float() if v.is_floating_point() else v for k, v in saved.items()}, ob, cfg, "retrieval")["logits"]
+        got = model(dict(visual_inputs=vis.to(CPU), text_input_ids=b["text_input_ids"].to(CPU), text_input_mask=b["text_input_mask"].to(CPU),
+                         n_examples_list=[2, 2]))["logits"].float().cpu()
+    torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-3)
 
 
-def test_load_state_dict_refreshes_compute_copies(emul):
+def test_load_state_dict_refreshes_compute_copies(hw):
     """loading weights into a PREPARED bf16 model must refresh the bf16 copies the kernels read."""
+    CPU = hw.dev
     cfg, sd, model = build("retrieval", RET, torch.bfloat16, CPU)
     frames = S.synthetic_frames(1, 2, 64, 3)[..., :64, :].repeat(1, 1, 1, 1, 2).contiguous()
     ids, mask = S.synthetic_text(2, 6, 3, cfg["vocab_size"])
-    b = dict(visual_inputs=frames, text_input_ids=ids.clamp(max=cfg["vocab_size"] - 1), text_input_mask=mask, n_examples_list=[2])
+    b = dict(visual_inputs=frames.to(CPU), text_input_ids=ids.clamp(max=cfg["vocab_size"] - 1).to(CPU), text_input_mask=mask.to(CPU), n_examples_list=[2])
     with torch.no_grad():
         before = model(dict(b))["logits"].float().clone()
     sd2 = S.full_state_dict(cfg, "retrieval", 9)
@@ -90,7 +106,8 @@ def test_load_state_dict_refreshes_compute_copies(emul):
     torch.testing.assert_close(bank.w16[:bank.n_train].float(), bank.master[:bank.n_train].bfloat16().float())
 
 
-def test_backbone_import_from_torchvision_and_detectron2_layouts(emul, tmp_path):
+def test_backbone_import_from_torchvision_and_detectron2_layouts(hw, tmp_path):
+    CPU = hw.dev
     cfg, sd, model = build("retrieval", RET, torch.float32, CPU)
     own = model.cnn.feature.state_dict()
     # a torchvision-style ResNet-50 state dict carrying recognisable values
@@ -120,6 +137,20 @@ def test_backbone_import_from_torchvision_and_detectron2_layouts(emul, tmp_path)
                     "proposal_generator.rpn_head.conv.weight": np.zeros((4, 4, 3, 3), np.float32), "pixel_mean": np.zeros(3, np.float32)}}
     assert C.load_detectron2_backbone(model.cnn, d2) == len(own)
     assert all(float(v.float().mean()) == 0.5 for v in model.cnn.feature.state_dict().values())
+    # a backbone with recognisable RANDOM weights, imported after prepare(): the kernels must compute with it (oracle on the same state)
+    sd9 = S.full_state_dict(cfg, "retrieval", 9)
+    d2r = {"model": {k[len("cnn.feature."):]: v.numpy() for k, v in sd9.items() if k.startswith("cnn.feature.backbone.")}}
+    assert C.load_detectron2_backbone(model.cnn, d2r) == len(own)
+    frames = S.synthetic_frames(1, 2, 64, 3)
+    ids, mask = S.synthetic_text(2, 6, 3, cfg["vocab_size"])
+    ids = ids.clamp(max=cfg["vocab_size"] - 1)
+    now = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref = O.clipbert_forward(now, dict(visual_inputs=O.image_norm(frames, S.PIXEL_MEAN, S.PIXEL_STD), text_input_ids=ids, text_input_mask=mask,
+                                           n_examples_list=[2]), cfg, "retrieval")["logits"]
+        got = model(dict(visual_inputs=frames.to(CPU), text_input_ids=ids.to(CPU), text_input_mask=mask.to(CPU), n_examples_list=[2]))["logits"].float().cpu()
+    torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-3)
+    assert (now["cnn.feature.backbone.res4.0.conv2.weight"] - sd9["cnn.feature.backbone.res4.0.conv2.weight"]).abs().max() == 0
     # load_separate_ckpt raises when nothing matches
     torch.save({"unrelated.weight": torch.zeros(3)}, os.path.join(str(tmp_path), "bad.pth"))
     with pytest.raises(RuntimeError):
@@ -156,9 +187,10 @@ def test_prefetch_loader_pinned_double_buffer_gpu():
     assert len({k for k in loader._pinned}) == 4                        # two tensor keys x two pinned slots, reused across batches
 
 
-def test_backbone_load_after_prepare_refreshes_compute_copies(emul):
+def test_backbone_load_after_prepare_refreshes_compute_copies(hw):
     """load_detectron2_backbone goes through cnn.feature.load_state_dict -- the bf16 compute copies, folded FrozenBN
     vectors and the packed stem filter of a PREPARED model must follow the new masters."""
+    CPU = hw.dev
     cfg, sd, model = build("retrieval", RET, torch.bfloat16, CPU)
     bank = model.rt.bank
     own = model.cnn.feature.state_dict()
@@ -168,7 +200,7 @@ def test_backbone_load_after_prepare_refreshes_compute_copies(emul):
     assert float(p.float().mean()) == 0.5
     assert bank.is_trainable(p)
     off = bank.offset[id(p)]
-    torch.testing.assert_close(bank.w16[off:off + p.numel()].float(), torch.full((p.numel(),), 0.5))      # compute copy == master
+    torch.testing.assert_close(bank.w16[off:off + p.numel()].float().cpu(), torch.full((p.numel(),), 0.5))      # compute copy == master
     assert model.rt.stem_w is None and all(m._ss is None for m in model.modules() if isinstance(m, M.Conv2d))
 
 

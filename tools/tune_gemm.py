@@ -19,7 +19,21 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-TILES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "128x128o2"}
+TILES = {1: "128x128", 2: "64x64", 3: "128x64", 4: "128x128o2", 5: "8w256x256", 6: "8w128x256", 7: "8w256x128"}
+TILE_DIM = {5: (256, 256), 6: (128, 256), 7: (256, 128)}
+
+
+def splits_for(tile, M, N, K, batch):
+    """K splits worth trying for an 8-wave tile: unsplit, and the splits that bring the grid to ~1x / ~2x the 256 CUs"""
+    bm, bn = TILE_DIM[tile]
+    tiles = -(-M // bm) * -(-N // bn) * batch
+    kt = -(-K // 64)
+    cand = {1}
+    for target in (256, 512):
+        s = max(1, round(target / tiles))
+        if s > 1 and kt // s >= 2 and s * batch * M * N * 4 <= (128 << 20):
+            cand.add(s)
+    return sorted(cand)
 
 
 def record_calls(mode):
@@ -78,9 +92,9 @@ def key_of(pos, kw):
             str(a.dtype).replace("torch.", ""))
 
 
-def time_config(pos, kw, tile, xcd, inner=16, outer=4, best_of=3, split=None):
+def time_config(pos, kw, tile, xcd, inner=16, outer=4, best_of=3, split=None, sched=0):
     from clipbert_amd import ops
-    kw = dict(kw, tile=tile, xcd_order=xcd)
+    kw = dict(kw, tile=tile, xcd_order=xcd, schedule=sched)
     if split is not None:
         kw["split_k"] = split
 
@@ -114,9 +128,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--modes", default="train")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "gemm_tuning.json"))
-    ap.add_argument("--tiles", default="1,2,3,4")
+    ap.add_argument("--tiles", default="1,2,3,4,5,6,7")
+    ap.add_argument("--sched", default="1,3", help="K-loop schedules of the 8-wave tiles to sweep (cb_gemm_desc.schedule values)")
     args = ap.parse_args()
-    tiles = [int(t) for t in args.tiles.split(",")]
+    tiles = [int(t) for t in args.tiles.split(",") if int(t) <= 4]
+    tiles8 = [int(t) for t in args.tiles.split(",") if int(t) >= 5]
+    scheds = [int(t) for t in args.sched.split(",")]
     os.environ["CB_GEMM_NO_TUNED"] = "1"                  # the recorded calls carry tile = 0: measure the heuristics as "auto"
     problems = {}
     for mode in args.modes.split(";" if ";" in args.modes or ":" in args.modes else ","):
@@ -151,6 +168,13 @@ def main():
                     base = {kk: v for kk, v in kw.items() if kk not in ("tile", "xcd_order", "split_k")}
                     us, err = time_config(pos, base, t, 1, split=sp)
                     res[f"{TILES[t]}/xcd/s{sp}"] = us if us is not None else None
+        # 8-wave LDS-DMA tiles: any form; their K split goes through workspace slabs (any epilogue)
+        for t in tiles8:
+            for sp in splits_for(t, k[3], k[4], k[5], k[6]):
+                for sc in scheds:
+                    base = {kk: v for kk, v in kw.items() if kk not in ("tile", "xcd_order", "split_k", "schedule")}
+                    us, err = time_config(pos, base, t, 1, split=sp, sched=sc)
+                    res[f"{TILES[t]}/xcd/s{sp}/m{sc - 1}"] = us if us is not None else None
         flops = 2.0 * k[3] * k[4] * k[5] * k[6]
         good = {c: v for c, v in res.items() if v is not None and c != "auto"}
         best = min(good, key=good.get)

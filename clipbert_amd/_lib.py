@@ -49,6 +49,9 @@ _SIGNATURES = {
     "cb_comm_init": [i32, i32, vp],
     "cb_comm_info": [vp, vp],
     "cb_allreduce_bucket": [vp, i64, i32, vp],
+    "cb_reduce_scatter_bucket": [vp, vp, i64, i32, vp],
+    "cb_allgather_bucket": [vp, vp, i64, i32, vp],
+    "cb_broadcast_bucket": [vp, i64, i32, i32, vp],
     "cb_comm_destroy": [],
     "cb_text_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp],
     "cb_visual_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,

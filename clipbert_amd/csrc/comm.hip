@@ -22,6 +22,9 @@ typedef void* Comm;
 typedef int (*GetUniqueIdFn)(UniqueId*);
 typedef int (*CommInitRankFn)(Comm*, int, UniqueId, int);
 typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, Comm, hipStream_t);
+typedef int (*ReduceScatterFn)(const void*, void*, size_t, int, int, Comm, hipStream_t);
+typedef int (*AllGatherFn)(const void*, void*, size_t, int, Comm, hipStream_t);
+typedef int (*BroadcastFn)(const void*, void*, size_t, int, int, Comm, hipStream_t);
 typedef int (*CommDestroyFn)(Comm);
 typedef const char* (*ErrorStringFn)(int);
 
@@ -30,6 +33,9 @@ struct CommState {
     GetUniqueIdFn get_unique_id = nullptr;
     CommInitRankFn init_rank = nullptr;
     AllReduceFn all_reduce = nullptr;
+    ReduceScatterFn reduce_scatter = nullptr;
+    AllGatherFn all_gather = nullptr;
+    BroadcastFn broadcast = nullptr;
     CommDestroyFn destroy = nullptr;
     ErrorStringFn error_string = nullptr;
     Comm comm = nullptr;
@@ -46,6 +52,9 @@ int load_rccl() {
     g_comm.get_unique_id = reinterpret_cast<GetUniqueIdFn>(dlsym(h, "ncclGetUniqueId"));
     g_comm.init_rank = reinterpret_cast<CommInitRankFn>(dlsym(h, "ncclCommInitRank"));
     g_comm.all_reduce = reinterpret_cast<AllReduceFn>(dlsym(h, "ncclAllReduce"));
+    g_comm.reduce_scatter = reinterpret_cast<ReduceScatterFn>(dlsym(h, "ncclReduceScatter"));
+    g_comm.all_gather = reinterpret_cast<AllGatherFn>(dlsym(h, "ncclAllGather"));
+    g_comm.broadcast = reinterpret_cast<BroadcastFn>(dlsym(h, "ncclBroadcast"));
     g_comm.destroy = reinterpret_cast<CommDestroyFn>(dlsym(h, "ncclCommDestroy"));
     g_comm.error_string = reinterpret_cast<ErrorStringFn>(dlsym(h, "ncclGetErrorString"));
     if (!g_comm.get_unique_id || !g_comm.init_rank || !g_comm.all_reduce || !g_comm.destroy)
@@ -96,6 +105,43 @@ extern "C" int cb_allreduce_bucket(void* buf, int64_t count, int32_t dtype, void
     if (count == 0) return 0;
     const int rc = g_comm.all_reduce(buf, buf, (size_t)count, dtype == CB_F32 ? 7 : 9, 0, g_comm.comm, cb_stream(stream));
     if (rc != 0) return rccl_fail("cb_allreduce_bucket", rc);
+    return 0;
+}
+
+// Reduce-scatter + all-gather: the two halves of an all-reduce with room for work in between (the optimizer on 1/world of the
+// parameters).  On the point-to-point xGMI mesh both run as direct exchanges over all links.
+// cb_reduce_scatter_bucket: rank r receives, in recv, the sum over ranks of elements [r*recv_count, (r+1)*recv_count) of every rank's
+// send (send holds world * recv_count elements; recv may be send + rank * recv_count: in place).
+// cb_allgather_bucket: every rank contributes send_count elements; recv (world * send_count elements) gets rank r's at offset
+// r * send_count (send may be recv + rank * send_count: in place).
+extern "C" int cb_reduce_scatter_bucket(const void* send, void* recv, int64_t recv_count, int32_t dtype, void* stream) {
+    CB_REQUIRE(g_comm.comm, "cb_reduce_scatter_bucket: cb_comm_init has not been called");
+    CB_REQUIRE(g_comm.reduce_scatter, "cb_reduce_scatter_bucket: this RCCL has no ncclReduceScatter");
+    CB_REQUIRE(send && recv && recv_count >= 0 && (dtype == CB_F32 || dtype == CB_BF16), "cb_reduce_scatter_bucket: bad arguments");
+    if (recv_count == 0) return 0;
+    const int rc = g_comm.reduce_scatter(send, recv, (size_t)recv_count, dtype == CB_F32 ? 7 : 9, 0, g_comm.comm, cb_stream(stream));
+    if (rc != 0) return rccl_fail("cb_reduce_scatter_bucket", rc);
+    return 0;
+}
+
+extern "C" int cb_allgather_bucket(const void* send, void* recv, int64_t send_count, int32_t dtype, void* stream) {
+    CB_REQUIRE(g_comm.comm, "cb_allgather_bucket: cb_comm_init has not been called");
+    CB_REQUIRE(g_comm.all_gather, "cb_allgather_bucket: this RCCL has no ncclAllGather");
+    CB_REQUIRE(send && recv && send_count >= 0 && (dtype == CB_F32 || dtype == CB_BF16), "cb_allgather_bucket: bad arguments");
+    if (send_count == 0) return 0;
+    const int rc = g_comm.all_gather(send, recv, (size_t)send_count, dtype == CB_F32 ? 7 : 9, g_comm.comm, cb_stream(stream));
+    if (rc != 0) return rccl_fail("cb_allgather_bucket", rc);
+    return 0;
+}
+
+// hvd.broadcast_parameters (run_video_retrieval.py:304): root's buffer to every rank, in place
+extern "C" int cb_broadcast_bucket(void* buf, int64_t count, int32_t dtype, int32_t root, void* stream) {
+    CB_REQUIRE(g_comm.comm, "cb_broadcast_bucket: cb_comm_init has not been called");
+    CB_REQUIRE(g_comm.broadcast, "cb_broadcast_bucket: this RCCL has no ncclBroadcast");
+    CB_REQUIRE(buf && count >= 0 && (dtype == CB_F32 || dtype == CB_BF16) && root >= 0 && root < g_comm.world, "cb_broadcast_bucket: bad arguments");
+    if (count == 0) return 0;
+    const int rc = g_comm.broadcast(buf, buf, (size_t)count, dtype == CB_F32 ? 7 : 9, root, g_comm.comm, cb_stream(stream));
+    if (rc != 0) return rccl_fail("cb_broadcast_bucket", rc);
     return 0;
 }
 

@@ -67,6 +67,36 @@ class NativeComm:
         _lib.check(_lib.get().cb_allreduce_bucket(t.data_ptr(), t.numel(), dtype_code(t.dtype), st.cuda_stream), "cb_allreduce_bucket")
         return t
 
+    def reduce_scatter_(self, t: torch.Tensor, stream=None) -> torch.Tensor:
+        """in place: t holds world equal shards; returns the view of THIS rank's shard, which receives the sum over the ranks"""
+        from . import _lib
+        from .ops import dtype_code
+        assert t.is_cuda and t.is_contiguous() and t.numel() % self.world == 0
+        n = t.numel() // self.world
+        mine = t[self.rank * n:(self.rank + 1) * n]
+        st = stream if stream is not None else torch.cuda.current_stream(t.device)
+        _lib.check(_lib.get().cb_reduce_scatter_bucket(t.data_ptr(), mine.data_ptr(), n, dtype_code(t.dtype), st.cuda_stream), "cb_reduce_scatter_bucket")
+        return mine
+
+    def all_gather_(self, t: torch.Tensor, stream=None) -> torch.Tensor:
+        """in place: every rank's shard of t (its 1/world slice) is delivered to all ranks"""
+        from . import _lib
+        from .ops import dtype_code
+        assert t.is_cuda and t.is_contiguous() and t.numel() % self.world == 0
+        n = t.numel() // self.world
+        st = stream if stream is not None else torch.cuda.current_stream(t.device)
+        _lib.check(_lib.get().cb_allgather_bucket(t.data_ptr() + self.rank * n * t.element_size(), t.data_ptr(), n, dtype_code(t.dtype),
+                                                  st.cuda_stream), "cb_allgather_bucket")
+        return t
+
+    def broadcast_(self, t: torch.Tensor, root: int = 0, stream=None) -> torch.Tensor:
+        from . import _lib
+        from .ops import dtype_code
+        assert t.is_cuda and t.is_contiguous()
+        st = stream if stream is not None else torch.cuda.current_stream(t.device)
+        _lib.check(_lib.get().cb_broadcast_bucket(t.data_ptr(), t.numel(), dtype_code(t.dtype), root, st.cuda_stream), "cb_broadcast_bucket")
+        return t
+
     @classmethod
     def destroy(cls):
         from . import _lib

@@ -307,6 +307,15 @@ int cb_comm_unique_id(void* id128);
 int cb_comm_init(int32_t rank, int32_t world, const void* id128);
 int cb_comm_info(int32_t* rank, int32_t* world);
 int cb_allreduce_bucket(void* buf, int64_t count, int32_t dtype, void* stream);
+/* The two halves of an all-reduce (direct reduce-scatter + all-gather over the xGMI mesh), so that the optimizer can
+ * run on 1/world of the parameters in between.  cb_reduce_scatter_bucket: `send` holds world * recv_count elements; rank r receives
+ * the sum over ranks of elements [r * recv_count, (r+1) * recv_count) in `recv` (recv == send + r * recv_count: in place).
+ * cb_allgather_bucket: every rank contributes send_count elements, `recv` (world * send_count) gets rank r's at r * send_count
+ * (send == recv + rank * send_count: in place).  cb_broadcast_bucket: root's buffer to all ranks (hvd.broadcast_parameters,
+ * run_video_retrieval.py:304).  Same stream / capture rules as cb_allreduce_bucket. */
+int cb_reduce_scatter_bucket(const void* send, void* recv, int64_t recv_count, int32_t dtype, void* stream);
+int cb_allgather_bucket(const void* send, void* recv, int64_t send_count, int32_t dtype, void* stream);
+int cb_broadcast_bucket(void* buf, int64_t count, int32_t dtype, int32_t root, void* stream);
 int cb_comm_destroy(void);
 
 #ifdef __cplusplus

@@ -158,8 +158,11 @@ def main():
         # CB_BENCH_DRY_DP=N (single process): the N-rank replay plan with every collective skipped -- times what data parallelism
         # costs a rank besides link time (three graphs instead of one, wire casts, bf16-direct AdamW).  A diagnostic, not the metric.
         dry_dp = int(os.environ.get("CB_BENCH_DRY_DP", "0")) if world == 1 else 0
+        # CB_BENCH_LOOPBACK=1 (single process): the N-rank plan with REAL cb_allreduce_bucket calls on a world-size-1 communicator,
+        # captured into the step's hipGraph -- shows that the whole exchange is capturable; a diagnostic, not the metric.
+        loopback = world == 1 and not dry_dp and os.environ.get("CB_BENCH_LOOPBACK") == "1"
         sync = GradSync(bank, compress=None if os.environ.get("CB_BENCH_FP32_WIRE") == "1" else "bf16",
-                        comm="native" if (os.environ.get("CB_COMM") == "native" and backend == "nccl") else "torch", pretend_world=dry_dp)
+                        comm=os.environ.get("CB_COMM", "auto"), pretend_world=dry_dp, loopback=loopback)   # auto: the library's own RCCL entry points on "nccl"
         sync.broadcast_parameters(0)
         opt = FusedAdamW(bank, lr=5e-5, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0)
     state = {"global_step": 0}
@@ -270,7 +273,7 @@ def main():
         eager_fn = forward_only_step
     else:
         sync.set_cnn_split(M.cnn_early_split(model))           # grid_encoder + res5 gradients can leave before res4 / res3 are done
-        if world > 1:
+        if world > 1 or sync.loopback:
             model.rt.after_encoder_backward = sync.reduce_transformer
             model.rt.after_res5_backward = sync.reduce_cnn_early
         eager_fn = train_step_eager
@@ -319,6 +322,29 @@ def main():
     elif use_graph and not train:
         g1, loss = capture(forward_only_step)
         run, plan, n_graphs = g1.replay, "one hipGraph", 1
+    elif use_graph and train and sync.active and not sync.dry and sync.carrier == "native" and (plan_env == "captured" or sync.loopback):
+        # ONE hipGraph for the whole data-parallel step: the bucket all-reduces (cb_allreduce_bucket on GradSync's comm stream,
+        # forked / joined by events) are captured with the kernels -- no host between the backward and the collectives.  Opt-in
+        # for N > 1 (CB_BENCH_PLAN=captured) until it has run on a multi-GPU node; the loopback run exercises it on one GPU.
+        def device_step_dp():
+            opt.zero_grad(lazy=True)
+            model.rt.pending_encoder_nodes = model.rt.pending_cnn_nodes = 0
+            loss_ = forward_loss()
+            loss_.backward(one)                    # the hooks issue the transformer / grid_encoder + res5 buckets from inside
+            if model.rt.after_encoder_backward is None:
+                sync.reduce_transformer()
+            sync.reduce_cnn()
+            g16 = sync.wire_gradients()
+            sync.wait(cast_back=g16 is None)
+            ops.counter_add(model.rt.seed_dev)
+            opt.launch(grad16=g16)
+            return loss_
+        g1, loss = capture(device_step_dp)
+
+        def run_dp():
+            host_prepare()
+            g1.replay()
+        run, plan, n_graphs = run_dp, "eager hyper-parameter upload + one hipGraph with the bucketed bf16 all-reduces captured inside", 1
     elif use_graph and world == 1 and not (train and sync.dry):
         g1, loss = capture(device_step_chains if chains > 1 else device_step_single)
 
@@ -464,11 +490,14 @@ def main():
         "config": {"workload": workload, "mode": args.mode, "videos_per_gpu": bv, "n_clips": nclip, "n_frames": T, "img_size": args.size,
                    "txt_len": args.txt_len, "texts_per_video": rep, "pairs_per_gpu": pairs, "score_agg_func": args.pool, "clips_folded": fold,
                    "input": "uint8 frames in HBM",
-                   "parallelism": f"dp{world}" + (f" (DRY RUN of the dp{sync.world} plan on one GPU: no collectives)" if (train and sync is not None and sync.dry) else ""), "hip_graph": use_graph, "replay_plan": plan, "n_graphs": n_graphs,
+                   "parallelism": f"dp{world}" + (f" (DRY RUN of the dp{sync.world} plan on one GPU: no collectives)" if (train and sync is not None and sync.dry) else "")
+                   + (" (LOOPBACK: the dp plan with world-size-1 RCCL collectives)" if (train and sync is not None and sync.loopback) else ""), "hip_graph": use_graph, "replay_plan": plan, "n_graphs": n_graphs,
                    "dropout": bool(train), "final_loss": None if final_loss is None else round(final_loss, 5)},
     }
     if dp_check is not None:
         out["config"]["dp_self_check"] = dp_check
+    if train and sync is not None and sync.active and not sync.dry:
+        out["config"]["grad_exchange"] = f"{sync.carrier} ({'cb_allreduce_bucket: RCCL behind the C ABI' if sync.carrier == 'native' else 'torch.distributed ' + backend}), bf16 wire, 64 MiB buckets"
     if gathered is not None:
         out["config"]["rows_gathered"] = len(gathered)
     if rank == 0 and world == 1 and not args.no_roofline:

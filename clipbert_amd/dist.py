@@ -110,15 +110,18 @@ class GradSync:
     reference's apex-O2 gradients are fp16 on the wire too): cast -> all-reduce -> cast back, three passes over the flat
     buffer (~0.3 ms) against ~1.5 ms of link time saved on 8 GPUs."""
 
-    def __init__(self, bank: ParamBank, group=None, bucket_bytes: int = 64 << 20, compress: Optional[str] = None, comm: str = "torch",
-                 pretend_world: int = 0):
+    def __init__(self, bank: ParamBank, group=None, bucket_bytes: int = 64 << 20, compress: Optional[str] = None, comm: str = "auto",
+                 pretend_world: int = 0, loopback: bool = False):
         """bucket_bytes: fp32 gradient bytes per all-reduce (0 = one collective per range).  The default 64 MiB (32 MiB on
         the wire in bf16) lets the cast of bucket i+1 run while bucket i is on the links, and keeps each collective well
         past the ~8 MiB where RCCL's ring reaches its link bandwidth."""
-        assert compress in (None, "bf16") and comm in ("torch", "native")
+        assert compress in (None, "bf16") and comm in ("auto", "torch", "native")
         # comm="native": the buckets go through cb_allreduce_bucket (RCCL called by the library) on this object's own HIP stream,
-        # ordered against the compute stream by events; "torch": torch.distributed all_reduce(async_op=True) (also the CPU / gloo path)
+        # ordered against the compute stream by events; "torch": torch.distributed all_reduce(async_op=True) (also the CPU / gloo path).
+        # "auto" (default): native when the process group is RCCL ("nccl") and the gradients live on a GPU -- if the library's
+        # communicator cannot be created the process group carries the buckets instead (self.carrier says which one runs).
         self.native = None
+        self.carrier = "torch"
         self.bank = bank
         bank.clients += 1
         self.group = group
@@ -128,6 +131,9 @@ class GradSync:
         self.dry = pretend_world > 1 and self.world == 1
         if self.dry:
             self.world = pretend_world
+        # loopback (single process, one GPU): the complete N-rank plan with REAL collectives on a world-size-1 communicator of the
+        # library -- every cb_allreduce_bucket is issued (and can be captured into a hipGraph) although it adds nothing
+        self.loopback = bool(loopback) and self.world == 1 and not self.dry
         t_end = bank.group_range[3][1]
         self.t_range = (0, t_end)
         self.c_range = (t_end, bank.n_train)
@@ -140,10 +146,20 @@ class GradSync:
         self.c_early: List = []             # set_cnn_split(): sub-ranges of the CNN range whose gradients are final early
         self.late_ranges = 0                # ranges wait() had to send itself because nobody reduced them (diagnostic)
         self._epoch_done = getattr(bank, "grad_epoch", 0)    # bank.grad_epoch (one per zero_grad) of the last completed exchange
-        if comm == "native" and self.world > 1:
+        want_native = comm == "native" or (comm == "auto" and dist.is_initialized() and bank.grad.is_cuda and dist.get_backend(group) == "nccl")
+        want_native = want_native or self.loopback
+        if want_native and (self.world > 1 or self.loopback) and not self.dry:
             assert bank.grad.is_cuda, "comm='native' needs the gradients on a GPU"
-            self.native = NativeComm.from_process_group(group)
-            self.comm_stream = torch.cuda.Stream(device=bank.grad.device)
+            try:
+                self.native = NativeComm.from_process_group(group)
+                self.comm_stream = torch.cuda.Stream(device=bank.grad.device)
+                self.carrier = "native"
+            except Exception as e:                        # noqa: BLE001  (comm="native" was asked for explicitly: fail loudly)
+                if comm == "native" or self.loopback:
+                    raise
+                import warnings
+                warnings.warn(f"GradSync: the library's RCCL communicator could not be created ({e}); torch.distributed carries the buckets")
+                self.native = None
 
     @property
     def grad_scale(self) -> float:
@@ -156,7 +172,7 @@ class GradSync:
     def cast_range(self, a: int, b: int):
         """fp32 gradients [a, b) -> the bf16 wire image (no communication: capturable into a hipGraph, so that a replay plan can
         end each of its graphs with the cast of the range it just finished and issue only the collectives eagerly)."""
-        if self.world == 1 or b <= a or self.compress != "bf16":
+        if not self.active or b <= a or self.compress != "bf16":
             return
         from . import ops
         self._ensure_wire()
@@ -215,8 +231,13 @@ class GradSync:
         for a, b in (self._cnn_late() if late_only else [self.c_range]):
             self.cast_range(a, b)
 
+    @property
+    def active(self) -> bool:
+        """an exchange takes place (several ranks, the dry run of their plan, or the one-GPU loopback)"""
+        return self.world > 1 or self.loopback
+
     def _reduce(self, a: int, b: int, cast: bool = True):
-        if self.world == 1 or b <= a:
+        if not self.active or b <= a:
             return
         for s0, e0 in self._inflight:
             assert e0 <= a or b <= s0, (f"GradSync: gradients [{a}, {b}) are already being reduced ([{s0}, {e0})): "
@@ -268,7 +289,7 @@ class GradSync:
     def wire_gradients(self) -> Optional[torch.Tensor]:
         """The flat bf16 gradient image (valid after wait(cast_back=False) once BOTH ranges were reduced): hand it to
         FusedAdamW.step / launch(grad16=...) and the two cast-back passes over the 594 MB fp32 buffer disappear."""
-        return self._wire if (self.compress == "bf16" and self.world > 1) else None
+        return self._wire if (self.compress == "bf16" and self.active) else None
 
     def wait(self, cast_back: bool = True):
         """cast_back=False (bf16 wire only): leave the reduced gradients in the wire buffer for an optimizer that reads bf16
@@ -278,7 +299,7 @@ class GradSync:
         # -- including a step for which NO reduce_* was called at all (hooks not armed, caller forgot): the gradient epoch of the
         # bank (one per zero_grad) tells that case from a repeated wait() with nothing left to do
         epoch = getattr(self.bank, "grad_epoch", 0)
-        if self.world > 1 and (self._inflight or epoch != self._epoch_done):
+        if self.active and (self._inflight or epoch != self._epoch_done):
             for a, b in self._uncovered():
                 self.late_ranges += 1
                 self._reduce(a, b)
@@ -303,8 +324,12 @@ class GradSync:
 
     def broadcast_parameters(self, src: int = 0):
         """hvd.broadcast_parameters equivalent (run_video_retrieval.py:304): one flat buffer per kind."""
-        if self.world == 1 or self.dry:
+        if not self.active or self.dry:
             return
-        dist.broadcast(self.bank.master, src, group=self.group)
-        dist.broadcast(self.bank.f_master, src, group=self.group)
+        if self.native is not None:                      # cb_broadcast_bucket on the current stream
+            self.native.broadcast_(self.bank.master, src)
+            self.native.broadcast_(self.bank.f_master, src)
+        else:
+            dist.broadcast(self.bank.master, src, group=self.group)
+            dist.broadcast(self.bank.f_master, src, group=self.group)
         self.bank.sync_compute()

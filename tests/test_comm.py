@@ -56,3 +56,42 @@ def test_native_comm_world1_allreduce_and_graph_capture():
         torch.testing.assert_close(t32, (2 * r32 + 1) * 0.5, rtol=0, atol=1e-6)
     finally:
         NativeComm.destroy()
+
+
+@pytest.mark.gpu
+def test_native_reduce_scatter_allgather_broadcast_world1():
+    """The two halves of an all-reduce and the parameter broadcast (cb_reduce_scatter_bucket / cb_allgather_bucket /
+    cb_broadcast_bucket) on a world-size-1 communicator, in place, eager and captured: values come back unchanged and the calls are
+    stream-ordered work.  (Multi-rank: the driver's scaling run; the arithmetic of the exchange: tests/test_dp_gloo.py.)"""
+    from clipbert_amd.dist import NativeComm
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    comm = NativeComm.from_process_group()
+    try:
+        g = torch.Generator(device="cpu").manual_seed(1)
+        t16 = torch.randn(1 << 18, generator=g).bfloat16().to(dev)
+        t32 = torch.randn(1 << 18, generator=g).to(dev)
+        r16, r32 = t16.clone(), t32.clone()
+        mine = comm.reduce_scatter_(t16)
+        assert mine.data_ptr() == t16.data_ptr() and mine.numel() == t16.numel()      # world 1: the shard is the whole bucket
+        comm.all_gather_(t16)
+        comm.reduce_scatter_(t32)
+        comm.all_gather_(t32)
+        comm.broadcast_(t32, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(t16, r16) and torch.equal(t32, r32)
+        graph = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                t32.add_(1.0)
+                comm.reduce_scatter_(t32)
+                t32.mul_(2.0)                             # "the optimizer on the shard"
+                comm.all_gather_(t32)
+            graph.replay()
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(t32, (r32 + 1) * 2, rtol=0, atol=1e-6)
+    finally:
+        NativeComm.destroy()

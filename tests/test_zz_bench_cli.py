@@ -54,3 +54,18 @@ def test_two_rank_dry_run_on_one_gpu(mode):
         assert out["config"]["n_graphs"] in (1, 2, 3, 4) and out["config"]["hip_graph"] is True      # machine fields only: never prose
     else:
         assert out["config"]["rows_gathered"] == 2 * 2 * 64       # 2 ranks x 2 timed steps x 64 captions
+
+
+@pytest.mark.gpu
+def test_loopback_plan_captures_the_collectives_of_the_full_step():
+    """the library's own RCCL entry point (cb_allreduce_bucket) inside the hipGraph of the FULL training step --
+    bench.py's data-parallel plan on one GPU with a world-size-1 communicator (CB_BENCH_LOOPBACK=1): one graph, no eager collective."""
+    env = dict(os.environ, CB_BENCH_LOOPBACK="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    cfg = out["config"]
+    assert cfg["n_graphs"] == 1 and cfg["hip_graph"] is True and "LOOPBACK" in cfg["parallelism"]
+    assert cfg["grad_exchange"].startswith("native")
+    assert out["value"] > 0 and 0.0 < cfg["final_loss"] < 5.0

@@ -1,7 +1,17 @@
 import csv, json, sys, collections
 calls = json.load(open(sys.argv[1])); rows = list(csv.DictReader(open(sys.argv[2])))
-g = [r for r in rows if "gemm" in r["Kernel_Name"] and "pixel_table" not in r["Kernel_Name"]]
-g.sort(key=lambda r: int(r["Start_Timestamp"]))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# one entry per cb_gemm call: its kernel (4-wave gemm_kernel / gemm_dma_kernel or 8-wave gemm8_kernel); the split-K reduce kernel that
+# follows an 8-wave launch belongs to the same call (its signature mentions cbgemm::GP: match on the kernel's own name)
+g = []
+for r in rows:
+    name = r["Kernel_Name"]
+    if "splitk_reduce_kernel" in name:
+        if g:
+            g[-1]["End_Timestamp"] = str(int(g[-1]["End_Timestamp"]) + int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        continue
+    if "gemm_kernel" in name or "gemm8_kernel" in name or "gemm_dma_kernel" in name:
+        g.append(dict(r))
 g = g[-len(calls):]
 agg = collections.defaultdict(lambda: [0.0, 0.0, 0])
 for c, r in zip(calls, g):

@@ -30,7 +30,14 @@ def main():
     write = per_dispatch(sys.argv[3], "WRITE_SIZE")
 
     def gemms(d):
-        g = [x for x in d if "gemm" in x[0] and "pixel_table" not in x[0]]
+        # one entry per cb_gemm call; the split-K reduce kernel that follows an 8-wave launch is part of that call
+        g = []
+        for name, val in d:
+            if "splitk_reduce_kernel" in name:
+                if g:
+                    g[-1][1] += val
+            elif "gemm_kernel" in name or "gemm8_kernel" in name or "gemm_dma_kernel" in name:
+                g.append([name, val])
         return g[-len(calls):]
     gf, gw = gemms(fetch), gemms(write)
     assert len(gf) == len(calls) == len(gw), (len(gf), len(gw), len(calls))

@@ -347,6 +347,13 @@ def main():
         run, plan, n_graphs = run_dp, "eager hyper-parameter upload + one hipGraph with the bucketed bf16 all-reduces captured inside", 1
     elif use_graph and world == 1 and not (train and sync.dry):
         g1, loss = capture(device_step_chains if chains > 1 else device_step_single)
+        if os.environ.get("CB_BENCH_TUNE") and train and chains == 1:
+            # tools/tune_instep.py: launch configurations judged by the whole captured step (a tuning run, not a measurement)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import tune_instep
+            tune_instep.run(lambda: capture(device_step_single)[0], host_prepare, os.environ["CB_BENCH_TUNE"],
+                            os.environ.get("CB_BENCH_TUNE_CAND", os.path.join(ROOT, "profiles", "r03f_gemm_tuning_cold.json")), mode=args.mode)
+            g1, loss = capture(device_step_single)
 
         def run_single():
             host_prepare()

@@ -277,6 +277,12 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
 
     // ---- 4-wave kernels
     p.split_k = split_caller;
+    {   // a split asked for WITH an 8-wave tile means "through slabs": if this problem ended up here (shape not covered, no workspace) the
+        // split only survives where the atomics path can take it (fp32 C accumulated in place, scale/alpha-only epilogue)
+        const bool atomics_ok = d->c_f32 && d->accumulate && !d->C2 && !d->residual && !d->mask && !d->gelu_grad_pre && d->act == CB_ACT_NONE &&
+                                !d->relu_after && !d->shift && d->dropout_p <= 0.f;
+        if (d->tile >= 5 && p.split_k > 1 && !atomics_ok) p.split_k = 1;
+    }
     if (split_tuned > 0 && d->tile == 0 && d->a_mode == CB_KROW && d->c_f32 && d->accumulate && !d->C2 && !d->residual &&
         !d->mask && !d->gelu_grad_pre && d->act == CB_ACT_NONE && !d->relu_after && !d->shift && d->dropout_p <= 0.f)
         p.split_k = split_tuned;       // weight-gradient form (plain epilogue, fp32 C accumulated in place: any K split is valid): the measured best

@@ -86,6 +86,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch
     d.dropout_p = dropout_p
     d.dropout_seed = dropout_seed
     d.dropout_seed_ptr = _ptr(seed_ptr)
+    if tile == 0 and _LAUNCH_OVERRIDE:       # tools/tune_instep.py: a launch configuration under test for this problem shape
+        ov = _LAUNCH_OVERRIDE.get((a_mode, b_mode, M, N, K, batch, R * S, split_k))
+        if ov is not None:
+            tile, xcd_order, schedule = ov[0], ov[1], ov[3]
+            d.split_k = ov[2] if ov[2] > 0 else split_k
     d.tile = tile
     d.schedule = schedule
     d.xcd_order = xcd_order
@@ -110,6 +115,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch
     return out
 
 
+_LAUNCH_OVERRIDE = {}                  # (a_mode, b_mode, M, N, K, batch, taps, split_k) -> (tile, xcd_order, split_k, schedule); tuning only
 _SPLITK_WS = {}
 _SPLITK_OFF = False                    # set while launches go to a SIDE stream (Runtime.side): the buffer belongs to the main stream's launches
 SPLITK_WS_BYTES = 128 << 20

@@ -10,6 +10,32 @@ import sys
 
 def gemm_name(n):
     """readable name of a cb_gemm instantiation from its (possibly half-demangled) symbol"""
+    if "splitk_reduce_kernel" in n:
+        return "cb_gemm split-K reduce (slabs -> epilogue)"
+    d8 = re.search(r"gemm8_kernel<(\d+), (\d+), \d+, \d+, \d+, (\d), cbgemm::(\w+)<\d+, (\w+)>, cbgemm::(\w+)<\d+, (\w+)>, (\w+)>", n)
+    if d8:                                                 # demangled form (rocprofv3 7.x)
+        bm, bn, sched, ka, aa, kb, ab, rs = d8.groups()
+        if ka == "RowkDma8" and kb == "RowkDma8":
+            form = "fwd conv (pixel gather)" if aa == "true" else "fwd linear / 1x1 conv"
+        elif ka == "RowkDma8":
+            form = "dgrad 3x3 conv (pixel gather x flipped taps)" if aa == "true" else "dgrad linear / 1x1 conv"
+        else:
+            form = "wgrad conv (pixel gather)" if ab == "2" else ("wgrad linear / 1x1 conv + bias row sums" if rs == "true" else "wgrad linear / 1x1 conv")
+        return f"cb_gemm 8-wave {bm}x{bn} bf16 LDS-DMA (schedule {sched}): {form}"
+    m8 = re.search(r"gemm8_kernelILi(\d+)ELi(\d+)ELi\d+ELi\d+ELi\d+ELi(\d)E(.*)", n)
+    if m8:
+        rest = m8.group(4)
+        loaders = re.findall(r"(RowkDma8|KrowDma8)ILi\d+EL([bi])(\d)", rest)
+        if len(loaders) == 1:                              # second loader abbreviated as a substitution (same template, other arguments)
+            loaders = loaders * 2
+        (ka, _ta, aa), (kb, _tb, ab) = (loaders + [("?", "", "0")] * 2)[:2]
+        if ka == "RowkDma8" and kb == "RowkDma8" and "RowkDma8" in rest and "KrowDma8" not in rest:
+            form = "fwd conv (pixel gather)" if aa == "1" else "fwd linear / 1x1 conv"
+        elif ka == "RowkDma8":
+            form = "dgrad 3x3 conv (pixel gather x flipped taps)" if aa == "1" else "dgrad linear / 1x1 conv"
+        else:
+            form = "wgrad conv (pixel gather)" if re.search(r"(KrowDma8|NS1_)ILi\d+ELi2E", rest) else "wgrad linear / 1x1 conv (+ bias row sums)"
+        return f"cb_gemm 8-wave {m8.group(1)}x{m8.group(2)} bf16 LDS-DMA (schedule {m8.group(3)}): {form}"
     if "gemm_kernel" not in n and "gemm_dma_kernel" not in n:
         return None
     m = re.search(r"gemm_dma_kernelILi(\d+)ELi(\d+)E", n)

@@ -73,6 +73,7 @@ __device__ __forceinline__ PMV adamw_one(float p, float g, float m, float v, flo
 template <typename G>
 __global__ void __launch_bounds__(256) adamw_kernel(float* p, const G* g, float* m, float* v, bf16* w16, int64_t n,
                                                     const float* hp, const float* sq_sum) {
+    if (hp[CB_HP_SKIP] != 0.f) return;                   // (block-uniform: every thread reads the same word)
     const float lr = hp[CB_HP_LR], b1 = hp[CB_HP_BETA1], b2 = hp[CB_HP_BETA2], eps = hp[CB_HP_EPS];
     const float wd = hp[CB_HP_WD], max_norm = hp[CB_HP_MAX_NORM];
     const float step_size = lr * sqrtf(hp[CB_HP_BC2]) / hp[CB_HP_BC1];

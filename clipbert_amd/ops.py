@@ -383,7 +383,7 @@ def sq_sum(g, out, ws=None):
 
 def adamw_hyper(lr, beta1, beta2, eps, weight_decay, step, max_norm=-1.0, grad_scale=1.0):
     """Host-side packing of the CB_HP_* array (see include/clipbert_hip.h)."""
-    return [lr, beta1, beta2, eps, weight_decay, 1.0 - beta1 ** step, 1.0 - beta2 ** step, max_norm, grad_scale, 0.0]
+    return [lr, beta1, beta2, eps, weight_decay, 1.0 - beta1 ** step, 1.0 - beta2 ** step, max_norm, grad_scale, 0.0, 0.0]
 
 
 def adamw(p, g, m, v, w16, hyper_dev, grad_sq_sum=None):

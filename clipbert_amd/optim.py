@@ -11,7 +11,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import ops
-from ._lib import HP_COUNT
+from ._lib import HP_COUNT, HP_SKIP
 from .params import N_GROUPS, ParamBank
 
 
@@ -80,6 +80,11 @@ class FusedAdamW:
             self._hp_host = self._hp_host.pin_memory()
         self._hp_events = [None, None]
         self._hp_dev = torch.zeros(N_GROUPS, 16, dtype=torch.float32, device=dev)
+        # hyper-parameters of the PREVIOUS step (launch(prev=True): an update deferred into the next step's graph); until a step
+        # exists behind it the skip flag makes that launch a no-op
+        self._hp_dev_prev = torch.zeros(N_GROUPS, 16, dtype=torch.float32, device=dev)
+        self._hp_dev_prev[:, HP_SKIP] = 1.0
+        self.deferred_pending = False        # an update of some groups has been left to the next step (flush with launch(..., reuse_norm=True))
         self._sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._sq_ws = torch.zeros(1024, dtype=torch.float32, device=dev)     # partials of the order-independent norm reduction
         self._last_scale = 1.0
@@ -97,6 +102,10 @@ class FusedAdamW:
         if self._hp_dev.is_cuda and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("FusedAdamW.prepare_step() inside a hipGraph capture: capture launch() only and call "
                                "prepare_step() eagerly before each replay (see INTEGRATION.md)")
+        if self.step_count > 0:
+            self._hp_dev_prev.copy_(self._hp_dev)              # D2D, stream-ordered before the upload below overwrites _hp_dev
+        if not self.deferred_pending:                          # nothing was left behind by the step before: a launch(prev=True) is a no-op
+            self._hp_dev_prev[:, HP_SKIP] = 1.0
         self.step_count += 1
         self._last_scale = grad_scale
         slot = self.step_count & 1
@@ -107,7 +116,7 @@ class FusedAdamW:
         for g, pg in enumerate(self.param_groups):
             hp = ops.adamw_hyper(pg["lr"], self.betas[0], self.betas[1], self.eps, pg["weight_decay"], self.step_count,
                                  self.max_grad_norm, grad_scale)
-            host[g, :HP_COUNT + 1] = torch.tensor(hp[:HP_COUNT + 1])
+            host[g, :HP_COUNT] = torch.tensor(hp[:HP_COUNT])
         self._hp_dev.copy_(host, non_blocking=True)
         if self._hp_dev.is_cuda:
             ev = torch.cuda.Event()
@@ -115,27 +124,36 @@ class FusedAdamW:
             self._hp_events[slot] = ev
 
     @torch.no_grad()
-    def launch(self, grad16: Optional[torch.Tensor] = None):
+    def launch(self, grad16: Optional[torch.Tensor] = None, groups: Optional[Sequence[int]] = None, prev: bool = False,
+               reuse_norm: bool = False):
         """Device half of a step (capturable): global grad-norm reduction, then clip + AdamW + bf16 weight refresh, reading
         the hyper-parameters from the device array prepare_step() filled.  ``grad16``: consume these bf16 gradients (flat, same
-        layout as bank.grad -- GradSync's reduced wire image, ``sync.wire_gradients()``) instead of the fp32 buffer."""
+        layout as bank.grad -- GradSync's reduced wire image, ``sync.wire_gradients()``) instead of the fp32 buffer.
+
+        Software-pipelined update (bench.py's one-GPU plan): ``groups`` restricts the launch to some of the 8 parameter groups --
+        e.g. the CNN groups (4-7) at the end of step i, and the transformer groups (0-3) at the START of step i+1's graph with
+        ``prev=True`` (hyper-parameters of step i) and ``reuse_norm=True`` (the norm step i computed over ALL gradients), on a side
+        stream beside the ResNet forward, which only reads CNN weights.  Same arithmetic, same order per parameter; a no-op until a
+        step exists behind it (CB_HP_SKIP).  The caller zeroes each half of the gradients after its update (ParamBank.zero_grad_range)."""
         bank = self.bank
-        if getattr(bank, "lazy_fresh", False):
+        if getattr(bank, "lazy_fresh", False) and not prev:
             raise RuntimeError("FusedAdamW: zero_grad(lazy=True) was not followed by an encoder backward -- the encoder weight "
                                "gradients were never written")
         sq = None
         if self.max_grad_norm > 0:
-            self._sq.zero_()
-            src = bank.grad if grad16 is None else grad16
-            ops.sq_sum(src[:bank.n_train], self._sq, self._sq_ws)           # deterministic: ranks must derive the same clip coefficient
+            if not reuse_norm:
+                self._sq.zero_()
+                src = bank.grad if grad16 is None else grad16
+                ops.sq_sum(src[:bank.n_train], self._sq, self._sq_ws)       # deterministic: ranks must derive the same clip coefficient
             sq = self._sq
+        hp_dev = self._hp_dev_prev if prev else self._hp_dev
         for g, pg in enumerate(self.param_groups):
             a, b = pg["range"]
-            if b <= a:
+            if b <= a or (groups is not None and g not in groups):
                 continue
             w16 = bank.w16[a:b] if bank.w16 is not None else None
             gsrc = bank.grad if grad16 is None else grad16
-            ops.adamw(bank.master[a:b], gsrc[a:b], bank.exp_avg[a:b], bank.exp_avg_sq[a:b], w16, self._hp_dev[g], sq)
+            ops.adamw(bank.master[a:b], gsrc[a:b], bank.exp_avg[a:b], bank.exp_avg_sq[a:b], w16, hp_dev[g], sq)
 
     def step(self, grad_scale: float = 1.0, grad16: Optional[torch.Tensor] = None):
         """grad_scale multiplies the gradients first (1/world_size after a SUM all-reduce)."""
@@ -151,6 +169,9 @@ class FusedAdamW:
         """{"state": {parameter name: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...], "step": n}: moments in the
         parameters' LOGICAL shapes (OIHW for convs), keyed by name so that the file does not depend on the flat layout."""
         bank = self.bank
+        if self.deferred_pending:
+            raise RuntimeError("FusedAdamW.state_dict(): an update deferred to the next step is pending -- flush it first "
+                               "(launch(groups=..., reuse_norm=True); deferred_pending = False)")
         state = {}
         for name, p in bank._trainable:
             off = bank.offset[id(p)]

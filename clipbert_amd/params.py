@@ -199,6 +199,20 @@ class ParamBank:
             self.grad.zero_()
             self.lazy_fresh = False
 
+    def zero_grad_range(self, lo: int, hi: int, lazy: bool = False):
+        """zero_grad restricted to [lo, hi) of the flat gradient buffer (a step whose halves are zeroed at different points, see
+        FusedAdamW.launch(groups=...)); ``lazy`` as in zero_grad: the lazy span is skipped.  Does not start a new gradient epoch."""
+        span = getattr(self, "lazy_span", None) if lazy else None
+        if span is None or span[1] <= lo or span[0] >= hi:
+            if hi > lo:
+                self.grad[lo:hi].zero_()
+            return
+        a, b = max(span[0], lo), min(span[1], hi)
+        if a > lo:
+            self.grad[lo:a].zero_()
+        if hi > b:
+            self.grad[b:hi].zero_()
+
     def take_fresh(self) -> bool:
         """True once after zero_grad(lazy=True): the lazy span holds stale values and must be overwritten (or zeroed) now"""
         fresh = getattr(self, "lazy_fresh", False)

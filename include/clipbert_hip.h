@@ -244,7 +244,8 @@ int cb_adamw(float* p, const float* g, float* m, float* v, void* w16, int64_t n,
 /* hyper: DEVICE array of CB_HP_COUNT floats (so a captured hipGraph sees new values each replay):
  * [lr, beta1, beta2, eps, weight_decay, 1-beta1^t, 1-beta2^t, max_norm, grad_scale] */
 enum { CB_HP_LR = 0, CB_HP_BETA1, CB_HP_BETA2, CB_HP_EPS, CB_HP_WD, CB_HP_BC1, CB_HP_BC2, CB_HP_MAX_NORM,
-       CB_HP_GRAD_SCALE, CB_HP_COUNT };
+       CB_HP_GRAD_SCALE, CB_HP_SKIP /* != 0: the launch does nothing (a captured, software-pipelined update with no step behind it) */,
+       CB_HP_COUNT };
 /* y = x * inverted-dropout mask(seed + *seed_ptr, index)  (forward and backward of nn.Dropout). */
 int cb_dropout(int32_t dtype, const void* x, void* y, int64_t n, float p, uint64_t seed,
                const uint64_t* seed_ptr, void* stream);

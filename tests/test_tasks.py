@@ -248,3 +248,36 @@ def test_lazy_zero_grad_first_writer_stores(hw):
     with pytest.raises(RuntimeError):
         opt.step()                                             # no backward wrote the span
     opt.zero_grad()
+
+
+def test_pipelined_optimizer_update_equals_plain_update(hw):
+    """FusedAdamW.launch(groups=..., prev=True, reuse_norm=True): the CNN groups at the end of a step and the transformer groups
+    deferred to the start of the next one (bench.py's software-pipelined plan) give bit-identical parameters / moments to one plain
+    launch per step; a deferred launch with no step behind it is a no-op."""
+    from clipbert_amd import optim
+    from test_model_small import build
+    res = []
+    for pipelined in (False, True):
+        cfg, sd, model = build("retrieval", dict(num_labels=2, loss_type="ce", margin=0.1), torch.float32, hw.dev)
+        bank = model.rt.bank
+        opt = optim.FusedAdamW(bank, lr=1e-2, betas=(0.9, 0.98), weight_decay=1e-3, cnn_lr=5e-3, max_grad_norm=0.5)
+        g = torch.Generator().manual_seed(3)
+        t_end = bank.group_range[3][1]
+        for step in range(3):
+            grads = torch.randn(bank.grad.numel(), generator=g).to(hw.dev)
+            if pipelined:
+                opt.prepare_step()
+                opt.launch(groups=(0, 1, 2, 3), prev=True, reuse_norm=True)      # the previous step's transformer half (step 0: skipped)
+                bank.grad.copy_(grads)
+                opt.launch(groups=(4, 5, 6, 7))                                  # norm over ALL gradients, CNN half
+                opt.deferred_pending = True
+            else:
+                bank.grad.copy_(grads)
+                opt.step()
+        if pipelined:
+            opt.launch(groups=(0, 1, 2, 3), reuse_norm=True)                     # flush
+            opt.deferred_pending = False
+        res.append((bank.master.clone().cpu(), bank.exp_avg.clone().cpu(), bank.exp_avg_sq.clone().cpu()))
+        assert t_end > 0 and bank.n_train > t_end
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

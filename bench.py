@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak (2:1 sparsity excluded)
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 
 BASE_CONFIG = dict(
     max_temporal_position_embeddings=100, backbone_channel_in_size=2048, max_grid_row_position_embeddings=100,
@@ -582,6 +582,9 @@ def measure_roofline(step_fn, pmc_ok=True):
     """Durations of the cb_gemm kernels of the step, by kernel family, against the dense bf16 MFMA peak with their
     ALGORITHMIC flops (2*M*N*K per problem).
 
+    A family = all cb_gemm launches of one form (forward / data gradient / weight gradient, linear or implicit-GEMM conv), whichever
+    kernel template serves them (4-wave gemm_kernel, 8-wave gemm8_kernel + its split-K reduce).
+
     HIP events cost several microseconds each on this stack, so bracketing every ~20 us launch individually would
     measure the markers.  Instead one eager step is recorded (every cb_gemm call with its live operands), then each
     family's calls are replayed back to back -- captured in a hipGraph, `reps` times -- between ONE pair of HIP events
@@ -594,7 +597,7 @@ def measure_roofline(step_fn, pmc_ok=True):
     def logged(a, b, M, N, K, **kw):
         form = ("wgrad" if kw.get("a_mode", 0) == ops.KROW else ("dgrad" if kw.get("b_mode", 0) in (ops.KROW, ops.KROW_TAPS) else "fwd"))
         conv = kw.get("a_mode", 0) == ops.ROWK_GATHER or kw.get("b_mode", 0) == ops.KROW_GATHER
-        key = f"gemm_kernel<bf16> {form}{' (implicit-GEMM conv)' if conv else ''}"
+        key = f"cb_gemm<bf16> {form}{' (implicit-GEMM conv)' if conv else ''}"
         calls.append((key, 2.0 * M * N * K * kw.get("batch", 1), (a, b, M, N, K), kw))
         return orig(a, b, M, N, K, **kw)
 

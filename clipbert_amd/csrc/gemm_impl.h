@@ -1115,9 +1115,17 @@ __global__ void __launch_bounds__(256, OCC) gemm_kernel(GP p) {
     // The 128x128 two-blocks-per-CU data-gradient kernel prefetches ONE operand, for the GELU' epilogue (dgrad of BertOutput.dense: the
     // 16 MB pre-activation would otherwise be requested by all blocks at once after their last MFMA).
     constexpr bool DGRAD = sizeof(T) == 2 && !LA::KROW && LB::KROW;
-    constexpr int EPF = !DGRAD ? 0 : (BM * BN <= 128 * 64 ? 2 : (OCC >= 2 ? 1 : 0));
+    // CB_FWD_EPF (round-3 experiment, tools/r03_fwd_epf.sh): forward kernels of the small tiles prefetch the RESIDUAL when the reduction is
+    // at most four K tiles (the ResNet conv3 1x1 convolutions with K = 64 ... 256: one block lives ~5 dependent memory round trips)
+#ifndef CB_FWD_EPF
+#define CB_FWD_EPF 0
+#endif
+    constexpr bool FWD = sizeof(T) == 2 && !LA::KROW && !LB::KROW && CB_FWD_EPF != 0;
+    constexpr int EPF = FWD ? (BM * BN <= 128 * 64 ? 2 : 0) : (!DGRAD ? 0 : (BM * BN <= 128 * 64 ? 2 : (OCC >= 2 ? 1 : 0)));
     EpiPre<BM, BN, EPF != 1> epre;
-    const bool epf_on = EPF != 0 && p.c_vec8 && (EPF == 2 ? p.relu_bwd != 0 : (p.dact_pre != nullptr && !p.relu_bwd));      // block-uniform
+    const bool epf_on = EPF != 0 && p.c_vec8 &&
+        (FWD ? (p.residual != nullptr && !p.relu_bwd && !p.mask && !p.dact_pre && nt <= 4)
+             : (EPF == 2 ? p.relu_bwd != 0 : (p.dact_pre != nullptr && !p.relu_bwd)));      // block-uniform
     if constexpr (EPF != 0) {
         if (epf_on) epi_prefetch<T, BM, BN, EPF != 1>(p, epre, m0, n0, tid);
     }

@@ -43,7 +43,7 @@ def main():
     assert len(gf) == len(calls) == len(gw), (len(gf), len(gw), len(calls))
     fam = collections.defaultdict(lambda: dict(launches=0, fetch_kib=0.0, write_kib=0.0, algorithmic_bytes=0.0, flop=0.0))
     for c, f, w in zip(calls, gf, gw):
-        key = f"gemm_kernel<bf16> {c['form']}{' (implicit-GEMM conv)' if c['conv'] else ''}"
+        key = f"cb_gemm<bf16> {c['form']}{' (implicit-GEMM conv)' if c['conv'] else ''}"
         a = fam[key]
         nb = c.get("batch", 1)
         taps = c.get("R", 1) * c.get("S", c.get("R", 1)) if c["conv"] else 1

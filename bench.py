@@ -162,7 +162,8 @@ def main():
         # captured into the step's hipGraph -- shows that the whole exchange is capturable; a diagnostic, not the metric.
         loopback = world == 1 and not dry_dp and os.environ.get("CB_BENCH_LOOPBACK") == "1"
         sync = GradSync(bank, compress=None if os.environ.get("CB_BENCH_FP32_WIRE") == "1" else "bf16",
-                        comm=os.environ.get("CB_COMM", "auto"), pretend_world=dry_dp, loopback=loopback)   # auto: the library's own RCCL entry points on "nccl"
+                        comm=os.environ.get("CB_COMM", "auto"), pretend_world=dry_dp, loopback=loopback,   # auto: the library's own RCCL entry points on "nccl"
+                        shard=os.environ.get("CB_BENCH_SHARD") == "1")      # opt-in: reduce-scatter -> owner-only AdamW -> all-gather
         sync.broadcast_parameters(0)
         opt = FusedAdamW(bank, lr=5e-5, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0)
     state = {"global_step": 0}
@@ -265,8 +266,17 @@ def main():
         g16 = sync.wire_gradients()             # N > 1, bf16 wire: AdamW reads the reduced image directly (no cast back to fp32)
         sync.wait(cast_back=g16 is None)
         ops.counter_add(model.rt.seed_dev)
-        opt.launch(grad16=g16)
+        dp_update(g16)
         return loss
+
+    def dp_update(g16):
+        """the optimizer behind a finished gradient exchange: every rank updates everything (all-reduce), or (CB_BENCH_SHARD=1) only
+        the 1/world of every bucket it received from the reduce-scatter, followed by the all-gather of the new weights"""
+        if sync.shard:
+            opt.launch(grad16=g16, pieces=sync.owned_pieces(), norm_reduce=sync.norm_all_reduce)
+            sync.gather_updated()
+        else:
+            opt.launch(grad16=g16)
 
     def forward_only_step():
         with torch.no_grad():
@@ -322,7 +332,7 @@ def main():
     log("eager warm-up done" + (f", loss {float(loss.item()):.4f}" if loss is not None else ""))
     dp_check = None
     if train and world > 1:
-        dp_check = dp_self_check(bank, dist, dev)
+        dp_check = dp_self_check(bank, dist, dev, compute_weights=sync.shard)
         log(f"DP self-check: {dp_check}")
 
     # ---- replay plan -----------------------------------------------------------------------------------------------------
@@ -355,7 +365,9 @@ def main():
     elif use_graph and not train:
         g1, loss = capture(forward_only_step)
         run, plan, n_graphs = g1.replay, "one hipGraph", 1
-    elif use_graph and train and sync.active and not sync.dry and sync.carrier == "native" and (plan_env == "captured" or sync.loopback):
+    elif use_graph and train and sync.active and not sync.dry and sync.shard and sync.carrier != "native":
+        run, plan, n_graphs = eager_fn, "eager (owner-only update over torch.distributed: not captured)", 0
+    elif use_graph and train and sync.active and not sync.dry and sync.carrier == "native" and (plan_env == "captured" or sync.loopback or sync.shard):
         # ONE hipGraph for the whole data-parallel step: the bucket all-reduces (cb_allreduce_bucket on GradSync's comm stream,
         # forked / joined by events) are captured with the kernels -- no host between the backward and the collectives.  Opt-in
         # for N > 1 (CB_BENCH_PLAN=captured) until it has run on a multi-GPU node; the loopback run exercises it on one GPU.
@@ -370,7 +382,7 @@ def main():
             g16 = sync.wire_gradients()
             sync.wait(cast_back=g16 is None)
             ops.counter_add(model.rt.seed_dev)
-            opt.launch(grad16=g16)
+            dp_update(g16)
             return loss_
         g1, loss = capture(device_step_dp)
 
@@ -548,7 +560,9 @@ def main():
     if dp_check is not None:
         out["config"]["dp_self_check"] = dp_check
     if train and sync is not None and sync.active and not sync.dry:
-        out["config"]["grad_exchange"] = f"{sync.carrier} ({'cb_allreduce_bucket: RCCL behind the C ABI' if sync.carrier == 'native' else 'torch.distributed ' + backend}), bf16 wire, 64 MiB buckets"
+        if sync.shard:
+            out["config"]["update"] = "owner-only: reduce-scatter -> AdamW on 1/world of every bucket -> all-gather of the new weights"
+        out["config"]["grad_exchange"] = f"{sync.carrier} ({('cb_reduce_scatter_bucket / cb_allgather_bucket' if sync.shard else 'cb_allreduce_bucket') + ': RCCL behind the C ABI' if sync.carrier == 'native' else 'torch.distributed ' + backend}), bf16 wire, 64 MiB buckets"
     if gathered is not None:
         out["config"]["rows_gathered"] = len(gathered)
     if rank == 0 and world == 1 and not args.no_roofline:
@@ -563,10 +577,12 @@ def main():
         dist.destroy_process_group()
 
 
-def dp_self_check(bank, dist, dev):
+def dp_self_check(bank, dist, dev, compute_weights=False):
     """After one eager data-parallel step every rank must hold identical parameters (same all-reduced gradients, same
-    AdamW update): compares an order-independent checksum of the fp32 masters across the ranks."""
-    local = torch.stack([bank.master.double().sum(), bank.master.double().abs().sum()]).to(dev)
+    AdamW update): compares an order-independent checksum of the fp32 masters across the ranks (owner-only update: of the bf16
+    compute weights, which are what the all-gather distributes -- the fp32 masters of the decay groups live on their owners)."""
+    w = bank.w16 if (compute_weights and bank.w16 is not None) else bank.master
+    local = torch.stack([w.double().sum(), w.double().abs().sum()]).to(dev)
     lo, hi = local.clone(), local.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)

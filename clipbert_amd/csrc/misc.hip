@@ -395,6 +395,20 @@ __global__ void __launch_bounds__(256) mean_bwd_kernel(const float* dmean, int64
     if (i < n) dx[i] = *dmean / (float)n;
 }
 __global__ void counter_add_kernel(int64_t* c, int64_t inc) { *c += inc; }
+// p[0, bytes) = 0: 16-byte stores over the aligned middle (grid-stride), byte stores for the unaligned head / tail
+__global__ __launch_bounds__(256) void zero_kernel(unsigned char* p, int64_t bytes) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    int64_t head = (int64_t)((16 - (a & 15)) & 15);
+    if (head > bytes) head = bytes;
+    const int64_t n16 = (bytes - head) >> 4;
+    u32x4* q = reinterpret_cast<u32x4*>(p + head);
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int64_t i = tid; i < n16; i += stride) q[i] = z;
+    const int64_t tail0 = head + (n16 << 4);
+    if (tid < head) p[tid] = 0;
+    if (tid < bytes - tail0) p[tail0 + tid] = 0;
+}
 }  // namespace
 
 extern "C" int cb_mean_fwd(const float* x, int64_t n, float* out, void* stream) {
@@ -406,6 +420,16 @@ extern "C" int cb_mean_bwd(const float* dmean, int64_t n, float* dx, void* strea
     CB_REQUIRE(dmean && dx && n > 0, "cb_mean_bwd: bad arguments");
     hipLaunchKernelGGL(mean_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cb_stream(stream), dmean, n, dx);
     return cb_launch_status("cb_mean_bwd");
+}
+extern "C" int cb_zero(void* p, int64_t bytes, void* stream) {
+    CB_REQUIRE(bytes >= 0 && (p || bytes == 0), "cb_zero: bad arguments");
+    if (bytes == 0) return 0;
+    const int64_t n16 = bytes >> 4;
+    int64_t blocks = (n16 + 256 * 4 - 1) / (256 * 4);                 // ~4 stores per thread; one block covers head + tail bytes
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, cb_stream(stream), static_cast<unsigned char*>(p), bytes);
+    return cb_launch_status("cb_zero");
 }
 extern "C" int cb_counter_add(int64_t* counter, int64_t inc, void* stream) {
     CB_REQUIRE(counter, "cb_counter_add: null counter");

@@ -111,7 +111,7 @@ class GradSync:
     buffer (~0.3 ms) against ~1.5 ms of link time saved on 8 GPUs."""
 
     def __init__(self, bank: ParamBank, group=None, bucket_bytes: int = 64 << 20, compress: Optional[str] = None, comm: str = "auto",
-                 pretend_world: int = 0, loopback: bool = False):
+                 pretend_world: int = 0, loopback: bool = False, shard: bool = False):
         """bucket_bytes: fp32 gradient bytes per all-reduce (0 = one collective per range).  The default 64 MiB (32 MiB on
         the wire in bf16) lets the cast of bucket i+1 run while bucket i is on the links, and keeps each collective well
         past the ~8 MiB where RCCL's ring reaches its link bandwidth."""
@@ -126,6 +126,7 @@ class GradSync:
         bank.clients += 1
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         # pretend_world > 1 (single process, no process group): everything a rank of an N-rank job does EXCEPT the collectives --
         # wire casts, bucket bookkeeping, 1/N scaling, bf16-direct AdamW -- so the non-link overhead of the DP plan can be timed on one GPU
         self.dry = pretend_world > 1 and self.world == 1
@@ -138,6 +139,10 @@ class GradSync:
         self.t_range = (0, t_end)
         self.c_range = (t_end, bank.n_train)
         self.bucket_elems = bucket_bytes // 4 if bucket_bytes > 0 else 0
+        if shard:
+            q = 64 * max(self.world, 1)
+            assert ParamBank.GROUP_ALIGN % q == 0, f"shard=True needs world in (1, 2, 4, 8): {self.world}"
+            self.bucket_elems = max(q, self.bucket_elems // ParamBank.GROUP_ALIGN * ParamBank.GROUP_ALIGN) if self.bucket_elems > 0 else 0
         self.compress = compress
         self._wire = None
         self._work: List = []
@@ -145,6 +150,15 @@ class GradSync:
         self._inflight: List = []           # ranges handed to _reduce since the last wait()
         self.c_early: List = []             # set_cnn_split(): sub-ranges of the CNN range whose gradients are final early
         self.late_ranges = 0                # ranges wait() had to send itself because nobody reduced them (diagnostic)
+        # shard=True ("owner-only update", the two halves of the all-reduce with the optimizer in between): every bucket
+        # is REDUCE-SCATTERED -- rank r ends up with the sum of the r-th 1/world of each bucket --, FusedAdamW.launch(pieces=
+        # sync.owned_pieces()) updates only those pieces, gather_updated() ALL-GATHERS the new compute weights (and the fp32 masters
+        # of the groups kernels read in fp32).  Same bytes on the links as the all-reduce; the optimizer streams 1/world of the state.
+        self.shard = bool(shard)
+        self._owned_done: List = []         # ... of the exchange wait() completed last (what the optimizer / gather_updated use)
+        self._buckets_done: List = []
+        self._owned: List = []              # (lo, hi) pieces of the flat buffers this rank owns, from the buckets reduced since wait()
+        self._buckets: List = []            # (s, e) of every bucket of the current exchange
         self._epoch_done = getattr(bank, "grad_epoch", 0)    # bank.grad_epoch (one per zero_grad) of the last completed exchange
         want_native = comm == "native" or (comm == "auto" and dist.is_initialized() and bank.grad.is_cuda and dist.get_backend(group) == "nccl")
         want_native = want_native or self.loopback
@@ -246,14 +260,19 @@ class GradSync:
         step = self.bucket_elems if self.bucket_elems > 0 else (b - a)
         for s in range(a, b, step):
             e = min(b, s + step)
+            if self.shard:
+                assert (e - s) % (64 * self.world) == 0, "shard=True: ranges must start / end at multiples of world x 64 elements (ParamBank.GROUP_ALIGN)"
+                n = (e - s) // self.world
+                self._owned.append((s + self.rank * n, s + (self.rank + 1) * n))
+                self._buckets.append((s, e))
             if self.compress == "bf16":
                 if cast:
                     self.cast_range(s, e)                          # (per bucket: the cast of bucket i+1 overlaps bucket i's transfer)
                 self._ensure_wire()
-                self._work.append(self._all_reduce(self._wire[s:e]))
+                self._work.append(self._exchange(self._wire[s:e]))
                 self._pending.append((s, e))
             else:
-                self._work.append(self._all_reduce(self.bank.grad[s:e]))
+                self._work.append(self._exchange(self.bank.grad[s:e]))
 
     def _uncovered(self):
         """parts of [0, n_train) not handed to _reduce since the last wait()"""
@@ -265,6 +284,69 @@ class GradSync:
         if cur < self.bank.n_train:
             out.append((cur, self.bank.n_train))
         return out
+
+    def _exchange(self, t: torch.Tensor):
+        """one bucket: all-reduce, or (shard=True) reduce-scatter in place -- this rank's 1/world slice receives the sum"""
+        if not self.shard:
+            return self._all_reduce(t)
+        if self.dry:
+            return None
+        if self.native is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream(t.device))
+            self.native.reduce_scatter_(t, self.comm_stream)
+            return None
+        if self.world == 1:
+            return None
+        n = t.numel() // self.world
+        if t.is_cuda and dist.get_backend(self.group) == "nccl":
+            return dist.reduce_scatter_tensor(t[self.rank * n:(self.rank + 1) * n], t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)   # gloo has no reduce-scatter: the owned slice is what is read
+
+    def owned_pieces(self):
+        """shard=True, after wait(): the (lo, hi) pieces of the flat buffers whose gradients THIS rank holds reduced"""
+        assert self.shard
+        return list(self._owned_done)
+
+    def norm_all_reduce(self, sq: torch.Tensor):
+        """sum over the ranks of the squared-gradient partial of the owned pieces (every rank then derives the same clip coefficient)"""
+        if not self.active or self.dry or (self.world == 1 and not self.loopback):
+            return sq
+        if self.native is not None:
+            self.native.all_reduce_(sq)                   # (on the current stream, between the partial sums and the update)
+        else:
+            dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.group)
+        return sq
+
+    def gather_updated(self, masters: bool = False):
+        """shard=True, after the optimizer ran on the owned pieces: every bucket's new bf16 compute weights (and the fp32 masters of
+        the no-decay groups -- biases and LayerNorm vectors, which kernels read in fp32; ``masters=True``: of everything, e.g. before
+        state_dict()) are all-gathered in place."""
+        assert self.shard
+        if not self.active or self.dry:
+            return
+        bank = self.bank
+        nd = [bank.group_range[g] for g in (1, 3, 5, 7)]
+        for s, e in self._buckets_done:
+            if bank.w16 is not None:
+                self._gather(bank.w16[s:e])
+            fp32_read = masters or bank.w16 is None or any(a < e and s < b for a, b in nd)
+            if fp32_read:
+                self._gather(bank.master[s:e])
+        if self.native is not None:
+            torch.cuda.current_stream(bank.grad.device).wait_stream(self.comm_stream)
+
+    def _gather(self, t: torch.Tensor):
+        if self.native is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream(t.device))
+            self.native.all_gather_(t, self.comm_stream)
+            return
+        if self.world == 1:
+            return
+        n = t.numel() // self.world
+        parts = [torch.empty_like(t[:n]) for _ in range(self.world)]
+        dist.all_gather(parts, t[self.rank * n:(self.rank + 1) * n].contiguous(), group=self.group)
+        for r, p in enumerate(parts):
+            t[r * n:(r + 1) * n].copy_(p)
 
     def _all_reduce(self, t: torch.Tensor):
         if self.dry:
@@ -311,6 +393,8 @@ class GradSync:
             torch.cuda.current_stream(self.bank.grad.device).wait_stream(self.comm_stream)
         self._work = []
         self._inflight = []
+        if self.shard:
+            self._owned_done, self._buckets_done, self._owned, self._buckets = self._owned, self._buckets, [], []
         if not cast_back and self.compress == "bf16":
             self._pending = []
             return

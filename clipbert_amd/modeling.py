@@ -819,7 +819,7 @@ def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
     dev = pk.x_final.device
     # ---- pooler ------------------------------------------------------------------------------------
     if d_seq is None:
-        dx = torch.zeros(M, d, dtype=dt, device=dev)
+        dx = ops.zeros((M, d), dt, dev)
     else:
         dx = d_seq.reshape(M, d)
         if dx.dtype != dt or not dx.is_contiguous():
@@ -891,7 +891,7 @@ def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
     ops.text_embed_bwd(dpre, pk.ids, bank.grad_image(we.weight), bank.grad_image(emb.position_embeddings.weight),
                        bank.grad_image(emb.token_type_embeddings.weight)[0], lt, L,
                        we.padding_idx if we.padding_idx is not None else -1, repeat=pk.text_repeat)
-    dgrid = torch.zeros(pk.grid_shape, dtype=torch.float32, device=dev)
+    dgrid = ops.zeros(pk.grid_shape, torch.float32, dev)
     ops.visual_embed_bwd(dpre, pk.src_row, pk.sel, dgrid, bank.grad_image(vemb.row_position_embeddings.weight),
                          bank.grad_image(vemb.col_position_embeddings.weight), bank.grad_image(vemb.token_type_embeddings.weight)[0],
                          bsz, lv, lt, L)
@@ -944,7 +944,7 @@ class _LinearFn(torch.autograd.Function):
             m = nseg * seglen
             tab = rt.table(nseg, 1, seglen, 1, 0, segstride * k, 0, k, dev)
         out_dt = torch.float32 if out_f32 else rt.dtype
-        ld = (n + 3) // 4 * 4
+        ld = n if n < 4 else (n + 3) // 4 * 4              # (1- / 2-column head outputs stay contiguous: the losses read them in place)
         store = torch.empty(m, ld, dtype=out_dt, device=dev)
         y = store[:, :n]
         save = ctx.needs_input_grad[0]
@@ -990,7 +990,7 @@ class _LinearFn(torch.autograd.Function):
                 ops.gemm(g, x2, n, k, m, out=gw, a_mode=KROW, lda=g.stride(0), b_mode=KROW_GATHER, b_tab=tab, ldb=0, R=1, S=1,
                          Cin=k, H=1, W=seglen, sH=0, sW=k, accumulate=True, split_k=split, tile=tile)
             rowmap = rt.strided_rowmap(nseg, 1, segstride, 1, seglen, 1, dy.device)
-            dx = torch.zeros(x2.shape, dtype=dt, device=dy.device)
+            dx = ops.zeros(x2.shape, dt, dy.device)
             ops.gemm(g, bank.compute(weight), m, k, n, out=dx, lda=g.stride(0), b_mode=KROW, c_rowmap=rowmap)
         if gb is not None:
             ops.colsum(g, gb, m, n, ldg=g.stride(0))

@@ -309,6 +309,18 @@ def counter_add(counter: torch.Tensor, inc: int = 1):
     _chk(_lib.get().cb_counter_add(_ptr(counter), inc, _stream(counter)), "cb_counter_add")
 
 
+def zero_(t: torch.Tensor) -> torch.Tensor:
+    """t[...] = 0 for a contiguous tensor (or contiguous slice of one): cb_zero on t's stream"""
+    assert t.is_contiguous()
+    if t.numel():
+        _chk(_lib.get().cb_zero(_ptr(t), t.numel() * t.element_size(), _stream(t)), "cb_zero")
+    return t
+
+
+def zeros(shape, dtype, device) -> torch.Tensor:
+    return zero_(torch.empty(shape, dtype=dtype, device=device))
+
+
 def visual_embed_bwd(dpre, src_row, sel, dgrid, drow, dcol, dtype0, b, lv, lt, l_total):
     _, t, hg, wg, d = dgrid.shape
     _chk(_lib.get().cb_visual_embed_bwd(dtype_code(dpre.dtype), _ptr(dpre), _ptr(src_row), _ptr(sel), _ptr(dgrid),

@@ -84,6 +84,7 @@ class FusedAdamW:
         # exists behind it the skip flag makes that launch a no-op
         self._hp_dev_prev = torch.zeros(N_GROUPS, 16, dtype=torch.float32, device=dev)
         self._hp_dev_prev[:, HP_SKIP] = 1.0
+        self._prev_live = False              # _hp_dev_prev holds a step's values (not the initial "skip")
         self.deferred_pending = False        # an update of some groups has been left to the next step (flush with launch(..., reuse_norm=True))
         self._sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._sq_ws = torch.zeros(1024, dtype=torch.float32, device=dev)     # partials of the order-independent norm reduction
@@ -102,10 +103,12 @@ class FusedAdamW:
         if self._hp_dev.is_cuda and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("FusedAdamW.prepare_step() inside a hipGraph capture: capture launch() only and call "
                                "prepare_step() eagerly before each replay (see INTEGRATION.md)")
-        if self.step_count > 0:
+        if self.deferred_pending and self.step_count > 0:      # an update was left behind by the step before: it needs that step's values
             self._hp_dev_prev.copy_(self._hp_dev)              # D2D, stream-ordered before the upload below overwrites _hp_dev
-        if not self.deferred_pending:                          # nothing was left behind by the step before: a launch(prev=True) is a no-op
+            self._prev_live = True
+        elif self._prev_live:                                  # nothing left behind: a launch(prev=True) is a no-op again
             self._hp_dev_prev[:, HP_SKIP] = 1.0
+            self._prev_live = False
         self.step_count += 1
         self._last_scale = grad_scale
         slot = self.step_count & 1
@@ -125,7 +128,7 @@ class FusedAdamW:
 
     @torch.no_grad()
     def launch(self, grad16: Optional[torch.Tensor] = None, groups: Optional[Sequence[int]] = None, prev: bool = False,
-               reuse_norm: bool = False):
+               reuse_norm: bool = False, pieces=None, norm_reduce=None):
         """Device half of a step (capturable): global grad-norm reduction, then clip + AdamW + bf16 weight refresh, reading
         the hyper-parameters from the device array prepare_step() filled.  ``grad16``: consume these bf16 gradients (flat, same
         layout as bank.grad -- GradSync's reduced wire image, ``sync.wire_gradients()``) instead of the fp32 buffer.
@@ -134,7 +137,11 @@ class FusedAdamW:
         e.g. the CNN groups (4-7) at the end of step i, and the transformer groups (0-3) at the START of step i+1's graph with
         ``prev=True`` (hyper-parameters of step i) and ``reuse_norm=True`` (the norm step i computed over ALL gradients), on a side
         stream beside the ResNet forward, which only reads CNN weights.  Same arithmetic, same order per parameter; a no-op until a
-        step exists behind it (CB_HP_SKIP).  The caller zeroes each half of the gradients after its update (ParamBank.zero_grad_range)."""
+        step exists behind it (CB_HP_SKIP).  The caller zeroes each half of the gradients after its update (ParamBank.zero_grad_range).
+
+        Owner-only update (GradSync(shard=True)): ``pieces`` = ``sync.owned_pieces()``, the (lo, hi) slices of the flat buffers whose
+        reduced gradients this rank holds after the reduce-scatter; only they are updated, ``norm_reduce`` (``sync.norm_all_reduce``)
+        sums the squared-norm partials over the ranks, and ``sync.gather_updated()`` afterwards distributes the new weights."""
         bank = self.bank
         if getattr(bank, "lazy_fresh", False) and not prev:
             raise RuntimeError("FusedAdamW: zero_grad(lazy=True) was not followed by an encoder backward -- the encoder weight "
@@ -142,23 +149,31 @@ class FusedAdamW:
         sq = None
         if self.max_grad_norm > 0:
             if not reuse_norm:
-                self._sq.zero_()
+                ops.zero_(self._sq)
                 src = bank.grad if grad16 is None else grad16
-                ops.sq_sum(src[:bank.n_train], self._sq, self._sq_ws)       # deterministic: ranks must derive the same clip coefficient
+                if pieces is None:
+                    ops.sq_sum(src[:bank.n_train], self._sq, self._sq_ws)   # deterministic: ranks must derive the same clip coefficient
+                else:
+                    for lo, hi in pieces:                                   # partial of the owned slices (accumulated), then summed over ranks
+                        ops.sq_sum(src[lo:hi], self._sq, self._sq_ws)
+                    if norm_reduce is not None:
+                        norm_reduce(self._sq)
             sq = self._sq
         hp_dev = self._hp_dev_prev if prev else self._hp_dev
         for g, pg in enumerate(self.param_groups):
             a, b = pg["range"]
             if b <= a or (groups is not None and g not in groups):
                 continue
-            w16 = bank.w16[a:b] if bank.w16 is not None else None
             gsrc = bank.grad if grad16 is None else grad16
-            ops.adamw(bank.master[a:b], gsrc[a:b], bank.exp_avg[a:b], bank.exp_avg_sq[a:b], w16, hp_dev[g], sq)
+            spans = [(a, b)] if pieces is None else [(max(a, lo), min(b, hi)) for lo, hi in pieces if lo < b and a < hi]
+            for x, y in spans:
+                w16 = bank.w16[x:y] if bank.w16 is not None else None
+                ops.adamw(bank.master[x:y], gsrc[x:y], bank.exp_avg[x:y], bank.exp_avg_sq[x:y], w16, hp_dev[g], sq)
 
-    def step(self, grad_scale: float = 1.0, grad16: Optional[torch.Tensor] = None):
+    def step(self, grad_scale: float = 1.0, grad16: Optional[torch.Tensor] = None, pieces=None, norm_reduce=None):
         """grad_scale multiplies the gradients first (1/world_size after a SUM all-reduce)."""
         self.prepare_step(grad_scale)
-        self.launch(grad16=grad16)
+        self.launch(grad16=grad16, pieces=pieces, norm_reduce=norm_reduce)
 
     def grad_norm(self) -> float:
         """Host-visible global norm of the (averaged) gradient of the last step (syncs)."""

@@ -48,6 +48,10 @@ def _physical(t: torch.Tensor) -> torch.Tensor:
 
 class ParamBank:
     ALIGN = 64          # elements; keeps every parameter 256-byte aligned in fp32 and 128-byte in bf16
+    GROUP_ALIGN = 512   # every optimizer group starts and ends at a multiple of 512 elements (zero padding behind its last parameter):
+                        # ranges made of whole groups -- and, inside the CNN group, of whole convolution weights, whose sizes are
+                        # multiples of 512 -- divide into world x 64-element shards for world in {1, 2, 4, 8}: what
+                        # GradSync(shard=True) reduce-scatters / all-gathers in place
 
     def __init__(self, root: nn.Module, device, compute_dtype: torch.dtype, transformer_lr_mul_prefix: str = "",
                  cnn_lr_mul_prefix: str = "grid_encoder", name_prefix: str = ""):
@@ -76,6 +80,7 @@ class ParamBank:
             for _n, p in g:
                 self.offset[id(p)] = off
                 off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            off = (off + self.GROUP_ALIGN - 1) // self.GROUP_ALIGN * self.GROUP_ALIGN      # (the padding stays zero: AdamW leaves it at zero)
             self.group_range.append((start, off))
         self.n_train = off
         dev = self.device
@@ -191,12 +196,12 @@ class ParamBank:
         if lazy and span is not None:
             a, b = span
             if a > 0:
-                self.grad[:a].zero_()
+                ops.zero_(self.grad[:a])
             if b < self.grad.numel():
-                self.grad[b:].zero_()
+                ops.zero_(self.grad[b:])
             self.lazy_fresh = True
         else:
-            self.grad.zero_()
+            ops.zero_(self.grad)
             self.lazy_fresh = False
 
     def zero_grad_range(self, lo: int, hi: int, lazy: bool = False):
@@ -205,13 +210,13 @@ class ParamBank:
         span = getattr(self, "lazy_span", None) if lazy else None
         if span is None or span[1] <= lo or span[0] >= hi:
             if hi > lo:
-                self.grad[lo:hi].zero_()
+                ops.zero_(self.grad[lo:hi])
             return
         a, b = max(span[0], lo), min(span[1], hi)
         if a > lo:
-            self.grad[lo:a].zero_()
+            ops.zero_(self.grad[lo:a])
         if hi > b:
-            self.grad[b:hi].zero_()
+            ops.zero_(self.grad[b:hi])
 
     def take_fresh(self) -> bool:
         """True once after zero_grad(lazy=True): the lazy span holds stale values and must be overwritten (or zeroed) now"""

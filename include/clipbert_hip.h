@@ -269,6 +269,10 @@ int cb_lse_loss(const float* logits, const int64_t* labels, int32_t n_clips, int
 int cb_mean_fwd(const float* x, int64_t n, float* out, void* stream);
 int cb_mean_bwd(const float* dmean, int64_t n, float* dx, void* stream);
 int cb_counter_add(int64_t* counter, int64_t inc, void* stream);
+/* p[0, bytes) = 0 (any alignment): the zero fills of the step -- gradient ranges that are accumulated into (optimizer.zero_grad() of
+ * run_video_retrieval.py:484), scatter targets of the embedding backwards, the squared-norm accumulator -- as a stream-ordered,
+ * capturable kernel of this library. */
+int cb_zero(void* p, int64_t bytes, void* stream);
 int cb_sq_sum(const float* g, int64_t n, float* out_accum, void* stream);
 /* The same sum with a result that does not depend on the order in which workgroups retire (fixed grid of <= min(1024, ws_floats)
  * blocks -> `ws` partials -> one block adds them in index order): data-parallel ranks holding bit-identical all-reduced

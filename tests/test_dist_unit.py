@@ -93,7 +93,7 @@ def test_cnn_range_in_two_parts():
     sync.wait()
 
 
-def test_wait_without_any_reduce_exchanges_the_whole_buffer():
+def test_wait_without_any_reduce_exchanges_the_whole_buffer(emul):
     """ADVICE r2: a step for which no reduce_* was called (hooks not armed) must not pass un-reduced gradients to the optimizer;
     a repeated wait() in the same step stays a no-op."""
     bank = _toy_bank()

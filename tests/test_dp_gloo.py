@@ -46,7 +46,9 @@ def _train_one_step(rank, world, out_path, compress=None):
                      text_input_mask=full["text_input_mask"][2 * rank:2 * rank + 2].contiguous(),
                      n_examples_list=[2], labels=full["labels"][2 * rank:2 * rank + 2])
     bank = model.rt.bank
-    sync = GradSync(bank, compress="bf16" if compress == "bf16direct" else compress)
+    shard = compress in ("shard", "shard16")
+    sync = GradSync(bank, compress="bf16" if compress in ("bf16direct", "shard16") else (None if shard else compress), shard=shard,
+                    bucket_bytes=(1 << 16) if shard else (64 << 20))
     sync.broadcast_parameters(0)
     calls, calls5 = [], []
     # attach(): transformer buckets from the end of the encoder backward; the two ends of the CNN range (grid_encoder, res5) from
@@ -62,9 +64,23 @@ def _train_one_step(rank, world, out_path, compress=None):
     out["loss"].mean().backward()
     assert calls5 == [1]
     sync.reduce_cnn()
-    g16 = sync.wire_gradients() if compress == "bf16direct" else None     # the optimizer reads the reduced bf16 image itself
-    sync.wait(cast_back=g16 is None)
-    opt.step(grad_scale=sync.grad_scale, grad16=g16)
+    g16 = sync.wire_gradients() if compress in ("bf16direct", "shard16") else None     # the optimizer reads the reduced bf16 image itself
+    sync.wait(cast_back=g16 is None and not shard)
+    if shard:
+        # owner-only update: each rank holds the reduced gradients of 1/world of every bucket, updates those slices, and the
+        # all-gather distributes the new weights (masters too here: rank 0 saves them)
+        pieces = sync.owned_pieces()
+        assert sum(hi - lo for lo, hi in pieces) * world == bank.n_train and len(pieces) > 2
+        before = bank.master.clone()
+        opt.step(grad_scale=sync.grad_scale, grad16=g16, pieces=pieces, norm_reduce=sync.norm_all_reduce)
+        if world > 1:
+            mine = torch.zeros(bank.n_train, dtype=torch.bool)
+            for lo, hi in pieces:
+                mine[lo:hi] = True
+            assert torch.equal(bank.master[:bank.n_train][~mine], before[:bank.n_train][~mine])      # other ranks' slices untouched
+        sync.gather_updated(masters=True)
+    else:
+        opt.step(grad_scale=sync.grad_scale, grad16=g16)
     assert calls == [1]                     # transformer bucket was launched from inside the backward
     if rank == 0:
         torch.save(dict(master=bank.master.clone(), norm=opt.grad_norm()), out_path)
@@ -180,6 +196,20 @@ def test_dp2_equals_dp1_on_the_global_batch(tmp_path):
     # is ~0, so bound the worst element by 2.5 lr and the mean deviation tightly
     diff = (c["master"] - b["master"]).abs()
     assert diff.max() < 2.5e-3 and diff.mean() < 2e-6, (diff.max(), diff.mean())
+
+
+def test_dp2_owner_only_update_equals_dp1(tmp_path):
+    """GradSync(shard=True): reduce-scatter -> AdamW on the owned 1/world of every bucket -> all-gather of the new weights (the
+    direct exchange of SURVEY 8e with the optimizer in between) gives the weights of the all-reduce path and of DP = 1."""
+    p2s, p2s16, p2, p2d, p1 = (str(tmp_path / n) for n in ("s.pt", "s16.pt", "ar.pt", "ar16.pt", "dp1.pt"))
+    _spawn_all([(2, p2s, "shard", "one_step"), (2, p2s16, "shard16", "one_step"), (2, p2, None, "one_step"), (2, p2d, "bf16direct", "one_step"),
+                (1, p1, None, "one_step")])
+    s, s16, ar, ar16, one = (torch.load(x) for x in (p2s, p2s16, p2, p2d, p1))
+    # same reduced gradients as the all-reduce path; the norm partials are summed in another order (two ranks' halves)
+    assert abs(s["norm"] - ar["norm"]) / ar["norm"] < 1e-5 and abs(s16["norm"] - ar16["norm"]) / ar16["norm"] < 1e-5
+    torch.testing.assert_close(s["master"], ar["master"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(s16["master"], ar16["master"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(s["master"], one["master"], rtol=1e-4, atol=2e-6)
 
 
 def test_sharded_retrieval_inference_gathers_all_rows(tmp_path):

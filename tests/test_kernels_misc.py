@@ -348,3 +348,18 @@ def test_layernorm_bwd_partials_equal_atomics_path(hw, dt, rows):
     ops.ln_partials_reduce(part, again, offs_g, offs_b)
     ops.ln_partials_reduce(part, again, offs_g, offs_b)
     assert torch.equal(again[:8 + 4 * D], flat[:8 + 4 * D])
+
+
+@pytest.mark.parametrize("off,n", [(0, 1), (1, 1), (3, 40), (0, 4096), (5, 4099), (7, 70001), (0, 0)])
+def test_zero_fill_touches_exactly_its_range(hw, off, n):
+    """cb_zero on a byte range of any alignment: the range becomes zero, its neighbours keep their values (the zero fills of the
+    step -- optimizer.zero_grad(), scatter targets, the squared-norm word -- go through it instead of torch fill kernels)"""
+    buf = torch.full((off + n + 33,), 0x5A, dtype=torch.uint8, device=DEV[0])
+    ops.zero_(buf[off:off + n])
+    want = torch.full_like(buf, 0x5A)
+    want[off:off + n] = 0
+    assert torch.equal(buf, want)
+    assert float(ops.zeros((3, 5), torch.float32, DEV[0]).abs().sum()) == 0.0
+    g = ones(1000)
+    ops.zero_(g[64:512])
+    assert float(g.sum()) == 1000 - 448 and float(g[64:512].abs().sum()) == 0.0

@@ -69,3 +69,17 @@ def test_loopback_plan_captures_the_collectives_of_the_full_step():
     assert cfg["n_graphs"] == 1 and cfg["hip_graph"] is True and "LOOPBACK" in cfg["parallelism"]
     assert cfg["grad_exchange"].startswith("native")
     assert out["value"] > 0 and 0.0 < cfg["final_loss"] < 5.0
+
+
+@pytest.mark.gpu
+def test_loopback_owner_only_update_is_captured_and_trains():
+    """The other half of VERDICT r2 item 7: cb_reduce_scatter_bucket -> AdamW on the owned pieces -> cb_allgather_bucket inside the ONE
+    hipGraph of the step (world-size-1 communicator; the 2-rank arithmetic is tests/test_dp_gloo.py::test_dp2_owner_only_update_equals_dp1)."""
+    env = dict(os.environ, CB_BENCH_LOOPBACK="1", CB_BENCH_SHARD="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    cfg = out["config"]
+    assert cfg["n_graphs"] == 1 and cfg["update"].startswith("owner-only") and "cb_reduce_scatter_bucket" in cfg["grad_exchange"]
+    assert out["value"] > 0 and 0.0 < cfg["final_loss"] < 5.0

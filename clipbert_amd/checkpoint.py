@@ -117,6 +117,7 @@ class ModelSaver:
 
     def save(self, step: int, model, optimizer=None, prefix: str = "model") -> Optional[str]:
         model_path = os.path.join(self.output_dir, f"{prefix}_step_{step}.pt")
+        _assert_whole(model, "ModelSaver.save()")
         if self.rank != 0:
             return None
         # contiguous OIHW copies: the file must not depend on our channels_last memory image
@@ -126,6 +127,13 @@ class ModelSaver:
             torch.save({"step": step, "optimizer": _cpu(optimizer.state_dict())},
                        os.path.join(self.output_dir, f"{prefix}_step_{step}_train_state.pt"))
         return model_path
+
+
+def _assert_whole(model, what):
+    rt = getattr(model, "rt", None)
+    bank = getattr(rt, "bank", None)
+    if bank is not None:
+        bank.assert_whole(what)
 
 
 class E2E_TrainingRestorer:
@@ -151,6 +159,7 @@ class E2E_TrainingRestorer:
             self.save()
 
     def save(self):
+        _assert_whole(self.model, "E2E_TrainingRestorer.save()")
         if self.rank != 0:
             return
         ckpt = {"global_step": self.global_step, "model_state_dict": _cpu(self.model.state_dict()),

@@ -25,6 +25,7 @@
 
 #include "gemm8_impl.h"
 #include <stdio.h>
+#include <cmath>
 
 using namespace cbgemm;
 
@@ -50,6 +51,8 @@ CB_G8_DECL(256, 128, 4, 2, 3)
 // steps over tile x workgroup order, tools/gen_tuned.py writes the table): consulted when the caller leaves tile /
 // xcd_order at 0 (auto); shapes that are not in the table fall through to the heuristics below.
 #include "gemm_tuned.h"
+// Shapes outside the table: a launch-cost model fitted to the same sweeps (tools/fit_gemm_model.py) ranks the legal configurations.
+#include "gemm_model.h"
 
 namespace {
 
@@ -106,6 +109,63 @@ int gemm8_form(const cb_gemm_desc* d, const GP& p, bool fast) {
     return 0;
 }
 
+
+// ---- launch-cost model (tools/fit_gemm_model.py: formula and fit) --------------------------------------------------------------
+struct ModelPick { int tile = 0, split = 0, sched = 0; double us = 1e300; };
+const int MODEL_TILE_ID[7] = {2, 3, 1, 4, 5, 6, 7};
+const int MODEL_BM[7] = {64, 128, 128, 128, 256, 128, 256};
+const int MODEL_BN[7] = {64, 64, 128, 128, 256, 256, 128};
+
+double model_us(int ti, int form, int64_t M, int64_t N, int64_t K, int64_t batch, int s, bool taps, bool m2, int c_esz) {
+    using namespace cbgemm;
+    const double* g = MODEL_G;
+    const int64_t wg = ((M + MODEL_BM[ti] - 1) / MODEL_BM[ti]) * ((N + MODEL_BN[ti] - 1) / MODEL_BN[ti]) * batch * s;
+    const int64_t kt = ((K + 63) / 64 + s - 1) / s;
+    const double r = (double)wg / (256.0 * MODEL_OCC[ti]);
+    const double rounds = g[3] * std::ceil(r - 1e-9) + (1.0 - g[3]) * (r > 1.0 ? r : 1.0);
+    const double ck = MODEL_C[ti][form] * (1.0 + g[4] * (taps ? 1 : 0)) * (1.0 + g[8] * (m2 ? 1 : 0));
+    const double ab = (double)(M * K + N * K) * 2.0 * batch, cb = (double)M * N * batch * c_esz;
+    const double red = (ti >= 4 && s > 1) ? (double)M * N * batch * s * 8.0 : 0.0;
+    const double atom = (ti < 4 && s > 1) ? (double)M * N * batch * s * 4.0 : 0.0;
+    return MODEL_A[ti] + rounds * (MODEL_B[ti][form] + kt * ck) + ab / (g[0] * 1e6) + cb / (g[5] * 1e6) + red / (g[1] * 1e6) + atom / (g[2] * 1e6) +
+           g[6] * (m2 ? 1 : 0);
+}
+
+// The configurations that are legal for this call (the same space tools/tune_gemm.py sweeps), ranked by the model.
+// can8: an 8-wave kernel covers the call; ws_bytes: K-split workspace the caller provided; free_split: the 4-wave kernels may split K
+// as they like (weight-gradient form: fp32 C accumulated in place through atomics).
+ModelPick model_pick(const cb_gemm_desc* d, const GP& p, bool can8, int64_t ws_bytes, bool free_split, int split_caller) {
+    const int form = d->a_mode == CB_KROW ? 2 : (d->b_mode != CB_ROWK ? 1 : 0);
+    const bool taps = p.R * p.S > 1;
+    const int c_esz = d->c_f32 ? 4 : 2;
+    const int64_t M = d->M, N = d->N, K = d->K, batch = p.batch;
+    ModelPick best;
+    auto consider = [&](int ti, int s, int sched) {
+        const double us = model_us(ti, form, M, N, K, batch, s, taps, sched == 3, c_esz);
+        if (us < best.us) { best.us = us; best.tile = MODEL_TILE_ID[ti]; best.split = s; best.sched = sched; }
+    };
+    static const int SPLITS4[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
+    for (int ti = 0; ti < 4; ++ti) {
+        if (N <= 64 && ti >= 2) continue;                          // (narrow outputs never take the 128-column tiles)
+        consider(ti, split_caller, 0);
+        if (free_split)
+            for (int s : SPLITS4)
+                if (s != split_caller && s <= (p.ktiles / 4 > 1 ? p.ktiles / 4 : 1)) consider(ti, s, 0);
+    }
+    if (can8)
+        for (int ti = 4; ti < 7; ++ti) {
+            const int64_t tiles = ((M + MODEL_BM[ti] - 1) / MODEL_BM[ti]) * ((N + MODEL_BN[ti] - 1) / MODEL_BN[ti]) * batch;
+            int cand[3] = {1, 0, 0};
+            int n = 1;
+            for (int target : {256, 512}) {                         // unsplit, or the grid brought to ~1x / ~2x the CUs
+                const int s = (int)std::lround((double)target / (double)tiles);
+                if (s > 1 && p.ktiles / s >= 2 && (int64_t)s * batch * M * N * 4 <= ws_bytes && s != cand[1]) cand[n++] = s;
+            }
+            for (int i = 0; i < n; ++i) { consider(ti, cand[i], 1); consider(ti, cand[i], 3); }
+        }
+    return best;
+}
+
 template <int BM, int BN, int WGM, int WGN, int NST>
 int launch8(int form, const GP& p, int mode, float* ws, hipStream_t st) {
     if (form == 1) return launch_gemm8_fwd<BM, BN, WGM, WGN, NST>(p, mode, ws, st);
@@ -116,7 +176,9 @@ int launch8(int form, const GP& p, int mode, float* ws, hipStream_t st) {
 }  // namespace
 
 
-extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
+namespace {
+// cb_gemm proper.  plan != nullptr: validate and choose as a launch would, write {tile, split_k, schedule, xcd_order}, launch nothing.
+int gemm_run(const cb_gemm_desc* d, void* stream, int32_t* plan, bool use_table) {
     CB_REQUIRE(d != nullptr, "cb_gemm: null descriptor");
     CB_REQUIRE(d->dtype == CB_F32 || d->dtype == CB_BF16, "cb_gemm: bad dtype %d", d->dtype);
     CB_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, "cb_gemm: negative dims");
@@ -208,7 +270,7 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     int tile = d->tile, xcd = d->xcd_order;
     const int split_caller = p.split_k;
     int split_tuned = 0, sched_tuned = 0;      // K split / K-loop schedule measured best for the table's tile (0: none recorded)
-    if (d->dtype == CB_BF16 && !no_tuned && (tile == 0 || xcd == 0)) {
+    if (d->dtype == CB_BF16 && !no_tuned && use_table && (tile == 0 || xcd == 0)) {
         if (const cbgemm::TunedEntry* e = cbgemm::tuned_lookup(d->a_mode, d->b_mode, d->M, d->N, d->K, p.batch, p.R * p.S, p.split_k)) {
             static const bool no8w = getenv("CB_GEMM_NO8W") != nullptr;          // diagnostic: ignore the table's 8-wave entries
             if (tile == 0 && !(no8w && e->tile >= 5)) { tile = e->tile; split_tuned = e->new_split; sched_tuned = e->sched; }
@@ -236,11 +298,24 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     // writes fp32 partial slabs into the caller's workspace and a second kernel adds them in index order and applies the FULL
     // epilogue: deterministic, no atomics, any epilogue.  Without a (large enough) workspace a split configuration is not run at all
     // (an unsplit large tile would leave most CUs idle): the 4-wave kernels take the problem.
-    const int form8 = (tile >= 5 && cv8) ? gemm8_form(d, p, fast) : 0;
+    const int form8 = (d->dtype == CB_BF16 && cv8) ? gemm8_form(d, p, fast) : 0;
     float* ws8 = nullptr;
-    if (tile >= 5 && form8 == 0) tile = 0;                       // not covered: the 4-wave kernels decide
+    if (tile >= 5 && form8 == 0) { tile = 0; split_tuned = sched_tuned = 0; }      // not covered: the 4-wave kernels decide
+    // the 4-wave kernels may choose their own K split where the result is accumulated in place through atomics (weight-gradient form)
+    const bool free_split = d->tile == 0 && d->a_mode == CB_KROW && d->c_f32 && d->accumulate && !d->C2 && !d->residual && !d->mask && !d->gelu_grad_pre &&
+                            d->act == CB_ACT_NONE && !d->relu_after && !d->shift && d->dropout_p <= 0.f;
+    const bool ws_usable = d->splitk_ws && aligned16(d->splitk_ws);
+    static const bool no_model = getenv("CB_GEMM_NO_MODEL") != nullptr;       // diagnostic: 64x64 tiles for everything outside the table
+    auto ask_model = [&](bool allow8) {                           // shapes outside the table (or whose table entry cannot run here)
+        if (d->dtype != CB_BF16 || no_model) return;
+        const ModelPick mp = model_pick(d, p, allow8 && form8 != 0, ws_usable ? d->splitk_ws_bytes : 0, free_split && !d->a_rowsum && p.batch == 1, split_caller);
+        tile = mp.tile;
+        split_tuned = (mp.tile >= 5 || mp.split != split_caller) ? mp.split : 0;
+        sched_tuned = mp.sched;
+    };
+    if (tile == 0) ask_model(true);
     if (tile >= 5) {
-        int split = d->tile == 0 ? (split_tuned > 0 ? split_tuned : 1) : split_caller;       // (table entry: its own measured split)
+        int split = d->tile == 0 ? (split_tuned > 0 ? split_tuned : 1) : split_caller;       // (table / model: its own split)
         if (split > p.ktiles) split = p.ktiles;
         bool no_ws = false;
         if (split > 1) {
@@ -250,8 +325,11 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
             if (d->splitk_ws && d->splitk_ws_bytes >= need && aligned16(d->splitk_ws)) ws8 = reinterpret_cast<float*>(d->splitk_ws);
             else { split = 1; no_ws = true; }
         }
-        if (no_ws) tile = 0;                                     // the configuration needs its split: without a workspace the 4-wave kernels decide
-        else p.split_k = split;
+        if (no_ws) {                                             // the configuration needs its split: without a workspace the model decides again
+            tile = 0; split_tuned = sched_tuned = 0;
+            ask_model(d->tile == 0);                                 // (it only offers splits the workspace holds; an explicit 8-wave request falls to 4 waves)
+            if (tile >= 5) p.split_k = split_tuned > 0 ? split_tuned : 1, ws8 = p.split_k > 1 ? reinterpret_cast<float*>(d->splitk_ws) : nullptr;
+        } else p.split_k = split;
     }
     static const bool trace = getenv("CB_GEMM_TRACE") != nullptr;
     if (trace) fprintf(stderr, "cb_gemm: M=%d N=%d K=%d modes=%d/%d tile=%d (asked %d) form8=%d split=%d ws=%d\n", d->M, d->N, d->K, d->a_mode, d->b_mode,
@@ -262,6 +340,7 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
         const int mode8 = d->schedule > 0 ? d->schedule - 1 : (sched_tuned > 0 ? sched_tuned - 1 : mode8_env);
         p.c_vec8 = 1;
         p.xcd_remap = !no_remap && xcd != 2;
+        if (plan) { plan[0] = tile; plan[1] = p.split_k; plan[2] = mode8 + 1; plan[3] = p.xcd_remap ? 1 : 2; return 0; }
         hipStream_t st8 = cb_stream(stream);
         int rc;
         if (tile == 5) rc = launch8<256, 256, 2, 4, 2>(form8, p, mode8, ws8, st8);
@@ -302,30 +381,27 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) {
     p.xcd_remap = !no_remap && xcd != 2;
 
     hipStream_t st = cb_stream(stream);
-    if (d->dtype == CB_F32) return launch_gemm<float, 64, 64, 2>(p, fast, st);
-    if (tile == 0) {
-        // Shapes outside the tuned table: rules read off the round-2 sweep (profiles/r02_gemm_tuning.json).  The 128x128 tile
-        // pays once it fills the chip (two blocks per CU resident: >= ~350 tiles) and the reduction is long enough to
-        // amortise its prologue; below that the 128x64 tile while it still gives ~1 block per CU; else 64x64.  N <= 64
-        // (stem / res2 convolutions) measured fastest with 64x64 tiles at every M.
-        const int64_t zmul = (int64_t)p.split_k * p.batch;
-        const int64_t t128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * zmul;
-        const int64_t t12864 = (int64_t)((d->M + 127) / 128) * ((d->N + 63) / 64) * zmul;
-        const int kred = d->K / p.split_k;
-        tile = 2;
-        if (d->a_mode == CB_KROW) {                   // weight gradients: big (batched) outputs only
-            if (t128 >= 256 && kred >= 1024) tile = 4;
-        } else if (d->N > 64) {
-            if (t128 >= 350 && kred >= 256) tile = 4;
-            else if (t12864 >= 200 && kred >= 512) tile = 3;
-        }
+    if (d->dtype == CB_F32) {
+        if (plan) { plan[0] = 2; plan[1] = p.split_k; plan[2] = 0; plan[3] = p.xcd_remap ? 1 : 2; return 0; }
+        return launch_gemm<float, 64, 64, 2>(p, fast, st);
     }
+    if (tile == 0) tile = 2;                         // (CB_GEMM_NO_MODEL)
     if (tile == 1 && d->N <= 64) tile = 3;           // narrow outputs (stem / res2 convs): 128x64 tile
     if (tile == 4 && d->N <= 64) tile = 3;
+    if (plan) { plan[0] = tile; plan[1] = p.split_k; plan[2] = 0; plan[3] = p.xcd_remap ? 1 : 2; return 0; }
     if (tile == 4) return launch_gemm<bf16, 128, 128, 1, 2>(p, fast, st);
     if (tile == 1) return launch_gemm<bf16, 128, 128, 2>(p, fast, st);
     if (tile == 3) return launch_gemm<bf16, 128, 64, 2>(p, fast, st);
     return launch_gemm<bf16, 64, 64, 3>(p, fast, st);
+}
+}  // namespace
+
+extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) { return gemm_run(d, stream, nullptr, true); }
+
+extern "C" int cb_gemm_plan(const cb_gemm_desc* d, int32_t use_table, int32_t* out4) {
+    CB_REQUIRE(out4 != nullptr, "cb_gemm_plan: null output");
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    return gemm_run(d, nullptr, out4, use_table != 0);
 }
 
 extern "C" int cb_build_pixel_table(cb_pixel* tab, int32_t N, int32_t OH, int32_t OW, int32_t stride, int32_t pad,

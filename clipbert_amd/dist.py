@@ -335,6 +335,22 @@ class GradSync:
         if self.native is not None:
             torch.cuda.current_stream(bank.grad.device).wait_stream(self.comm_stream)
 
+    def gather_state(self, optimizer=None):
+        """shard=True, before anything reads the WHOLE state (state_dict(), ModelSaver / E2E_TrainingRestorer.save() on rank 0): every
+        rank calls this; the fp32 masters and (``optimizer``: its) AdamW moments of every bucket are all-gathered from their owners."""
+        assert self.shard
+        bank = self.bank
+        if self.active and not self.dry:
+            for s, e in self._buckets_done:
+                self._gather(bank.master[s:e])
+                if optimizer is not None:
+                    self._gather(bank.exp_avg[s:e])
+                    self._gather(bank.exp_avg_sq[s:e])
+            if self.native is not None:
+                torch.cuda.current_stream(bank.grad.device).wait_stream(self.comm_stream)
+        if optimizer is not None or not self.active:
+            bank.owner_only_dirty = False
+
     def _gather(self, t: torch.Tensor):
         if self.native is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream(t.device))
@@ -343,6 +359,15 @@ class GradSync:
         if self.world == 1:
             return
         n = t.numel() // self.world
+        if t.is_cuda and dist.get_backend(self.group) != "nccl":           # gloo carries GPU tensors for all_reduce / broadcast only
+            mine = t[self.rank * n:(self.rank + 1) * n].clone()
+            t.zero_()
+            t[self.rank * n:(self.rank + 1) * n].copy_(mine)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        if t.is_cuda:
+            dist.all_gather_into_tensor(t, t[self.rank * n:(self.rank + 1) * n].clone(), group=self.group)
+            return
         parts = [torch.empty_like(t[:n]) for _ in range(self.world)]
         dist.all_gather(parts, t[self.rank * n:(self.rank + 1) * n].contiguous(), group=self.group)
         for r, p in enumerate(parts):

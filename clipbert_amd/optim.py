@@ -160,6 +160,8 @@ class FusedAdamW:
                         norm_reduce(self._sq)
             sq = self._sq
         hp_dev = self._hp_dev_prev if prev else self._hp_dev
+        if pieces is not None:
+            bank.owner_only_dirty = True          # masters / moments outside the owned pieces are stale until GradSync.gather_state()
         for g, pg in enumerate(self.param_groups):
             a, b = pg["range"]
             if b <= a or (groups is not None and g not in groups):
@@ -184,6 +186,7 @@ class FusedAdamW:
         """{"state": {parameter name: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...], "step": n}: moments in the
         parameters' LOGICAL shapes (OIHW for convs), keyed by name so that the file does not depend on the flat layout."""
         bank = self.bank
+        bank.assert_whole("FusedAdamW.state_dict()")
         if self.deferred_pending:
             raise RuntimeError("FusedAdamW.state_dict(): an update deferred to the next step is pending -- flush it first "
                                "(launch(groups=..., reuse_norm=True); deferred_pending = False)")

@@ -188,6 +188,13 @@ class ParamBank:
                 return                                  # another parameter sits in between
         self.lazy_span = (spans[0][0], spans[-1][1])
 
+    def assert_whole(self, what: str):
+        """Owner-only updates (GradSync(shard=True)) leave every rank with ITS pieces of the fp32 masters and AdamW moments: anything
+        that reads the whole state (state_dict(), a checkpoint) needs GradSync.gather_state() on all ranks first."""
+        if getattr(self, "owner_only_dirty", False):
+            raise RuntimeError(f"{what}: the parameters / optimizer moments are sharded over the ranks (owner-only update) -- "
+                               "call GradSync.gather_state(optimizer) on every rank first")
+
     def zero_grad(self, lazy: bool = False):
         """lazy=True: the caller guarantees that a full backward follows before the gradients are read; the lazy span (see
         set_lazy_span) is then left as it is and marked fresh -- its producer stores instead of accumulating."""

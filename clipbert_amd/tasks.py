@@ -143,7 +143,13 @@ def train_step(model, optimizer, batch: Dict, cfg, global_step: int, sync=None, 
         sync.wait(cast_back=g16 is None)
         scale = sync.grad_scale
     set_learning_rates(optimizer, cfg, global_step + 1, n_epoch)
-    optimizer.step(grad_scale=scale, grad16=g16)
+    if sync is not None and getattr(sync, "shard", False) and sync.active:
+        # owner-only update: this rank holds the reduced gradients of 1/world of every bucket (reduce-scatter), updates those pieces,
+        # and the all-gather hands every rank the new compute weights
+        optimizer.step(grad_scale=scale, grad16=g16, pieces=sync.owned_pieces(), norm_reduce=sync.norm_all_reduce)
+        sync.gather_updated()
+    else:
+        optimizer.step(grad_scale=scale, grad16=g16)
     return loss.detach()
 
 
@@ -225,12 +231,16 @@ def start_training(model, optimizer, train_loader, cfg, sync=None, validate_fn=N
     total_bsz = n_gpu * int(_get(cfg, "train_batch_size", 1)) * acc * int(_get(cfg, "max_n_example_per_group", 1) or 1)
     model.train()
 
+    sharded = sync is not None and getattr(sync, "shard", False) and sync.active
+
     def run_validation(step):
         if validate_fn is not None:
             log = validate_fn(model, step)
             if log_fn is not None and log is not None:
                 log_fn(step, log)
         if model_saver is not None:
+            if sharded:
+                sync.gather_state(optimizer)                # (every rank: the fp32 masters and moments return from their owners)
             model_saver.save(step=step, model=model)
 
     if global_step >= num_train_steps:
@@ -244,6 +254,8 @@ def start_training(model, optimizer, train_loader, cfg, sync=None, validate_fn=N
         if log_fn is not None:
             log_fn(global_step, {"train/loss": float(loss.item()) if global_step % 50 == 0 else None})
         if restorer is not None:
+            if sharded and (restorer.global_step + 1) % restorer.save_steps == 0:
+                sync.gather_state(optimizer)                # restore.pt is written by this step()
             restorer.step()
         if valid_steps and global_step % valid_steps == 0:
             run_validation(global_step)

@@ -119,6 +119,11 @@ typedef struct {
  * (src/modeling/modeling.py:534-539, transformers.py:504-515), detectron2 ResNet convs + FrozenBN
  * (src/modeling/grid_feat.py:95) and grid_encoder conv (:43-45,99), and their autograd backward. */
 int cb_gemm(const cb_gemm_desc* d, void* stream);
+/* What cb_gemm would launch for `d` (same validation, nothing launched; the operand pointers are only checked for alignment):
+ * out4 = {tile, split_k, schedule, xcd_order} as the descriptor fields of those names.  d->tile / xcd_order / schedule == 0 (auto) are
+ * resolved by the per-shape table measured on MI355X (csrc/gemm_tuned.h; use_table != 0) and, for shapes outside it, by the launch-cost
+ * model fitted to the same sweeps (csrc/gemm_model.h, tools/fit_gemm_model.py).  For tools and tests. */
+int cb_gemm_plan(const cb_gemm_desc* d, int32_t use_table, int32_t* out4);
 
 /* Output-pixel table of a convolution: entry m=(n,oh,ow) -> offset of input pixel
  * (n, oh*stride-pad, ow*stride-pad) and its (ih0, iw0).  sN/sH/sW in elements. */

@@ -78,12 +78,19 @@ def _train_one_step(rank, world, out_path, compress=None):
             for lo, hi in pieces:
                 mine[lo:hi] = True
             assert torch.equal(bank.master[:bank.n_train][~mine], before[:bank.n_train][~mine])      # other ranks' slices untouched
-        sync.gather_updated(masters=True)
+        sync.gather_updated()               # what a training step does: the compute weights (+ the masters kernels read in fp32)
+        try:
+            opt.state_dict()
+            raise AssertionError("state_dict() of a sharded state must refuse")
+        except RuntimeError as e:
+            assert "gather_state" in str(e)
+        sync.gather_state(opt)              # before a checkpoint: masters and moments from their owners
+        assert len(opt.state_dict()["state"]) > 0
     else:
         opt.step(grad_scale=sync.grad_scale, grad16=g16)
     assert calls == [1]                     # transformer bucket was launched from inside the backward
     if rank == 0:
-        torch.save(dict(master=bank.master.clone(), norm=opt.grad_norm()), out_path)
+        torch.save(dict(master=bank.master.clone(), norm=opt.grad_norm(), exp_avg=bank.exp_avg.clone(), exp_avg_sq=bank.exp_avg_sq.clone()), out_path)
 
 
 def _train_multi_clip_accumulated(rank, world, out_path, compress=None):
@@ -151,6 +158,48 @@ def _sharded_inference(rank, world, out_path, compress=None):
         torch.save(dict(rows=sorted((r["vid_id"], r["txt_id"], r["score"]) for r in rows), metrics=metrics), out_path)
 
 
+def _training_loop(rank, world, out_path, compress=None):
+    """tasks.start_training on 2 ranks: 2 optimizer steps, validation + model_step_N.pt, restore.pt -- with the
+    all-reduce exchange or (compress == "shard") the owner-only update, whose checkpoints need the state back from its owners."""
+    from types import SimpleNamespace
+    import test_model_small as T
+    from clipbert_amd import checkpoint as C
+    from clipbert_amd import data as D
+    from clipbert_amd import synthetic as S
+    from clipbert_amd import tasks
+    from clipbert_amd.dist import GradSync
+    from clipbert_amd.optim import FusedAdamW
+    cpu = torch.device("cpu")
+    cfg, sd, model = T.build("retrieval", dict(num_labels=2, loss_type="ce", margin=0.1), torch.float32, cpu)
+    bank = model.rt.bank
+    shard = compress == "shard"
+    sync = GradSync(bank, shard=shard, bucket_bytes=(1 << 16) if shard else (64 << 20))
+    sync.broadcast_parameters(0)
+    opt = FusedAdamW(bank, lr=1e-3, betas=(0.9, 0.98), weight_decay=1e-3, cnn_lr=1e-3, max_grad_norm=5.0)
+    out_dir = os.path.dirname(out_path) + f"/loop_{compress}"
+    tcfg = SimpleNamespace(train_n_clips=2, num_frm=2, score_agg_func="lse", gradient_accumulation_steps=1, learning_rate=1e-3,
+                           cnn_learning_rate=1e-3, decay="linear", cnn_lr_decay="linear", num_train_steps=2, warmup_ratio=0.0, valid_steps=2,
+                           train_batch_size=1, max_n_example_per_group=1, output_dir=out_dir, save_steps_ratio=0.5)
+    batches = []
+    for i in range(2):                                       # this rank's share: one video (2 clips x 2 frames) + 2 texts per micro-step
+        frames = S.synthetic_frames(1, 4, 64, 50 + 2 * i + rank).contiguous()
+        ids, mask = S.synthetic_text(2, 6, 50 + 2 * i + rank, cfg["vocab_size"])
+        batches.append(dict(visual_inputs=frames, text_input_ids=ids.clamp(max=cfg["vocab_size"] - 1), text_input_mask=mask,
+                            labels=torch.tensor([1, 0]), n_examples_list=[2]))
+    saver = C.ModelSaver(os.path.join(out_dir, "ckpt"))
+    restorer = C.E2E_TrainingRestorer(tcfg, model, opt)
+    end = tasks.start_training(model, opt, D.PrefetchLoader(batches, device=cpu), tcfg, sync=sync, model_saver=saver, restorer=restorer,
+                               total_n_examples=12)
+    assert end == 2
+    if shard:
+        sync.gather_state(opt)
+    if rank == 0:
+        ck = torch.load(os.path.join(out_dir, "restore.pt"))
+        torch.save(dict(master=bank.master.clone(), exp_avg=bank.exp_avg.clone(), step=ck["global_step"],
+                        ckpt_model={k: v for k, v in torch.load(os.path.join(out_dir, "ckpt", "model_step_2.pt")).items()},
+                        restore_optim=ck["optim_state_dict"]["state"]), out_path)
+
+
 def _worker(rank, world, port, out_path, compress=None, fn="one_step"):
     torch.set_num_threads(2)
     os.environ["EMUL_THREADS"] = "4"
@@ -158,7 +207,7 @@ def _worker(rank, world, port, out_path, compress=None, fn="one_step"):
     import torch.distributed as dist
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
-        dict(one_step=_train_one_step, multi=_train_multi_clip_accumulated, infer=_sharded_inference)[fn](rank, world, out_path, compress)
+        dict(one_step=_train_one_step, multi=_train_multi_clip_accumulated, infer=_sharded_inference, loop=_training_loop)[fn](rank, world, out_path, compress)
     finally:
         dist.destroy_process_group()
 
@@ -210,6 +259,25 @@ def test_dp2_owner_only_update_equals_dp1(tmp_path):
     torch.testing.assert_close(s["master"], ar["master"], rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(s16["master"], ar16["master"], rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(s["master"], one["master"], rtol=1e-4, atol=2e-6)
+    for k in ("exp_avg", "exp_avg_sq"):                  # gather_state(): the moments of every piece from its owner
+        torch.testing.assert_close(s[k], ar[k], rtol=1e-5, atol=1e-7)     # (atomic weight-gradient sums differ in the last bits run to run)
+
+
+def test_dp2_training_loop_owner_only_checkpoints_equal_all_reduce(tmp_path):
+    """start_training on two ranks, all-reduce vs owner-only update: same final weights, and the files rank 0 wrote (model_step_2.pt,
+    restore.pt with the AdamW moments) hold the WHOLE state -- gathered from the owners before each save."""
+    ps, pa = str(tmp_path / "loop_s.pt"), str(tmp_path / "loop_a.pt")
+    _spawn_all([(2, ps, "shard", "loop"), (2, pa, None, "loop")])
+    s, a = torch.load(ps), torch.load(pa)
+    assert s["step"] == a["step"] == 2
+    torch.testing.assert_close(s["master"], a["master"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(s["exp_avg"], a["exp_avg"], rtol=1e-5, atol=1e-7)
+    assert set(s["ckpt_model"]) == set(a["ckpt_model"])
+    for k, v in a["ckpt_model"].items():
+        if torch.is_tensor(v) and v.is_floating_point():
+            torch.testing.assert_close(s["ckpt_model"][k], v, rtol=1e-5, atol=1e-7, msg=k)
+    for name, st in a["restore_optim"].items():
+        torch.testing.assert_close(s["restore_optim"][name]["exp_avg_sq"], st["exp_avg_sq"], rtol=1e-4, atol=1e-10, msg=name)
 
 
 def test_sharded_retrieval_inference_gathers_all_rows(tmp_path):

@@ -1,0 +1,88 @@
+"""cb_gemm_plan: what cb_gemm launches for a descriptor (host logic only: runs without a GPU, nothing is launched).
+
+Shapes of the bench steps come from the per-shape table measured on MI355X (csrc/gemm_tuned.h); every other shape is ranked by the
+launch-cost model fitted to the same sweeps (csrc/gemm_model.h, tools/fit_gemm_model.py).  The model's choices are held to the
+committed sweep: their total time may exceed the per-problem best of the sweep by at most the margin recorded at fit time + 3 points."""
+import ctypes as C
+import json
+import os
+import sys
+
+import pytest
+
+from clipbert_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import fit_gemm_model as F  # noqa: E402
+
+
+def plan(M, N, K, a_mode=0, b_mode=0, batch=1, tile=0, split_k=1, use_table=1, ws=True, c_f32=False, accumulate=False):
+    lib = _lib.get()
+    d = _lib.GemmDesc()
+    C.memset(C.byref(d), 0, C.sizeof(d))
+    d.dtype, d.M, d.N, d.K, d.a_mode, d.b_mode, d.batch, d.tile, d.split_k = 1, M, N, K, a_mode, b_mode, batch, tile, split_k
+    d.A = d.B = d.C = 1 << 20
+    d.a_bytes = d.b_bytes = 1 << 30
+    d.lda = M if a_mode == 2 else K
+    d.ldb = N if b_mode == 2 else K
+    d.ldc = N
+    d.c_f32, d.accumulate = int(c_f32), int(accumulate)
+    if batch > 1:
+        d.batch_stride_a, d.batch_stride_b, d.batch_stride_c = K * M, K * N, M * N
+    if ws:
+        d.splitk_ws, d.splitk_ws_bytes = 1 << 20, 128 << 20
+    out = (C.c_int32 * 4)()
+    _lib.check(lib.cb_gemm_plan(C.byref(d), use_table, out), "cb_gemm_plan")
+    return tuple(out)
+
+
+def test_large_untuned_shapes_take_the_8_wave_tiles():
+    for shape in ((4096, 4096, 4096), (8192, 8192, 1024), (6000, 5120, 2048)):
+        tile, split, sched, _ = plan(*shape)
+        assert tile in (5, 6, 7) and split == 1 and sched in (1, 3), (shape, tile, split, sched)
+    tile, split, _, _ = plan(4096, 4096, 4096, a_mode=2, b_mode=2, c_f32=True, accumulate=True)      # weight-gradient form
+    assert tile in (5, 6, 7)
+
+
+def test_small_and_narrow_shapes_stay_on_the_4_wave_tiles():
+    assert plan(64, 2, 1536)[0] == 2                             # a head: one 64x64 tile
+    assert plan(300, 768, 768)[0] in (2, 3)
+    assert plan(200000, 64, 576)[0] in (2, 3)                    # N <= 64 never takes a 128-column tile
+
+
+def test_split_needs_a_workspace_and_long_k_weight_gradients_split():
+    tile, split, _, _ = plan(256, 2304, 100352, a_mode=2, b_mode=2, c_f32=True, accumulate=True, use_table=0)
+    assert split > 1                                             # 36 / 9 tiles of a 100k-deep reduction: K must be split
+    if tile >= 5:
+        assert split * 256 * 2304 * 4 <= 128 << 20
+    tile2, split2, _, _ = plan(256, 2304, 100352, a_mode=2, b_mode=2, c_f32=True, accumulate=True, use_table=0, ws=False)
+    assert tile2 <= 4 or split2 == 1                             # no workspace: no 8-wave split (the atomics path may still split)
+    t3, s3, _, _ = plan(3136, 768, 18432, use_table=0, ws=False)  # bf16 output, no workspace: nothing may split
+    assert s3 == 1
+
+
+def test_explicit_requests_are_kept_and_table_entries_win():
+    assert plan(4096, 4096, 4096, tile=2)[0] == 2
+    assert plan(4096, 4096, 4096, tile=5, split_k=2)[:2] == (5, 2)
+    assert plan(4096, 4096, 4096, tile=5, split_k=2, ws=False)[0] <= 4          # the slab split has nowhere to go: 4-wave kernels
+    # a shape of the metric step: the table's entry, not the model's opinion
+    with_table, without = plan(2624, 3072, 768), plan(2624, 3072, 768, use_table=0)
+    assert with_table[0] in (1, 2, 3, 4, 5, 6, 7) and without[0] in (1, 2, 3, 4, 5, 6, 7)
+
+
+def test_model_choices_against_the_committed_sweep():
+    fit = json.load(open(os.path.join(ROOT, "profiles", "r03m_gemm_model_fit.json")))
+    probs = F.load([os.path.join(ROOT, p) for p in fit["sweeps"]])
+    lib = _lib.get()
+
+    def pick(p):
+        c = F.lib_pick(lib, _lib.GemmDesc, p)
+        us = F.measured(p)
+        if c in us:
+            return c
+        same = [k for k in us if F.parse(k)[0] == F.parse(c)[0] and F.parse(k)[1] != "rr"]
+        return min(same, key=lambda k: abs(F.parse(k)[2] - F.parse(c)[2])) if same else min(us, key=us.get)
+    best, picked = F.regret(pick, probs)
+    regret = 100 * (picked / best - 1)
+    assert regret <= fit["in_sample"]["regret_pct"] + 3.0, (regret, fit["in_sample"])

@@ -122,7 +122,8 @@ double model_us(int ti, int form, int64_t M, int64_t N, int64_t K, int64_t batch
     const int64_t wg = ((M + MODEL_BM[ti] - 1) / MODEL_BM[ti]) * ((N + MODEL_BN[ti] - 1) / MODEL_BN[ti]) * batch * s;
     const int64_t kt = ((K + 63) / 64 + s - 1) / s;
     const double r = (double)wg / (256.0 * MODEL_OCC[ti]);
-    const double rounds = g[3] * std::ceil(r - 1e-9) + (1.0 - g[3]) * (r > 1.0 ? r : 1.0);
+    const double q = ti >= 4 ? g[7] : g[3];                      // how hard the grid is quantised in whole rounds over the CUs
+    const double rounds = q * std::ceil(r - 1e-9) + (1.0 - q) * (r > 1.0 ? r : 1.0);
     const double ck = MODEL_C[ti][form] * (1.0 + g[4] * (taps ? 1 : 0)) * (1.0 + g[8] * (m2 ? 1 : 0));
     const double ab = (double)(M * K + N * K) * 2.0 * batch, cb = (double)M * N * batch * c_esz;
     const double red = (ti >= 4 && s > 1) ? (double)M * N * batch * s * 8.0 : 0.0;

@@ -10,7 +10,7 @@ configuration (tile t, K split s, schedule) on a problem (form f in {fwd, dgrad,
 
     wg     = ceil(M / BM_t) * ceil(N / BN_t) * batch * s                        workgroups
     r      = wg / (256 * occ_t)                                                 rounds of the grid over the CUs
-    rounds = q * ceil(r) + (1 - q) * max(1, r)
+    rounds = q * ceil(r) + (1 - q) * max(1, r)                                  q = q4 (4-wave tiles) or q8 (8-wave: one workgroup per CU, occ = 1)
     T      = a_t + rounds * (b_tf + ceil(ceil(K / 64) / s) * c_tf * (1 + g_taps * [taps > 1]) * (1 + g_m2 * [schedule 2]))
              + (A + B bytes) / bw_ab + (C bytes) / bw_c + (8-wave split: slab bytes) / bw_red + (4-wave split: atomic bytes) / bw_atom
              + d_m2 * [schedule 2]
@@ -29,7 +29,11 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEFAULT_SWEEPS = [os.path.join(ROOT, "profiles", "r03f_gemm_tuning_cold.json")]
+DEFAULT_SWEEPS = [os.path.join(ROOT, "profiles", f) for f in
+                  ("r03f_gemm_tuning_cold.json",          # the bench workloads (train 2x2 / tgif / infer16 / 448 px x 4 clips)
+                   "r03m_sweep_v10_t24_cold.json",        # train, 10 videos, 24 text tokens
+                   "r03o_sweep_fit_cold.json")]           # train 6 videos x 40 tokens, 24 videos, 192 px, 4 clips x 1 frame; tgif 6 videos; infer16 x 32 captions
+DEFAULT_HOLDOUT = os.path.join(ROOT, "profiles", "r03o_sweep_holdout_cold.json")    # train 12 videos x 20 tokens x 256 px; tgif 10 videos: never fitted
 #            name         BM   BN  model index  cb_gemm tile id
 TILES = {"64x64": (64, 64, 0, 2), "128x64": (128, 64, 1, 3), "128x128": (128, 128, 2, 1), "128x128o2": (128, 128, 3, 4),
          "8w256x256": (256, 256, 4, 5), "8w128x256": (128, 256, 5, 6), "8w256x128": (256, 128, 6, 7)}
@@ -61,7 +65,8 @@ def predict(x, f):
     ti, fo = f["ti"], f["form"]
     a, occ, b, c, g = x[ti], x[NT + ti], x[2 * NT + ti * 3 + fo], x[5 * NT + ti * 3 + fo], x[8 * NT:]
     r = f["wg"] / (256 * occ)
-    rounds = g[3] * math.ceil(r - 1e-9) + (1 - g[3]) * max(1.0, r)
+    q = g[7] if ti >= 4 else g[3]
+    rounds = q * math.ceil(r - 1e-9) + (1 - q) * max(1.0, r)
     ck = c * (1 + g[4] * f["taps"]) * (1 + g[8] * f["m2"])
     return (a + rounds * (b + f["kt"] * ck) + f["ab"] / (g[0] * 1e6) + f["cb"] / (g[5] * 1e6) + f["red"] / (g[1] * 1e6) + f["atom"] / (g[2] * 1e6)
             + g[6] * f["m2"])
@@ -82,14 +87,30 @@ def rows_of(probs):
     return [(i, feats(p, c), v) for i, p in enumerate(probs) for c, v in measured(p).items() if parse(c)[1] != "rr"]
 
 
+def predict_vec(x, F):
+    """predict() over arrays (F: dict of numpy arrays, one entry per measurement)"""
+    ti, fo = F["ti"], F["form"]
+    a, occ, b, c, g = x[ti], x[NT + ti], x[2 * NT + ti * 3 + fo], x[5 * NT + ti * 3 + fo], x[8 * NT:]
+    r = F["wg"] / (256 * occ)
+    q = np.where(ti >= 4, g[7], g[3])
+    rounds = q * np.ceil(r - 1e-9) + (1 - q) * np.maximum(1.0, r)
+    ck = c * (1 + g[4] * F["taps"]) * (1 + g[8] * F["m2"])
+    return (a + rounds * (b + F["kt"] * ck) + F["ab"] / (g[0] * 1e6) + F["cb"] / (g[5] * 1e6) + F["red"] / (g[1] * 1e6) + F["atom"] / (g[2] * 1e6)
+            + g[6] * F["m2"])
+
+
 def fit_rows(rows):
     from scipy.optimize import least_squares
-    x0 = np.array([5.0] * NT + [4, 2, 1, 2, 1, 1, 1] + [2.0] * (3 * NT) + [0.3] * 3 + [0.4] * 3 + [0.6] * 3 + [0.6] * 3 + [1.2] * 3 + [1.0] * 6
+    F = {k: np.array([f[k] for _, f, _ in rows], dtype=np.int64 if k in ("ti", "form") else np.float64) for k in rows[0][1]}
+    logv = np.log(np.array([v for _, _, v in rows]))
+    x0 = np.array([5.0] * NT + [4, 2, 1, 1.9, 1, 1, 1] + [2.0] * (3 * NT) + [0.3] * 3 + [0.4] * 3 + [0.6] * 3 + [0.6] * 3 + [1.2] * 3 + [1.0] * 6
                   + [3.0, 3.0, 1.0, 0.5, 0.2, 3.0, 0.0, 0.0, 0.0])
-    lb = np.array([0.0] * NT + [0.25] * NT + [0.0] * (3 * NT) + [0.01] * (3 * NT) + [0.3, 0.3, 0.1, 0, -0.5, 0.3, -5, 0, -0.5])
-    ub = np.array([50.0] * NT + [16] * NT + [50.0] * (3 * NT) + [10.0] * (3 * NT) + [20, 20, 20, 1, 3, 20, 5, 1, 0.5])
-    res = lambda x: [math.log(max(predict(x, f), 1e-3)) - math.log(v) for _, f, v in rows]      # noqa: E731
-    return least_squares(res, x0, bounds=(lb, ub), max_nfev=300).x
+    lb = np.array([0.0] * NT + [1.0, 1.0, 0.5, 0.5] + [0.999] * 3 + [0.0] * (3 * NT) + [0.01] * (3 * NT) + [0.3, 0.3, 0.1, 0, -0.5, 0.3, -5, 0, -0.5])
+    ub = np.array([50.0] * NT + [6.0, 3.0, 1.001, 2.001] + [1.001] * 3 +      # (occupancy: at most what the kernels' LDS / registers allow)
+                  [50.0] * (3 * NT) + [10.0] * (3 * NT) + [20, 20, 20, 1, 3, 20, 5, 1, 0.5])
+    x0[8 * NT + 7] = 0.8                    # (the 8-wave tiles hold one workgroup per CU: their grid is quantised in whole rounds)
+    res = lambda x: np.log(np.maximum(predict_vec(x, F), 1e-3)) - logv       # noqa: E731
+    return least_squares(res, x0, bounds=(lb, ub), max_nfev=400).x
 
 
 def choose(x, p):
@@ -119,7 +140,7 @@ def write_header(x, path, note):
                  f"static const double MODEL_OCC[7] = {{{fmt(occ)}}};\n"
                  f"static const double MODEL_B[7][3] = {{{', '.join('{' + fmt(b[i * 3:i * 3 + 3]) + '}' for i in range(NT))}}};     // [tile][fwd, dgrad, wgrad]\n"
                  f"static const double MODEL_C[7][3] = {{{', '.join('{' + fmt(c[i * 3:i * 3 + 3]) + '}' for i in range(NT))}}};\n"
-                 "// bw_ab, bw_red, bw_atom (bytes / us / 1e6), ceil weight q, g_taps, bw_c, d_m2 (us), (unused), g_m2\n"
+                 "// bw_ab, bw_red, bw_atom (bytes / us / 1e6), ceil weight q of the 4-wave tiles, g_taps, bw_c, d_m2 (us), ceil weight of the 8-wave tiles, g_m2\n"
                  f"static const double MODEL_G[9] = {{{fmt(g)}}};\n"
                  "}  // namespace cbgemm\n")
 
@@ -183,7 +204,7 @@ def lib_pick(lib, GemmDesc, p, use_table=0):
 
 def main():
     cmd = sys.argv[1] if len(sys.argv) > 1 else "fit"
-    paths = sys.argv[2:] or DEFAULT_SWEEPS
+    paths = sys.argv[2:] or (DEFAULT_SWEEPS if cmd == "fit" else DEFAULT_SWEEPS + [DEFAULT_HOLDOUT])
     probs = load(paths)
     if cmd == "fit":
         rows = rows_of(probs)
@@ -199,12 +220,21 @@ def main():
             xr = fit_rows([r for r in rows if r[0] not in test])
             b_, h_ = regret(lambda p: choose(xr, p), [probs[i] for i in test])
             TB, TH = TB + b_, TH + h_
+        rules = lambda p: rules_pick(p) if rules_pick(p) in measured(p) else min(measured(p), key=measured(p).get)      # noqa: E731
+        rb, rh = regret(rules, probs)
         rep = dict(sweeps=[os.path.relpath(p, ROOT) for p in paths], problems=len(probs), measurements=len(rows), rms_log_error=float(err.std()),
-                   in_sample=dict(best_ms=tb / 1e3, model_ms=th / 1e3, regret_pct=100 * (th / tb - 1)),
+                   in_sample=dict(best_ms=tb / 1e3, model_ms=th / 1e3, regret_pct=100 * (th / tb - 1), round2_rules_regret_pct=100 * (rh / rb - 1)),
                    cross_validated_5fold=dict(best_ms=TB / 1e3, model_ms=TH / 1e3, regret_pct=100 * (TH / TB - 1)), parameters=[float(v) for v in x])
+        if os.path.exists(DEFAULT_HOLDOUT) and DEFAULT_HOLDOUT not in [os.path.abspath(p) for p in paths]:
+            hold = load([DEFAULT_HOLDOUT])
+            hb, hh = regret(lambda p: choose(x, p), hold)
+            qb, qh = regret(rules, hold)
+            rep["held_out"] = dict(sweep=os.path.relpath(DEFAULT_HOLDOUT, ROOT), problems=len(hold), best_ms=hb / 1e3, model_ms=hh / 1e3,
+                                   regret_pct=100 * (hh / hb - 1), round2_rules_regret_pct=100 * (qh / qb - 1))
         print(json.dumps({k: v for k, v in rep.items() if k != "parameters"}, indent=1))
         write_header(x, os.path.join(ROOT, "clipbert_amd", "csrc", "gemm_model.h"),
-                     f"{len(rows)} measurements of {len(probs)} problems; 5-fold CV regret {rep['cross_validated_5fold']['regret_pct']:.1f} %")
+                     f"{len(rows)} measurements of {len(probs)} problems; regret vs the sweep's best: 5-fold CV {rep['cross_validated_5fold']['regret_pct']:.1f} %"
+                     + (f", held-out workloads {rep['held_out']['regret_pct']:.1f} %" if "held_out" in rep else ""))
         json.dump(rep, open(os.path.join(ROOT, "profiles", "r03m_gemm_model_fit.json"), "w"), indent=1)
     else:
         sys.path.insert(0, ROOT)
@@ -222,10 +252,13 @@ def main():
                 c = min(same, key=lambda k: abs(math.log2(max(parse(k)[2], 1)) - math.log2(max(parse(c)[2], 1)))) if same else min(measured(p), key=measured(p).get)
             picks[(p["form"], p["M"], p["N"], p["K"], p["batch"], p["taps"])] = c
             return c
-        tb, th = regret(pick, probs)
-        rb, rh = regret(lambda p: rules_pick(p) if rules_pick(p) in measured(p) else min(measured(p), key=measured(p).get), probs)
-        print(f"round-2 rules      : best {rb / 1e3:.2f} ms, picked {rh / 1e3:.2f} ms, regret {100 * (rh / rb - 1):.1f} %")
-        print(f"library (table off): best {tb / 1e3:.2f} ms, picked {th / 1e3:.2f} ms, regret {100 * (th / tb - 1):.1f} %  ({missing} picks not in the sweep: nearest measured split used)")
+        for path in paths:
+            ps = load([path])
+            missing = 0
+            tb, th = regret(pick, ps)
+            rb, rh = regret(lambda p: rules_pick(p) if rules_pick(p) in measured(p) else min(measured(p), key=measured(p).get), ps)
+            print(f"{os.path.relpath(path, ROOT)} ({len(ps)} problems): round-2 rules regret {100 * (rh / rb - 1):.1f} %, library (table off) "
+                  f"{100 * (th / tb - 1):.1f} % (best {tb / 1e3:.2f} ms, picked {th / 1e3:.2f} ms; {missing} picks outside the sweep -> nearest measured split)")
 
 
 if __name__ == "__main__":

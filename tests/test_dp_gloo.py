@@ -230,12 +230,21 @@ def test_dp2_multi_clip_loop_with_accumulation(tmp_path):
     torch.testing.assert_close(a["master"], b["master"], rtol=1e-4, atol=2e-6)
 
 
-def test_dp2_equals_dp1_on_the_global_batch(tmp_path):
-    p2, p2c, p2d, p1 = str(tmp_path / "dp2.pt"), str(tmp_path / "dp2c.pt"), str(tmp_path / "dp2d.pt"), str(tmp_path / "dp1.pt")
-    # p2c: bf16 gradients on the wire; p2d: ... consumed by AdamW without the cast back
-    _spawn_all([(2, p2, None, "one_step"), (2, p2c, "bf16", "one_step"), (2, p2d, "bf16direct", "one_step"), (1, p1, None, "one_step")])
-    a, c, b = torch.load(p2), torch.load(p2c), torch.load(p1)
-    d = torch.load(p2d)
+@pytest.fixture(scope="module")
+def one_step_runs(tmp_path_factory):
+    """one optimizer step of the same global batch under every exchange variant, all spawned at once (11 processes) and shared by the
+    tests below: DP = 1; DP = 2 with fp32 / bf16 wire / bf16 wire consumed directly; DP = 2 owner-only update with fp32 / bf16 wire"""
+    d = tmp_path_factory.mktemp("one_step")
+    jobs = {name: (world, str(d / f"{name}.pt"), compress, "one_step")
+            for name, world, compress in (("dp1", 1, None), ("dp2", 2, None), ("dp2c", 2, "bf16"), ("dp2d", 2, "bf16direct"),
+                                          ("shard", 2, "shard"), ("shard16", 2, "shard16"))}
+    _spawn_all(list(jobs.values()))
+    return {k: torch.load(v[1]) for k, v in jobs.items()}
+
+
+def test_dp2_equals_dp1_on_the_global_batch(one_step_runs):
+    # dp2c: bf16 gradients on the wire; dp2d: ... consumed by AdamW without the cast back
+    a, c, d, b = (one_step_runs[k] for k in ("dp2", "dp2c", "dp2d", "dp1"))
     torch.testing.assert_close(d["master"], c["master"], rtol=0, atol=0)            # same values as cast-back + fp32 AdamW, bit for bit
     assert d["norm"] == c["norm"]
     assert abs(a["norm"] - b["norm"]) / b["norm"] < 1e-3
@@ -247,13 +256,10 @@ def test_dp2_equals_dp1_on_the_global_batch(tmp_path):
     assert diff.max() < 2.5e-3 and diff.mean() < 2e-6, (diff.max(), diff.mean())
 
 
-def test_dp2_owner_only_update_equals_dp1(tmp_path):
+def test_dp2_owner_only_update_equals_dp1(one_step_runs):
     """GradSync(shard=True): reduce-scatter -> AdamW on the owned 1/world of every bucket -> all-gather of the new weights (the
     direct exchange of SURVEY 8e with the optimizer in between) gives the weights of the all-reduce path and of DP = 1."""
-    p2s, p2s16, p2, p2d, p1 = (str(tmp_path / n) for n in ("s.pt", "s16.pt", "ar.pt", "ar16.pt", "dp1.pt"))
-    _spawn_all([(2, p2s, "shard", "one_step"), (2, p2s16, "shard16", "one_step"), (2, p2, None, "one_step"), (2, p2d, "bf16direct", "one_step"),
-                (1, p1, None, "one_step")])
-    s, s16, ar, ar16, one = (torch.load(x) for x in (p2s, p2s16, p2, p2d, p1))
+    s, s16, ar, ar16, one = (one_step_runs[k] for k in ("shard", "shard16", "dp2", "dp2d", "dp1"))
     # same reduced gradients as the all-reduce path; the norm partials are summed in another order (two ranks' halves)
     assert abs(s["norm"] - ar["norm"]) / ar["norm"] < 1e-5 and abs(s16["norm"] - ar16["norm"]) / ar16["norm"] < 1e-5
     torch.testing.assert_close(s["master"], ar["master"], rtol=1e-5, atol=1e-7)

@@ -928,9 +928,6 @@ class _EncoderFn(torch.autograd.Function):
 # =================================================================================================
 # heads (small autograd nodes: one consumer each, so autograd never has to add tensors)
 # =================================================================================================
-_PAD_SMALL_HEADS = False          # diagnostic (tools/r03n_head_check.py)
-
-
 class _LinearFn(torch.autograd.Function):
     """y = act(x W^T + b).  ``rows`` = (n_seg, seg_len, seg_stride_rows) selects x rows (b*stride + t)."""
     @staticmethod
@@ -947,7 +944,7 @@ class _LinearFn(torch.autograd.Function):
             m = nseg * seglen
             tab = rt.table(nseg, 1, seglen, 1, 0, segstride * k, 0, k, dev)
         out_dt = torch.float32 if out_f32 else rt.dtype
-        ld = n if (n < 4 and not _PAD_SMALL_HEADS) else (n + 3) // 4 * 4     # (1- / 2-column head outputs stay contiguous: the losses read them in place)
+        ld = n if n < 4 else (n + 3) // 4 * 4              # (1- / 2-column head outputs stay contiguous: the losses read them in place)
         store = torch.empty(m, ld, dtype=out_dt, device=dev)
         y = store[:, :n]
         save = ctx.needs_input_grad[0]

@@ -1,3 +1,5 @@
+"""bf16 max |delta| of one full-size golden case on the GPU: python tools/golden_bf16_error.py <case>  (try CB_GEMM_NO_MODEL=1 / CB_GEMM_TRACE=1:
+another tile or K split is another fp32 summation order and re-draws the bf16 rounding noise downstream)."""
 import os, sys
 import numpy as np
 import torch

@@ -55,7 +55,38 @@ class NativeComm:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         else:
             rank, world, box = 0, 1, [cls.unique_id()]
-        cls._instance = cls(rank, world, box[0])
+        if world == 1:
+            cls._instance = cls(rank, world, box[0])
+            return cls._instance
+        # Several ranks: ncclCommInitRank and a first collective of THIS library's communicator run in a helper thread with a deadline,
+        # the result (sum of rank + 1 over the ranks) is checked, and the ranks agree over the process group whether everybody passed:
+        # a communicator that cannot be created, hangs or adds wrongly makes every rank raise together (GradSync(comm="auto") then lets
+        # torch.distributed carry the buckets) instead of some ranks proceeding and the job dead-locking in its first bucket.
+        import threading
+        dev = torch.cuda.current_device()
+        out = {}
+
+        def bring_up():
+            try:
+                torch.cuda.set_device(dev)                     # (the current device is per thread)
+                comm = cls(rank, world, box[0])
+                probe = torch.full((1024,), float(rank + 1), dtype=torch.float32, device=f"cuda:{dev}")
+                comm.all_reduce_(probe)
+                torch.cuda.synchronize(dev)
+                out["comm"], out["ok"] = comm, bool((probe == world * (world + 1) / 2).all().item())
+            except Exception as e:                               # noqa: BLE001
+                out["err"] = e
+
+        th = threading.Thread(target=bring_up, daemon=True, name="cb_comm_init")
+        th.start()
+        th.join(timeout=float(__import__("os").environ.get("CB_COMM_INIT_TIMEOUT", "120")))
+        ok = bool(out.get("ok", False))
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=f"cuda:{dev}" if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) != 1:
+            why = out.get("err") or ("no answer within the deadline" if th.is_alive() else "the probe all-reduce returned a wrong sum" if "ok" in out else "failed on another rank")
+            raise RuntimeError(f"NativeComm: bring-up of the library's RCCL communicator failed on at least one rank (rank {rank}: {why})")
+        cls._instance = out["comm"]
         return cls._instance
 
     def all_reduce_(self, t: torch.Tensor, stream=None):

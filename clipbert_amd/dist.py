@@ -449,7 +449,7 @@ class GradSync:
             torch.cuda.current_stream(self.bank.grad.device).wait_stream(self.comm_stream)
         self._work = []
         self._inflight = []
-        if self.shard:
+        if self.shard and self._buckets:               # (a repeated wait() of the same step keeps the pieces of the exchange it completed)
             self._owned_done, self._buckets_done, self._owned, self._buckets = self._owned, self._buckets, [], []
         if not cast_back and self.compress == "bf16":
             self._pending = []

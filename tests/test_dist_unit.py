@@ -106,3 +106,22 @@ def test_wait_without_any_reduce_exchanges_the_whole_buffer(emul):
     torch.testing.assert_close(bank.grad[:bank.n_train], g0[:bank.n_train].bfloat16().float(), rtol=0, atol=0)
     sync.wait()
     assert sync.late_ranges == 1
+
+
+def test_owner_only_pieces_partition_every_bucket_and_survive_a_repeated_wait():
+    """GradSync(shard=True): rank r owns the r-th 1/world of every bucket (groups are padded to 512 elements, so the pieces are whole
+    64-element runs for world 2 / 4 / 8); a second wait() in the same step must not forget them."""
+    bank = _toy_bank()
+    assert all(a % ParamBank.GROUP_ALIGN == 0 and b % ParamBank.GROUP_ALIGN == 0 for a, b in bank.group_range) and bank.n_train % 512 == 0
+    for world in (2, 4, 8):
+        sync = GradSync(bank, compress=None, pretend_world=world, shard=True, bucket_bytes=4096)      # 1024-element buckets
+        sync.reduce_transformer()
+        sync.reduce_cnn()
+        sync.wait()
+        pieces = sync.owned_pieces()
+        assert pieces and all((hi - lo) % 64 == 0 and lo % 64 == 0 for lo, hi in pieces)
+        assert sum(hi - lo for lo, hi in pieces) * world == bank.n_train          # rank 0's share of every bucket
+        sync.wait()
+        assert sync.owned_pieces() == pieces
+        sync.reduce_transformer(); sync.reduce_cnn(); sync.wait()
+        assert sync.owned_pieces() == pieces                                       # the same partition every step

@@ -13,6 +13,10 @@ fi
 (time timeout 600 python bench.py) > $O/bench.log 2>&1; grep -E "timed region|real" $O/bench.log
 (time timeout 300 python bench.py --mode tgif --no-cpu-baseline) > $O/bench_tgif.log 2>&1; grep -E "timed region" $O/bench_tgif.log
 (time timeout 300 python bench.py --mode infer16 --no-cpu-baseline) > $O/bench_infer16.log 2>&1; grep -E "timed region" $O/bench_infer16.log
+(time timeout 300 python bench.py --size 448 --txt-len 20 --n-clips 4 --no-cpu-baseline) > $O/bench_448c4.log 2>&1; grep -E "timed region" $O/bench_448c4.log
+# the data-parallel plans on one GPU with a world-size-1 communicator of the library (real cb_* collectives, captured into the step's graph)
+(time timeout 300 env CB_BENCH_LOOPBACK=1 python bench.py --no-cpu-baseline --no-roofline) > $O/bench_loopback_allreduce.log 2>&1; grep -E "replay plan|timed region" $O/bench_loopback_allreduce.log | cut -c1-200
+(time timeout 300 env CB_BENCH_LOOPBACK=1 CB_BENCH_SHARD=1 python bench.py --no-cpu-baseline --no-roofline) > $O/bench_loopback_owner_only.log 2>&1; grep -E "replay plan|timed region" $O/bench_loopback_owner_only.log | cut -c1-200
 # N > 1 control flow on this 1-GPU box: two ranks share GPU 0, gloo collectives (captures, split replay plan, bucketed exchange,
 # cross-rank parameter check, sharded inference + row gather).  A control-flow check, not a measurement.
 export CB_BENCH_SHARE_GPU=1 CB_BENCH_BACKEND=gloo

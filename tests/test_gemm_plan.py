@@ -86,3 +86,37 @@ def test_model_choices_against_the_committed_sweep():
     best, picked = F.regret(pick, probs)
     regret = 100 * (picked / best - 1)
     assert regret <= fit["in_sample"]["regret_pct"] + 3.0, (regret, fit["in_sample"])
+
+
+def test_random_calls_get_legal_plans():
+    """Whatever the cost model prefers, the plan must be launchable: 8-wave tiles only with 16-byte output chunks and a workspace that
+    holds the slabs of their split; the 4-wave kernels split only the weight-gradient form (fp32 C accumulated in place); narrow outputs
+    never take a 128-column tile; every split owns at least one K tile."""
+    import random
+    rng = random.Random(7)
+    forms = [(0, 0, False), (0, 2, False), (2, 2, True)]                      # (a_mode, b_mode, fp32 accumulate): fwd, dgrad, wgrad
+    seen8 = seen_split4 = 0
+    for _ in range(1500):
+        a_mode, b_mode, wg = rng.choice(forms)
+        M = rng.choice([1, 4, 63, 64, 200, 777, 1312, 2624, 5000, 12544, 50176, 200704])
+        N = rng.choice([1, 2, 8, 64, 72, 128, 256, 768, 1000, 1024, 2304, 3072, 18432])
+        K = rng.choice([8, 64, 128, 256, 512, 768, 2304, 4608, 18432, 100352])
+        ws = rng.random() < 0.7
+        if wg and (M % 8 or N % 8):
+            continue                                                             # (row-contiguous loads of the KROW forms want 8-element rows)
+        tile, split, sched, xcd = plan(M, N, K, a_mode=a_mode, b_mode=b_mode, c_f32=wg, accumulate=wg, ws=ws, use_table=rng.random() < 0.5)
+        ktiles = -(-K // 64)
+        assert tile in (1, 2, 3, 4, 5, 6, 7) and 1 <= split <= max(1, ktiles) and xcd in (1, 2), (M, N, K, tile, split)
+        if tile >= 5:
+            seen8 += 1
+            assert N % 8 == 0 and sched in (1, 2, 3)
+            if split > 1:
+                assert ws and split * M * N * 4 <= 128 << 20
+        else:
+            assert sched == 0
+            if split > 1:
+                seen_split4 += 1
+                assert wg, (M, N, K, a_mode, b_mode, split)
+            if N <= 64:
+                assert tile in (2, 3)
+    assert seen8 > 50 and seen_split4 > 5                      # (the sample reaches both regimes)

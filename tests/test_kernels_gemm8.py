@@ -182,6 +182,43 @@ def test_conv_forward_backward(hw, tile, sched, k, stride, pad, H, W, Cin, Cout)
         torch.testing.assert_close(dw.view(Cout, k, k, Cin), wr.grad.permute(0, 2, 3, 1), rtol=2e-2, atol=8e-2)
 
 
+def test_auto_configuration_of_untabled_shapes(hw):
+    """tile = 0 on shapes that are in no table: the launch-cost model's pick (here: 8-wave tiles with tens of K slabs for thin outputs
+    over a long reduction -- tests/test_gemm_plan.py says what it picks) goes through the same selection -> workspace -> reduce glue
+    the table's entries use; results against torch, and the same bits as the explicitly requested configuration."""
+    import ctypes as C
+    from clipbert_amd import _lib
+    buf = ws(hw, 32 << 20)
+    for form, (M, N, K) in (("fwd", (128, 512, 8192)), ("dgrad", (384, 256, 8192))):
+        a = hw(rnd(M, K, seed=1).to(BF))
+        b = hw(rnd(N, K, seed=2, scale=0.05).to(BF)) if form == "fwd" else hw(rnd(K, N, seed=2, scale=0.05).to(BF))
+        bias = hw(rnd(N, seed=3))
+        kw = dict(shift=bias, act=ops.ACT_RELU) if form == "fwd" else dict(b_mode=ops.KROW, ldb=N)
+        ref = a.float() @ (b.float().t() if form == "fwd" else b.float())
+        ref = torch.relu(ref + bias) if form == "fwd" else ref
+        auto = torch.empty(M, N, dtype=BF, device=hw.dev)
+        ops.gemm(a, b, M, N, K, out=auto, splitk_ws=buf, **kw)
+        torch.testing.assert_close(auto.float(), ref, **TOL)
+        d = _lib.GemmDesc()
+        C.memset(C.byref(d), 0, C.sizeof(d))
+        d.dtype, d.M, d.N, d.K, d.b_mode, d.batch, d.split_k = 1, M, N, K, (0 if form == "fwd" else 2), 1, 1
+        d.A = d.B = d.C = 1 << 20
+        d.a_bytes = d.b_bytes = 1 << 30
+        d.lda, d.ldb, d.ldc = K, (K if form == "fwd" else N), N
+        d.splitk_ws, d.splitk_ws_bytes = 1 << 20, 32 << 20
+        out4 = (C.c_int32 * 4)()
+        _lib.check(_lib.get().cb_gemm_plan(C.byref(d), 1, out4), "cb_gemm_plan")
+        tile, split, sched, _ = out4
+        assert tile >= 5 and split > 1, (form, tuple(out4))              # (the regime this test is about)
+        same = torch.empty(M, N, dtype=BF, device=hw.dev)
+        ops.gemm(a, b, M, N, K, out=same, splitk_ws=buf, tile=tile, split_k=split, schedule=sched, **kw)
+        assert torch.equal(same, auto)
+        # a workspace too small for any slab split: the same call must still be right (no split on offer)
+        nows = torch.empty(M, N, dtype=BF, device=hw.dev)
+        ops.gemm(a, b, M, N, K, out=nows, splitk_ws=torch.empty(4, dtype=torch.float32, device=hw.dev), **kw)
+        torch.testing.assert_close(nows.float(), ref, **TOL)
+
+
 def test_unsupported_shapes_fall_back_to_the_4_wave_kernels(hw):
     """tile 5-7 on a problem the 8-wave kernels do not cover (N % 8 != 0, fp32) must still give the right answer."""
     M, N, K = 70, 36, 72

@@ -62,32 +62,54 @@ class NativeComm:
         # the result (sum of rank + 1 over the ranks) is checked, and the ranks agree over the process group whether everybody passed:
         # a communicator that cannot be created, hangs or adds wrongly makes every rank raise together (GradSync(comm="auto") then lets
         # torch.distributed carry the buckets) instead of some ranks proceeding and the job dead-locking in its first bucket.
-        import threading
         dev = torch.cuda.current_device()
-        out = {}
 
         def bring_up():
+            torch.cuda.set_device(dev)                         # (the current device is per thread)
+            comm = cls(rank, world, box[0])
+            probe = torch.full((1024,), float(rank + 1), dtype=torch.float32, device=f"cuda:{dev}")
+            comm.all_reduce_(probe)
+            torch.cuda.synchronize(dev)
+            return comm, bool((probe == world * (world + 1) / 2).all().item())
+
+        def agree(ok: bool) -> bool:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=f"cuda:{dev}" if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            return int(flag.item()) == 1
+
+        import os
+        cls._instance = cls._bring_up_guarded(bring_up, agree, float(os.environ.get("CB_COMM_INIT_TIMEOUT", "120")), rank)
+        return cls._instance
+
+    @staticmethod
+    def _bring_up_guarded(bring_up, agree, timeout_s: float, rank: int = 0):
+        """``bring_up() -> (communicator, probe_ok)`` in a helper thread with a deadline; ``agree(ok) -> bool`` = AND over the ranks
+        (a collective of the process group: every rank calls it exactly once, whatever happened locally).  Returns the communicator
+        when every rank succeeded; raises RuntimeError on every rank otherwise."""
+        import threading
+        out = {}
+
+        def run():
             try:
-                torch.cuda.set_device(dev)                     # (the current device is per thread)
-                comm = cls(rank, world, box[0])
-                probe = torch.full((1024,), float(rank + 1), dtype=torch.float32, device=f"cuda:{dev}")
-                comm.all_reduce_(probe)
-                torch.cuda.synchronize(dev)
-                out["comm"], out["ok"] = comm, bool((probe == world * (world + 1) / 2).all().item())
+                out["comm"], out["ok"] = bring_up()
             except Exception as e:                               # noqa: BLE001
                 out["err"] = e
 
-        th = threading.Thread(target=bring_up, daemon=True, name="cb_comm_init")
+        th = threading.Thread(target=run, daemon=True, name="cb_comm_init")
         th.start()
-        th.join(timeout=float(__import__("os").environ.get("CB_COMM_INIT_TIMEOUT", "120")))
+        th.join(timeout=timeout_s)
         ok = bool(out.get("ok", False))
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=f"cuda:{dev}" if dist.get_backend(group) == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        if int(flag.item()) != 1:
-            why = out.get("err") or ("no answer within the deadline" if th.is_alive() else "the probe all-reduce returned a wrong sum" if "ok" in out else "failed on another rank")
+        if not agree(ok):
+            if ok:
+                why = "failed on another rank"
+            elif "err" in out:
+                why = repr(out["err"])
+            elif th.is_alive():
+                why = f"no answer within {timeout_s:.0f} s"
+            else:
+                why = "the probe all-reduce returned a wrong sum"
             raise RuntimeError(f"NativeComm: bring-up of the library's RCCL communicator failed on at least one rank (rank {rank}: {why})")
-        cls._instance = out["comm"]
-        return cls._instance
+        return out["comm"]
 
     def all_reduce_(self, t: torch.Tensor, stream=None):
         """in-place sum over the ranks, enqueued on `stream` (default: the current stream)"""

@@ -125,3 +125,28 @@ def test_owner_only_pieces_partition_every_bucket_and_survive_a_repeated_wait():
         assert sync.owned_pieces() == pieces
         sync.reduce_transformer(); sync.reduce_cnn(); sync.wait()
         assert sync.owned_pieces() == pieces                                       # the same partition every step
+
+
+def test_native_communicator_bring_up_is_all_or_nothing():
+    """NativeComm._bring_up_guarded: the multi-rank bring-up of the library's RCCL communicator either succeeds on every rank or raises on
+    every rank -- whether the local attempt raised, answered with a wrong sum, never came back, or another rank reported a failure; the
+    agreement collective is called exactly once in every case."""
+    import time
+    from clipbert_amd.dist import NativeComm
+    calls = []
+
+    def agree_with(others_ok):
+        def agree(ok):
+            calls.append(ok)
+            return ok and others_ok
+        return agree
+    assert NativeComm._bring_up_guarded(lambda: ("comm", True), agree_with(True), 5.0) == "comm" and calls == [True]
+    cases = {"another rank": (lambda: ("comm", True), False), "wrong sum": (lambda: ("comm", False), True),
+             "RuntimeError('boom')": (lambda: (_ for _ in ()).throw(RuntimeError("boom")), True),
+             "no answer within": (lambda: (time.sleep(3.0), ("comm", True))[1], True)}
+    for needle, (work, others_ok) in cases.items():
+        calls.clear()
+        t0 = time.perf_counter()
+        with pytest.raises(RuntimeError, match="bring-up") as ei:
+            NativeComm._bring_up_guarded(work, agree_with(others_ok), 0.3, rank=1)
+        assert needle in str(ei.value) and len(calls) == 1 and time.perf_counter() - t0 < 2.5, (needle, str(ei.value), calls)

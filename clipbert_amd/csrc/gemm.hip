@@ -337,7 +337,7 @@ int gemm_run(const cb_gemm_desc* d, void* stream, int32_t* plan, bool use_table)
                        tile, d->tile, form8, tile >= 5 ? p.split_k : split_caller, ws8 != nullptr);
     if (tile >= 5) {
         static const int mode8_env = getenv("CB_GEMM8_MODE") ? atoi(getenv("CB_GEMM8_MODE")) : 2;
-        CB_REQUIRE(d->schedule >= 0 && d->schedule <= 3, "cb_gemm: bad schedule %d", d->schedule);
+        CB_REQUIRE(d->schedule >= 0 && d->schedule <= 4, "cb_gemm: bad schedule %d", d->schedule);
         const int mode8 = d->schedule > 0 ? d->schedule - 1 : (sched_tuned > 0 ? sched_tuned - 1 : mode8_env);
         p.c_vec8 = 1;
         p.xcd_remap = !no_remap && xcd != 2;

@@ -106,7 +106,7 @@ def main():
         ("fwd", 8192, 8192, 1024, 1), ("fwd", 4096, 4096, 4096, 1), ("dgrad", 8192, 8192, 1024, 1), ("wgrad", 4096, 4096, 4096, 1),
     ]
     if args.quick:
-        shapes = shapes[:3] + shapes[7:8] + shapes[-4:-3]
+        shapes = shapes[:3] + shapes[7:8] + shapes[11:12] + shapes[14:15] + shapes[-4:-2] + shapes[-1:]
     rows = []
     for form, M, N, K, batch in shapes:
         out, ref, run = make(form, M, N, K, batch)
@@ -117,7 +117,7 @@ def main():
             cfgs += [(t, 0, s) for t in (2, 4) for s in (4, 8)]
         for t in (5, 6, 7):
             for s in splits_for(t, M, N, K, batch):
-                cfgs += [(t, sched, s) for sched in (1, 2, 3)]
+                cfgs += [(t, sched, s) for sched in (1, 2, 3, 4)]          # 4 = the persistent kernel (name .../m3)
         res, bad = {}, []
         for t, sched, split in cfgs:
             name = TILE_NAME[t] + (f"/m{sched - 1}" if t >= 5 else "") + (f"/s{split}" if split > 1 else "")
@@ -149,7 +149,7 @@ def main():
     with open(args.out, "w") as fh:
         json.dump(dict(device=torch.cuda.get_device_name(0), rows=rows), fh, indent=1)
     # schedule comparison over all shapes: total time of the best split per (tile, schedule)
-    for sched in (0, 1, 2):
+    for sched in (0, 1, 2, 3):
         tot = 0.0
         for r in rows:
             c = [v for k, v in r["us"].items() if k.startswith("8w") and f"/m{sched}" in k and v]

@@ -36,6 +36,8 @@ class GemmDesc(C.Structure):
 _SIGNATURES = {
     "cb_gemm": [C.POINTER(GemmDesc), vp],
     "cb_gemm_plan": [vp, i32, vp],
+    "cb_gemm_group": [vp, i32, vp],
+    "cb_gemm_workspace_bytes": [vp, vp],
     "cb_build_pixel_table": [vp, i32, i32, i32, i32, i32, i64, i64, i64, vp],
     "cb_stem_pack": [i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "cb_image_norm": [vp, vp, vp, vp, i64, i64, vp],

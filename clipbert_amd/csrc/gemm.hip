@@ -26,6 +26,7 @@
 #include "gemm8_impl.h"
 #include <stdio.h>
 #include <cmath>
+#include <vector>
 
 using namespace cbgemm;
 
@@ -36,6 +37,9 @@ extern template int launch_gemm<bf16, 128, 128, 2>(const GP&, bool, hipStream_t)
 extern template int launch_gemm<bf16, 128, 64, 2>(const GP&, bool, hipStream_t);
 extern template int launch_gemm<bf16, 64, 64, 3>(const GP&, bool, hipStream_t);
 extern template int launch_gemm<bf16, 128, 128, 1, 2>(const GP&, bool, hipStream_t);
+extern template int launch_gemm_group<float, 64, 64, 2, 1>(const GroupArgs&, int, hipStream_t);
+extern template int launch_gemm_group<bf16, 64, 64, 3, 1>(const GroupArgs&, int, hipStream_t);
+extern template int launch_gemm_group<bf16, 128, 128, 1, 2>(const GroupArgs&, int, hipStream_t);
 // 8-wave LDS-DMA structure (gemm8_impl.h), instantiated in gemm8_inst_*.hip
 #define CB_G8_DECL(BM, BN, WGM, WGN, NST)                                                             \
     extern template int launch_gemm8_fwd<BM, BN, WGM, WGN, NST>(const GP&, int, float*, hipStream_t);   \
@@ -178,16 +182,18 @@ int launch8(int form, const GP& p, int mode, float* ws, hipStream_t st) {
 
 
 namespace {
-// cb_gemm proper.  plan != nullptr: validate and choose as a launch would, write {tile, split_k, schedule, xcd_order}, launch nothing.
-int gemm_run(const cb_gemm_desc* d, void* stream, int32_t* plan, bool use_table) {
+// Validation + translation of a descriptor into the kernels' parameter block: everything about a call that does not depend on
+// the launch configuration.  fast: 16-byte range-checked buffer loads are legal; cv8: the row-contiguous (8-column) epilogue is.
+struct Prepared { GP p; bool fast, cv8; };
+int gemm_prepare(const cb_gemm_desc* d, Prepared& out) {
     CB_REQUIRE(d != nullptr, "cb_gemm: null descriptor");
     CB_REQUIRE(d->dtype == CB_F32 || d->dtype == CB_BF16, "cb_gemm: bad dtype %d", d->dtype);
     CB_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, "cb_gemm: negative dims");
-    if (d->M == 0 || d->N == 0) return 0;
     CB_REQUIRE(d->A && d->B && d->C, "cb_gemm: null operand");
     const int esz = d->dtype == CB_BF16 ? 2 : 4;
     const int eps = 16 / esz;
-    GP p{};
+    GP& p = out.p;
+    p = GP{};
     p.A = d->A; p.B = d->B; p.C = d->C; p.C2 = d->C2; p.residual = d->residual; p.mask = d->mask;
     p.dact_pre = d->gelu_grad_pre; p.ldd = d->ld_gelu; p.a_rowsum = d->a_rowsum;
     p.relu_bwd = d->relu_bwd != 0; p.post_scale = d->post_scale; p.post_scale2 = d->post_scale2;
@@ -263,21 +269,9 @@ int gemm_run(const cb_gemm_desc* d, void* stream, int32_t* plan, bool use_table)
     }
     p.a_bytes = (uint32_t)(fast ? d->a_bytes : 0);
     p.b_bytes = (uint32_t)(fast ? d->b_bytes : 0);
-    static const bool no_remap = getenv("CB_GEMM_NO_XCD_REMAP") != nullptr;
-    static const bool no_tuned = getenv("CB_GEMM_NO_TUNED") != nullptr;
     CB_REQUIRE(d->tile >= 0 && d->tile <= 7, "cb_gemm: bad tile %d", d->tile);
     CB_REQUIRE(d->xcd_order >= 0 && d->xcd_order <= 2, "cb_gemm: bad xcd_order %d", d->xcd_order);
     CB_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "cb_gemm: dropout_p out of range");
-    int tile = d->tile, xcd = d->xcd_order;
-    const int split_caller = p.split_k;
-    int split_tuned = 0, sched_tuned = 0;      // K split / K-loop schedule measured best for the table's tile (0: none recorded)
-    if (d->dtype == CB_BF16 && !no_tuned && use_table && (tile == 0 || xcd == 0)) {
-        if (const cbgemm::TunedEntry* e = cbgemm::tuned_lookup(d->a_mode, d->b_mode, d->M, d->N, d->K, p.batch, p.R * p.S, p.split_k)) {
-            static const bool no8w = getenv("CB_GEMM_NO8W") != nullptr;          // diagnostic: ignore the table's 8-wave entries
-            if (tile == 0 && !(no8w && e->tile >= 5)) { tile = e->tile; split_tuned = e->new_split; sched_tuned = e->sched; }
-            if (xcd == 0) xcd = e->xcd;
-        }
-    }
     // vector epilogue: every touched row pointer must be 16-byte (fp32) / 8-byte (bf16) aligned at n%4==0
     const int cesz = d->c_f32 ? 4 : esz;
     bool cv = (d->ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(d->C) % (4 * cesz)) == 0);
@@ -294,6 +288,34 @@ int gemm_run(const cb_gemm_desc* d, void* stream, int32_t* plan, bool use_table)
     if (d->residual) cv8 = cv8 && (d->ldr % 8 == 0) && aligned16(d->residual);
     if (d->mask) cv8 = cv8 && (d->ldm % 8 == 0) && aligned16(d->mask);
     if (d->gelu_grad_pre) cv8 = cv8 && (d->ld_gelu % 8 == 0) && aligned16(d->gelu_grad_pre);
+    out.fast = fast; out.cv8 = cv8;
+    return 0;
+}
+
+// cb_gemm proper.  plan != nullptr: validate and choose as a launch would, write {tile, split_k, schedule, xcd_order}, launch nothing.
+int gemm_run(const cb_gemm_desc* d, void* stream, int32_t* plan, bool use_table) {
+    CB_REQUIRE(d != nullptr, "cb_gemm: null descriptor");
+    CB_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, "cb_gemm: negative dims");
+    if (d->M == 0 || d->N == 0) return 0;
+    Prepared prep;
+    if (int rc = gemm_prepare(d, prep)) return rc;
+    GP& p = prep.p;
+    const bool fast = prep.fast;
+    bool cv8 = prep.cv8;
+    const int esz = d->dtype == CB_BF16 ? 2 : 4;
+    (void)esz;
+    static const bool no_remap = getenv("CB_GEMM_NO_XCD_REMAP") != nullptr;
+    static const bool no_tuned = getenv("CB_GEMM_NO_TUNED") != nullptr;
+    int tile = d->tile, xcd = d->xcd_order;
+    const int split_caller = p.split_k;
+    int split_tuned = 0, sched_tuned = 0;      // K split / K-loop schedule measured best for the table's tile (0: none recorded)
+    if (d->dtype == CB_BF16 && !no_tuned && use_table && (tile == 0 || xcd == 0)) {
+        if (const cbgemm::TunedEntry* e = cbgemm::tuned_lookup(d->a_mode, d->b_mode, d->M, d->N, d->K, p.batch, p.R * p.S, p.split_k)) {
+            static const bool no8w = getenv("CB_GEMM_NO8W") != nullptr;          // diagnostic: ignore the table's 8-wave entries
+            if (tile == 0 && !(no8w && e->tile >= 5)) { tile = e->tile; split_tuned = e->new_split; sched_tuned = e->sched; }
+            if (xcd == 0) xcd = e->xcd;
+        }
+    }
 
     // ---- 8-wave LDS-DMA tiles (5: 256x256, 6: 128x256, 7: 256x128), bf16 fast path, row-contiguous epilogue.  Their K split
     // writes fp32 partial slabs into the caller's workspace and a second kernel adds them in index order and applies the FULL
@@ -399,10 +421,185 @@ int gemm_run(const cb_gemm_desc* d, void* stream, int32_t* plan, bool use_table)
 
 extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) { return gemm_run(d, stream, nullptr, true); }
 
+// ---- cb_gemm_group -------------------------------------------------------------------------------------------------------------
+namespace {
+// kernel class of a prepared problem for the grouped kernels, or -1: launched on its own
+int group_class(const cb_gemm_desc* d, const Prepared& pr) {
+    if (!pr.fast || d->batch > 1 || d->a_rowsum || d->zero_fill_pitch || d->tile >= 5 || d->tile == 1 || d->tile == 3) return -1;
+    if (d->a_mode == CB_KROW && d->b_mode == CB_KROW) return GC_WGRAD;
+    if (d->a_mode == CB_KROW && d->b_mode == CB_KROW_GATHER) return GC_WGRAD_GATHER;
+    if (d->a_mode == CB_ROWK && d->b_mode == CB_ROWK) return GC_FWD;
+    if (d->a_mode == CB_ROWK_GATHER && d->b_mode == CB_ROWK) return GC_FWD_GATHER;
+    return -1;
+}
+// the K split of a problem may be chosen freely where partial sums combine through atomics (cb_gemm's own rule)
+bool split_is_free(const cb_gemm_desc* d) {
+    return d->a_mode == CB_KROW && d->c_f32 && d->accumulate && !d->C2 && !d->residual && !d->mask && !d->gelu_grad_pre && d->act == CB_ACT_NONE &&
+           !d->relu_after && !d->shift && d->dropout_p <= 0.f;
+}
+
+struct GroupItem { const cb_gemm_desc* d; Prepared pr; int cls; int split; };
+
+// Launch configuration of one grouped launch (bf16): tile 2 (64x64) or 4 (128x128, two workgroups per CU) and a K split per problem.
+// Cost model (calibrated on the in-step durations of profiles/r03z_train_step.md; tools/group_probe.py re-measures it): a CU retires
+// the K tiles of its resident workgroups at a fixed aggregate rate once it holds enough of them -- 0.30 us per 64x64 K tile
+// (~445 TF chip-wide), 0.77 us per 128x128 one (~700 TF) -- so a launch costs its fixed part plus (workgroups per CU) x (K tiles
+// per workgroup) x that unit, plus the fp32 atomics of the split problems at ~2 TB/s.
+double group_cost(const std::vector<GroupItem*>& g, int tile, int s, int* splits) {
+    const int B = tile == 4 ? 128 : 64;
+    int maxkt = 1;
+    for (auto* it : g) maxkt = it->pr.p.ktiles > maxkt ? it->pr.p.ktiles : maxkt;
+    const int kt_target = (maxkt + s - 1) / s;
+    int64_t W = 0;
+    int kt_per_max = 1;
+    double atom = 0.0;
+    for (size_t i = 0; i < g.size(); ++i) {
+        const cb_gemm_desc* d = g[i]->d;
+        const int kt = g[i]->pr.p.ktiles;
+        int si = d->split_k > 0 ? d->split_k : 1;
+        if (split_is_free(d)) {
+            si = (kt + kt_target / 2) / kt_target;
+            if (si < 1) si = 1;
+            while (si > 1 && kt / si < 4) --si;                    // (every split keeps at least four K tiles)
+        }
+        if (si > kt) si = kt > 0 ? kt : 1;
+        splits[i] = si;
+        const int64_t tiles = (int64_t)((d->M + B - 1) / B) * ((d->N + B - 1) / B);
+        W += tiles * si;
+        const int per = (kt + si - 1) / si;
+        kt_per_max = per > kt_per_max ? per : kt_per_max;
+        if (si > 1) atom += (double)d->M * d->N * 4.0 * si;
+    }
+    const int64_t per_cu = (W + 255) / 256;
+    double unit;
+    if (tile == 4) unit = per_cu <= 1 ? 1.0 : 0.77;
+    else unit = per_cu <= 1 ? 0.45 : (per_cu == 2 ? 0.35 : 0.30);
+    // workgroups beyond what a CU holds at once (2 / 4) queue behind the first round: their K loops do not overlap
+    return 8.0 + (double)per_cu * kt_per_max * unit + atom / 2.0e6;
+}
+
+int launch_group_chunk(std::vector<GroupItem*>& g, int dtype, int cls, hipStream_t st) {
+    static const bool no_remap = getenv("CB_GEMM_NO_XCD_REMAP") != nullptr;
+    static const bool no_wide = getenv("CB_GEMM_NO_WIDE_EPILOGUE") != nullptr;
+    static const bool trace = getenv("CB_GEMM_TRACE") != nullptr;
+    int splits[GROUP_MAX];
+    int tile = 2;
+    if (dtype == CB_F32) {
+        for (size_t i = 0; i < g.size(); ++i) splits[i] = g[i]->d->split_k > 0 ? g[i]->d->split_k : 1;
+    } else {
+        const int asked = g[0]->d->tile;
+        bool narrow = false;
+        for (auto* it : g) narrow = narrow || it->d->N <= 64;
+        if (asked == 2 || asked == 4) {                              // explicit: the caller's tile and splits
+            tile = asked;
+            for (size_t i = 0; i < g.size(); ++i) splits[i] = g[i]->d->split_k > 0 ? g[i]->d->split_k : 1;
+        } else {
+            static const int SPLITS[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+            bool any_free = false;
+            for (auto* it : g) any_free = any_free || split_is_free(it->d);
+            double best = 1e300;
+            int tmp[GROUP_MAX];
+            for (int t : {2, 4}) {
+                if (t == 4 && narrow) continue;
+                for (int s : SPLITS) {
+                    if (s > 1 && !any_free) break;
+                    const double c = group_cost(g, t, s, tmp);
+                    if (c < best) { best = c; tile = t; for (size_t i = 0; i < g.size(); ++i) splits[i] = tmp[i]; }
+                }
+            }
+        }
+    }
+    const int B = (dtype == CB_BF16 && tile == 4) ? 128 : 64;
+    GroupArgs ga{};
+    ga.n = (int)g.size();
+    int xcd = 0;
+    int64_t acc = 0;
+    for (size_t i = 0; i < g.size(); ++i) {
+        const cb_gemm_desc* d = g[i]->d;
+        GP p = g[i]->pr.p;
+        p.split_k = splits[i] > p.ktiles ? (p.ktiles > 0 ? p.ktiles : 1) : splits[i];
+        if (p.split_k > 1) {
+            CB_REQUIRE(d->c_f32, "cb_gemm_group: split_k > 1 needs an fp32 output");
+            CB_REQUIRE(!d->C2 && !d->residual && !d->mask && !d->gelu_grad_pre && d->act == CB_ACT_NONE && !d->relu_after && !d->shift && d->dropout_p <= 0.f,
+                       "cb_gemm_group: split_k > 1 supports only scale/alpha in the epilogue");
+        }
+        p.c_vec8 = g[i]->pr.cv8 && p.split_k == 1 && !no_wide;
+        if (d->xcd_order != 0) xcd = d->xcd_order;
+        acc += (int64_t)((d->M + B - 1) / B) * ((d->N + B - 1) / B) * p.split_k;
+        CB_REQUIRE(acc < (1ll << 30), "cb_gemm_group: too many workgroups");
+        ga.tile_end[i] = (int)acc;
+        ga.g[i] = p;
+        if (trace) fprintf(stderr, "cb_gemm_group[%zu/%zu]: M=%d N=%d K=%d modes=%d/%d cls=%d tile=%d split=%d\n", i, g.size(), d->M, d->N, d->K, d->a_mode,
+                           d->b_mode, cls, tile, p.split_k);
+    }
+    ga.xcd_remap = !no_remap && xcd != 2;
+    if (dtype == CB_F32) return launch_gemm_group<float, 64, 64, 2, 1>(ga, cls, st);
+    if (tile == 4) return launch_gemm_group<bf16, 128, 128, 1, 2>(ga, cls, st);
+    return launch_gemm_group<bf16, 64, 64, 3, 1>(ga, cls, st);
+}
+}  // namespace
+
+extern "C" int cb_gemm_group(const cb_gemm_desc* descs, int32_t n, void* stream) {
+    CB_REQUIRE(n >= 0 && (n == 0 || descs != nullptr), "cb_gemm_group: bad arguments");
+    static const bool off = getenv("CB_GEMM_NO_GROUP") != nullptr;        // diagnostic: every problem as its own cb_gemm launch
+    std::vector<GroupItem> items;
+    items.reserve(n);
+    for (int i = 0; i < n; ++i) {
+        const cb_gemm_desc* d = descs + i;
+        CB_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, "cb_gemm_group: negative dims (problem %d)", i);
+        if (d->M == 0 || d->N == 0) continue;
+        GroupItem it{d, Prepared{}, -1, 1};
+        if (int rc = gemm_prepare(d, it.pr)) return rc;
+        it.cls = off ? -1 : group_class(d, it.pr);
+        items.push_back(it);
+    }
+    hipStream_t st = cb_stream(stream);
+    std::vector<char> done(items.size(), 0);
+    for (size_t i = 0; i < items.size(); ++i) {
+        if (done[i]) continue;
+        if (items[i].cls < 0) {                                           // not covered by a grouped kernel
+            done[i] = 1;
+            if (int rc = gemm_run(items[i].d, stream, nullptr, true)) return rc;
+            continue;
+        }
+        std::vector<GroupItem*> bucket;                                   // same dtype and class (and an explicit tile request in common), caller's order
+        for (size_t j = i; j < items.size(); ++j)
+            if (!done[j] && items[j].cls == items[i].cls && items[j].d->dtype == items[i].d->dtype && items[j].d->tile == items[i].d->tile) {
+                bucket.push_back(&items[j]);
+                done[j] = 1;
+            }
+        if (bucket.size() == 1) {
+            if (int rc = gemm_run(bucket[0]->d, stream, nullptr, true)) return rc;
+            continue;
+        }
+        const size_t nchunks = (bucket.size() + GROUP_MAX - 1) / GROUP_MAX;
+        const size_t per = (bucket.size() + nchunks - 1) / nchunks;
+        for (size_t c = 0; c < bucket.size(); c += per) {
+            std::vector<GroupItem*> chunk(bucket.begin() + c, bucket.begin() + (c + per < bucket.size() ? c + per : bucket.size()));
+            if (int rc = launch_group_chunk(chunk, items[i].d->dtype, items[i].cls, st)) return rc;
+        }
+    }
+    return 0;
+}
+
 extern "C" int cb_gemm_plan(const cb_gemm_desc* d, int32_t use_table, int32_t* out4) {
     CB_REQUIRE(out4 != nullptr, "cb_gemm_plan: null output");
     out4[0] = out4[1] = out4[2] = out4[3] = 0;
     return gemm_run(d, nullptr, out4, use_table != 0);
+}
+
+// K-split scratch cb_gemm would use for `d` if it were handed an unlimited one: what a caller sizes splitk_ws by.
+extern "C" int cb_gemm_workspace_bytes(const cb_gemm_desc* d, int64_t* bytes) {
+    CB_REQUIRE(d != nullptr && bytes != nullptr, "cb_gemm_workspace_bytes: null argument");
+    *bytes = 0;
+    alignas(16) static float dummy[4];
+    cb_gemm_desc q = *d;
+    q.splitk_ws = dummy;                                   // (never dereferenced in plan mode)
+    q.splitk_ws_bytes = (int64_t)1 << 60;
+    int32_t plan[4] = {0, 0, 0, 0};
+    if (int rc = gemm_run(&q, nullptr, plan, true)) return rc;
+    if (plan[0] >= 5 && plan[1] > 1) *bytes = (int64_t)plan[1] * (d->batch > 1 ? d->batch : 1) * d->M * d->N * 4;
+    return 0;
 }
 
 extern "C" int cb_build_pixel_table(cb_pixel* tab, int32_t N, int32_t OH, int32_t OW, int32_t stride, int32_t pad,

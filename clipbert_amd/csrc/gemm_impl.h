@@ -1047,8 +1047,9 @@ __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 
 
 // OCC = blocks per CU the register allocation must leave room for (__launch_bounds__'s second argument counts waves per SIMD;
 // a 256-thread block puts one wave on each SIMD)
-template <typename T, int BM, int BN, typename LA, typename LB, int PF, bool RS = false, int OCC = 1>
-__global__ void __launch_bounds__(256, OCC) gemm_kernel(GP p) {
+// One output tile of one problem: everything a workgroup of gemm_kernel / gemm_group_kernel does once it knows its (problem, tile).
+template <typename T, int BM, int BN, typename LA, typename LB, int PF, bool RS, int OCC>
+__device__ __forceinline__ void gemm_tile(GP& p, TileId bid) {
     using X = Tr<T>;
     constexpr int BK = X::BK;
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
@@ -1058,7 +1059,6 @@ __global__ void __launch_bounds__(256, OCC) gemm_kernel(GP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    TileId bid = tile_id(p);
     apply_batch(p, bid);
     const int m0 = bid.by * BM, n0 = bid.bx * BN;
     const int kt_per = (p.ktiles + p.split_k - 1) / p.split_k;
@@ -1232,6 +1232,54 @@ __global__ void __launch_bounds__(256, OCC) gemm_kernel(GP p) {
     }
     if constexpr (EPF != 0) tile_epilogue<T, BM, BN, SMEM_BYTES, EPF>(p, acc, smem, m0, n0, tid, epre, epf_on);
     else tile_epilogue<T, BM, BN, SMEM_BYTES>(p, acc, smem, m0, n0, tid);
+}
+
+template <typename T, int BM, int BN, typename LA, typename LB, int PF, bool RS = false, int OCC = 1>
+__global__ void __launch_bounds__(256, OCC) gemm_kernel(GP p) {
+    gemm_tile<T, BM, BN, LA, LB, PF, RS, OCC>(p, tile_id(p));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grouped launch (cb_gemm_group): up to GROUP_MAX independent problems of ONE kernel class (same tile, same loaders) share a
+// grid.  The problem table travels in the kernel arguments (no device-side table to keep alive, capturable into a hipGraph as
+// is); workgroup `lin` -- after the XCD-compact remap over the WHOLE grid, so that a problem's tiles stay on one L2 -- finds its
+// problem by a scan over the prefix sums and then runs exactly gemm_kernel's tile code.  A launch of many small problems fills
+// the chip where each of them alone is a fraction of a round of workgroups, and the problems' cold starts / store tails overlap.
+// ---------------------------------------------------------------------------------------------
+constexpr int GROUP_MAX = 10;
+struct GroupArgs {
+    int n, xcd_remap;
+    int tile_end[GROUP_MAX];          // problem i owns workgroups [tile_end[i-1], tile_end[i])
+    GP g[GROUP_MAX];
+};
+static_assert(sizeof(GroupArgs) + 256 <= 4096, "kernel arguments (+ the hidden ones) are limited to 4 KiB");
+
+template <int BM, int BN>
+__device__ __forceinline__ int group_locate(const GroupArgs& ga, TileId& bid) {
+    const unsigned total = gridDim.x;
+    unsigned lin = blockIdx.x;
+    if (ga.xcd_remap) {
+        const unsigned xcd = lin & 7u, i = lin >> 3;
+        const unsigned q = total >> 3, r = total & 7u;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    int pi = 0;
+    while (pi + 1 < ga.n && lin >= (unsigned)ga.tile_end[pi]) ++pi;
+    const unsigned local = lin - (pi > 0 ? (unsigned)ga.tile_end[pi - 1] : 0u);
+    const unsigned gx = (unsigned)((ga.g[pi].N + BN - 1) / BN), gy = (unsigned)((ga.g[pi].M + BM - 1) / BM);
+    bid.bx = (int)(local % gx);
+    const unsigned rest = local / gx;
+    bid.by = (int)(rest % gy);
+    bid.bz = (int)(rest / gy);
+    return pi;
+}
+
+template <typename T, int BM, int BN, typename LA, typename LB, int PF, bool RS = false, int OCC = 1>
+__global__ void __launch_bounds__(256, OCC) gemm_group_kernel(GroupArgs ga) {
+    TileId bid;
+    const int pi = group_locate<BM, BN>(ga, bid);
+    GP p = ga.g[pi];
+    gemm_tile<T, BM, BN, LA, LB, PF, RS, OCC>(p, bid);
 }
 
 // =============================================================================================
@@ -1553,5 +1601,36 @@ int launch_gemm(const GP& p, bool fast, hipStream_t st) {
     return launch_k<T, BM, BN, PF, OCC, KrowLoader<T, BM, false>, KrowLoader<T, BN, false>>(p, st);
 }
 
+// ---- grouped launches: the kernel classes cb_gemm_group covers (fast path only; everything else is launched problem by problem)
+enum { GC_WGRAD = 0,        // A KROW, B KROW            (weight gradient of a Linear / 1x1 stride-1 convolution)
+       GC_WGRAD_GATHER = 1, // A KROW, B KROW_GATHER     (weight gradient of a convolution: pixels gathered)
+       GC_FWD = 2,          // A ROWK, B ROWK            (Linear / 1x1 stride-1 convolution forward)
+       GC_FWD_GATHER = 3,   // A ROWK_GATHER, B ROWK     (convolution forward)
+       GC_COUNT = 4 };
+
+template <typename T, int BM, int BN, int PF, int OCC>
+int launch_gemm_group(const GroupArgs& ga, int cls, hipStream_t st) {
+    const dim3 grid((unsigned)ga.tile_end[ga.n - 1]);
+#define CB_LAUNCH_GROUP(LA_, LB_)                                                                                     \
+    do {                                                                                                              \
+        hipLaunchKernelGGL((gemm_group_kernel<T, BM, BN, LA_, LB_, PF, false, OCC>), grid, dim3(NTHREADS), 0, st, ga); \
+        return cb_launch_status("cb_gemm_group");                                                                     \
+    } while (0)
+    using RA0 = RowkFast<T, BM, false>; using RA1 = RowkFast<T, BM, true>; using RB0 = RowkFast<T, BN, false>;
+    if constexpr (sizeof(T) == 2) {
+        using KA = KrowTr<BM, KM_PLAIN>; using KB0 = KrowTr<BN, KM_PLAIN>; using KB2 = KrowTr<BN, KM_GATHER>;
+        if (cls == GC_WGRAD) CB_LAUNCH_GROUP(KA, KB0);
+        if (cls == GC_WGRAD_GATHER) CB_LAUNCH_GROUP(KA, KB2);
+    } else {
+        constexpr int KB2A = BM >= 128 ? 8 : 4, KB2B = BN >= 128 ? 8 : 4;
+        using KA = KrowFast<T, BM, KM_PLAIN, KB2A, 0>; using KB0 = KrowFast<T, BN, KM_PLAIN, KB2B, 128>; using KB2 = KrowFast<T, BN, KM_GATHER, KB2B, 128>;
+        if (cls == GC_WGRAD) CB_LAUNCH_GROUP(KA, KB0);
+        if (cls == GC_WGRAD_GATHER) CB_LAUNCH_GROUP(KA, KB2);
+    }
+    if (cls == GC_FWD) CB_LAUNCH_GROUP(RA0, RB0);
+    if (cls == GC_FWD_GATHER) CB_LAUNCH_GROUP(RA1, RB0);
+#undef CB_LAUNCH_GROUP
+    return cb_fail("cb_gemm_group: unknown kernel class %d", cls);
+}
 
 }  // namespace cbgemm

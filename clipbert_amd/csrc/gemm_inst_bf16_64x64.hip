@@ -3,4 +3,5 @@
 
 namespace cbgemm {
 template int launch_gemm<bf16, 64, 64, 3>(const GP&, bool, hipStream_t);
+template int launch_gemm_group<bf16, 64, 64, 3, 1>(const GroupArgs&, int, hipStream_t);
 }

@@ -3,4 +3,5 @@
 
 namespace cbgemm {
 template int launch_gemm<float, 64, 64, 2>(const GP&, bool, hipStream_t);
+template int launch_gemm_group<float, 64, 64, 2, 1>(const GroupArgs&, int, hipStream_t);
 }

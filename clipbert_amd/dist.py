@@ -51,8 +51,17 @@ class NativeComm:
             return cls._instance
         if dist.is_initialized():
             rank, world = dist.get_rank(group), dist.get_world_size(group)
-            box = [cls.unique_id() if rank == 0 else None]
+            # rank 0 ALWAYS enters the broadcast: if it cannot even create the id (library without RCCL, dlopen failure) it sends the
+            # error instead, and every rank raises together -- nobody is left waiting in the collective
+            box = [None]
+            if rank == 0:
+                try:
+                    box = [cls.unique_id()]
+                except Exception as e:                           # noqa: BLE001
+                    box = [("error", repr(e))]
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            if not isinstance(box[0], (bytes, bytearray)):
+                raise RuntimeError(f"NativeComm: rank 0 could not create the RCCL unique id: {box[0][1] if box[0] else 'nothing received'}")
         else:
             rank, world, box = 0, 1, [cls.unique_id()]
         if world == 1:
@@ -78,7 +87,17 @@ class NativeComm:
             return int(flag.item()) == 1
 
         import os
-        cls._instance = cls._bring_up_guarded(bring_up, agree, float(os.environ.get("CB_COMM_INIT_TIMEOUT", "120")), rank)
+        try:
+            cls._instance = cls._bring_up_guarded(bring_up, agree, float(os.environ.get("CB_COMM_INIT_TIMEOUT", "120")), rank)
+        except RuntimeError:
+            # ranks whose own bring-up succeeded still hold a communicator inside the library: drop it, so that a later
+            # cb_comm_init (another attempt, another group) starts clean
+            try:
+                from . import _lib
+                _lib.get().cb_comm_destroy()
+            except Exception:                                    # noqa: BLE001
+                pass
+            raise
         return cls._instance
 
     @staticmethod
@@ -213,6 +232,8 @@ class GradSync:
         self._owned: List = []              # (lo, hi) pieces of the flat buffers this rank owns, from the buckets reduced since wait()
         self._buckets: List = []            # (s, e) of every bucket of the current exchange
         self._epoch_done = getattr(bank, "grad_epoch", 0)    # bank.grad_epoch (one per zero_grad) of the last completed exchange
+        self._grid = None                   # bucket_grid(): fixed at first use
+        self._grid_used = False
         want_native = comm == "native" or (comm == "auto" and dist.is_initialized() and bank.grad.is_cuda and dist.get_backend(group) == "nccl")
         want_native = want_native or self.loopback
         if want_native and (self.world > 1 or self.loopback) and not self.dry:
@@ -252,13 +273,34 @@ class GradSync:
         """The CNN range is [grid_encoder | res3 | res4 | res5] (the reference's parameter-group order); its two ends -- grid_encoder
         and res5, ~3/4 of the bytes -- are final when the ResNet backward has passed res5 (modeling.cnn_backward_steps yields there).
         ``res5_start`` = modeling.cnn_early_split(model); None switches the split off."""
-        self.c_early = []
-        if res5_start is None:
-            return
-        lo, hi = self.c_range
-        mid = self.bank.group_range[6][0]           # end of the grid_encoder groups = start of the backbone group
-        assert lo <= mid <= res5_start <= hi, (lo, mid, res5_start, hi)
-        self.c_early = [r for r in ((lo, mid), (res5_start, hi)) if r[1] > r[0]]
+        new = []
+        if res5_start is not None:
+            lo, hi = self.c_range
+            mid = self.bank.group_range[6][0]           # end of the grid_encoder groups = start of the backbone group
+            assert lo <= mid <= res5_start <= hi, (lo, mid, res5_start, hi)
+            new = [r for r in ((lo, mid), (res5_start, hi)) if r[1] > r[0]]
+        if new != self.c_early:
+            # the split moves the bucket grid, i.e. (shard=True) which rank owns which elements: the AdamW moments and fp32 masters
+            # never travel between steps, so the grid may only change while no owner-only update has happened on it
+            assert not (self.shard and self._grid_used), \
+                "GradSync.set_cnn_split after an owner-only exchange: the ownership of optimizer state is fixed by the first one"
+            self.c_early = new
+            self._grid = None
+
+    def bucket_grid(self):
+        """The FIXED list of (start, end) buckets of the flat gradient buffer: the canonical ranges (transformer; the CNN range cut at
+        the set_cnn_split points) each divided from ITS start in steps of bucket_elems.  Every exchange -- the overlap hooks, reduce_cnn
+        with or without the early part, the safety net of wait() -- is made of whole buckets of this grid, whatever range it was
+        issued for: with shard=True the owner of an element (and of its AdamW moments / fp32 master) therefore never changes."""
+        if self._grid is None:
+            cuts = sorted({self.t_range[0], self.t_range[1], self.c_range[1]} | {x for r in self.c_early for x in r})
+            grid = []
+            for a, b in zip(cuts, cuts[1:]):
+                step = self.bucket_elems if self.bucket_elems > 0 else (b - a)
+                for s0 in range(a, b, max(step, 1)):
+                    grid.append((s0, min(b, s0 + step)))
+            self._grid = grid
+        return self._grid
 
     def attach(self, model):
         """Arm the overlap hooks of a prepared ClipBert: the transformer buckets leave from the end of the last encoder backward of a
@@ -310,9 +352,14 @@ class GradSync:
             assert e0 <= a or b <= s0, (f"GradSync: gradients [{a}, {b}) are already being reduced ([{s0}, {e0})): "
                                         "wait() before reducing a range again (one exchange per optimizer step)")
         self._inflight.append((a, b))
-        step = self.bucket_elems if self.bucket_elems > 0 else (b - a)
-        for s in range(a, b, step):
-            e = min(b, s + step)
+        buckets = [(s, e) for s, e in self.bucket_grid() if a <= s and e <= b]
+        covered = sum(e - s for s, e in buckets)
+        if covered != b - a or (buckets and (buckets[0][0] != a or buckets[-1][1] != b)):
+            raise RuntimeError(f"GradSync: [{a}, {b}) is not a union of whole buckets of the fixed grid (canonical cuts "
+                               f"{sorted({x for r in [self.t_range, self.c_range] + list(self.c_early) for x in r})}): reduce the transformer / CNN ranges "
+                               "(or their set_cnn_split parts), not arbitrary slices")
+        self._grid_used = True
+        for s, e in buckets:
             if self.shard:
                 assert (e - s) % (64 * self.world) == 0, "shard=True: ranges must start / end at multiples of world x 64 elements (ParamBank.GROUP_ALIGN)"
                 n = (e - s) // self.world
@@ -378,7 +425,9 @@ class GradSync:
         if not self.active or self.dry:
             return
         bank = self.bank
-        nd = [bank.group_range[g] for g in (1, 3, 5, 7)]
+        # what kernels read in fp32: every 1-D parameter (biases, LayerNorm / BatchNorm vectors -- the regression head's
+        # BatchNorm1d.weight sits in a DECAY group) plus, as before, whole no-decay groups
+        nd = [bank.group_range[g] for g in (1, 3, 5, 7)] + bank.fp32_read_ranges()
         for s, e in self._buckets_done:
             if bank.w16 is not None:
                 self._gather(bank.w16[s:e])
@@ -472,7 +521,11 @@ class GradSync:
         self._work = []
         self._inflight = []
         if self.shard and self._buckets:               # (a repeated wait() of the same step keeps the pieces of the exchange it completed)
-            self._owned_done, self._buckets_done, self._owned, self._buckets = self._owned, self._buckets, [], []
+            # one exchange = every bucket of the fixed grid exactly once: the owned pieces are the same set every step
+            if sorted(self._buckets) != self.bucket_grid():
+                raise RuntimeError("GradSync(shard=True): the exchange of this step did not cover the bucket grid exactly once "
+                                   f"({len(self._buckets)} buckets issued, {len(self.bucket_grid())} in the grid)")
+            self._owned_done, self._buckets_done, self._owned, self._buckets = sorted(self._owned), sorted(self._buckets), [], []
         if not cast_back and self.compress == "bf16":
             self._pending = []
             return
@@ -484,14 +537,32 @@ class GradSync:
                 self.bank.grad[s:e].copy_(self._wire[s:e])
         self._pending = []
 
+    def _broadcast(self, t: torch.Tensor, src: int):
+        if self.native is not None:                      # cb_broadcast_bucket on the current stream
+            self.native.broadcast_(t, src)
+        else:
+            dist.broadcast(t, dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
+
     def broadcast_parameters(self, src: int = 0):
         """hvd.broadcast_parameters equivalent (run_video_retrieval.py:304): one flat buffer per kind."""
         if not self.active or self.dry:
             return
-        if self.native is not None:                      # cb_broadcast_bucket on the current stream
-            self.native.broadcast_(self.bank.master, src)
-            self.native.broadcast_(self.bank.f_master, src)
-        else:
-            dist.broadcast(self.bank.master, src, group=self.group)
-            dist.broadcast(self.bank.f_master, src, group=self.group)
+        self.bank.assert_whole("GradSync.broadcast_parameters()")
+        self._broadcast(self.bank.master, src)
+        self._broadcast(self.bank.f_master, src)
         self.bank.sync_compute()
+
+    def broadcast_state(self, optimizer, src: int = 0):
+        """Parameters AND optimizer state of rank ``src`` on every rank (hvd.broadcast_parameters + hvd.broadcast_optimizer_state,
+        run_video_retrieval.py:304-305 / the restorer's restore on every rank): fp32 masters, both AdamW moments and the step count
+        (the bias corrections depend on it) -- ranks that resume from different states would otherwise drift apart."""
+        self.broadcast_parameters(src)
+        if not self.active or self.dry:
+            return
+        bank = self.bank
+        bank.ensure_state()
+        self._broadcast(bank.exp_avg, src)
+        self._broadcast(bank.exp_avg_sq, src)
+        box = [int(optimizer.step_count) if self.rank == src else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
+        optimizer.step_count = int(box[0])

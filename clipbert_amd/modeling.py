@@ -17,6 +17,7 @@ directly into the flat fp32 gradient buffer (``p.grad`` is a view of it).
 """
 import contextlib
 import math
+import os
 from types import SimpleNamespace
 from typing import List, Optional
 
@@ -198,6 +199,7 @@ class Runtime:
         self.forward_count = 0                           # host counter folded into every dropout seed: each forward (each
                                                          # clip of a clip loop) draws its own masks; kept in the saved pack
         self.side_stream = None                          # second HIP stream: weight-gradient GEMMs run beside the dgrad chain
+        self.group_wgrads = os.environ.get("CB_NO_GROUP_WGRAD") is None     # ResNet weight gradients per stage through cb_gemm_group
         self._side_refs = []
 
     def side(self, *tensors):
@@ -314,8 +316,10 @@ def _conv_dgrad(rt: Runtime, g, conv, in_shape, scale=None, mask=None, residual=
     return (out, second) if fuse is not None else out
 
 
-def _conv_wgrad(rt: Runtime, g, x, conv):
-    """dW[co][(r,s,c)] += sum_pixels g[m,co] * x[pix(m,r,s), c], straight into the flat fp32 grad buffer."""
+def _conv_wgrad(rt: Runtime, g, x, conv, pending=None):
+    """dW[co][(r,s,c)] += sum_pixels g[m,co] * x[pix(m,r,s), c], straight into the flat fp32 grad buffer.
+    ``pending`` (a list): the launch is only DESCRIBED and appended -- the caller hands the weight gradients of a whole ResNet stage
+    to cb_gemm_group at once (they are off the data-gradient chain: a few launches that fill the chip instead of one per convolution)."""
     gw = rt.bank.grad_image(conv.weight)
     if gw is None:
         return
@@ -325,14 +329,15 @@ def _conv_wgrad(rt: Runtime, g, x, conv):
     m = n * oh * ow
     kk = k * k * cin
     split, tile = _pick_split(cout, kk, m)
+    run = ops.gemm if pending is None else (lambda *a, **kw: pending.append(ops.gemm_desc(*a, **kw)))
     if k == 1 and s == 1:
-        ops.gemm(g.view(m, cout), x.view(m, cin), cout, cin, m, out=gw.view(cout, kk), a_mode=KROW, lda=cout,
-                 b_mode=KROW, ldb=cin, accumulate=True, split_k=split, tile=tile)
+        run(g.view(m, cout), x.view(m, cin), cout, cin, m, out=gw.view(cout, kk), a_mode=KROW, lda=cout,
+            b_mode=KROW, ldb=cin, accumulate=True, split_k=split, tile=tile)
     else:
         tab = rt.table(n, oh, ow, s, p, h * w * cin, w * cin, cin, x.device)
-        ops.gemm(g.view(m, cout), x, cout, kk, m, out=gw.view(cout, kk), a_mode=KROW, lda=cout, b_mode=KROW_GATHER,
-                 b_tab=tab, ldb=0, R=k, S=k, Cin=cin, H=h, W=w, sH=w * cin, sW=cin, accumulate=True, split_k=split,
-                 tile=tile)
+        run(g.view(m, cout), x, cout, kk, m, out=gw.view(cout, kk), a_mode=KROW, lda=cout, b_mode=KROW_GATHER,
+            b_tab=tab, ldb=0, R=k, S=k, Cin=cin, H=h, W=w, sH=w * cin, sW=cin, accumulate=True, split_k=split,
+            tile=tile)
 
 
 def _stem_weight(rt: Runtime, conv: Conv2d):
@@ -415,6 +420,15 @@ def cnn_backward_steps(bb: "GridFeatBackbone", saved_pack, dgrid: torch.Tensor):
         return
     res5_ids = {id(b) for b in bb.feature.backbone.res5}
     first_res5 = min((i for i, rec in enumerate(saved) if id(rec[0]) in res5_ids), default=None)
+    # weight gradients of a stage's convolutions: described as the data-gradient chain passes them, launched together when the chain
+    # leaves the stage (cb_gemm_group; not with the side-stream variant, which overlaps them one by one)
+    stage_of = {id(b): name for name, *_ in RESNET50_STAGES for b in getattr(bb.feature.backbone, name)}
+    pend = [] if (rt.group_wgrads and rt.side_stream is None) else None
+
+    def flush():
+        if pend:
+            ops.gemm_group(pend, dg)
+            pend.clear()
 
     def fuse_spec(i):
         """the ReLU x FrozenBN-scale backward of block i, done by the launch that produces d(output of block i)"""
@@ -432,15 +446,17 @@ def cnn_backward_steps(bb: "GridFeatBackbone", saved_pack, dgrid: torch.Tensor):
         s1, _ = blk.conv1.scale_shift()
         dz, gsc = (sec, None) if blk.shortcut is None else (None, sec)
         with rt.side(g3, y2, sec):
-            _conv_wgrad(rt, g3, y2, blk.conv3)
+            _conv_wgrad(rt, g3, y2, blk.conv3, pend)
             if blk.shortcut is not None:
-                _conv_wgrad(rt, gsc, x, blk.shortcut)
+                _conv_wgrad(rt, gsc, x, blk.shortcut, pend)
         g2 = _conv_dgrad(rt, g3, blk.conv3, y2.shape, scale=s2, mask=y2)       # -> d(conv2 out) * mask * scale2
         with rt.side(g2, y1):
-            _conv_wgrad(rt, g2, y1, blk.conv2)
+            _conv_wgrad(rt, g2, y1, blk.conv2, pend)
         g1 = _conv_dgrad(rt, g2, blk.conv2, y1.shape, scale=s1, mask=y1)
         with rt.side(g1, x):
-            _conv_wgrad(rt, g1, x, blk.conv1)
+            _conv_wgrad(rt, g1, x, blk.conv1, pend)
+        if idx == 0 or stage_of.get(id(saved[idx - 1][0])) != stage_of.get(id(blk)):
+            flush()                                     # the chain leaves this stage: its weight gradients in a few grouped launches
         if idx == first_res5 and idx > 0:
             rt.join()
             yield "grid_encoder+res5"

@@ -47,14 +47,15 @@ def _chk(rc, what):
     _lib.check(rc, what)
 
 
-def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch.Tensor, a_mode=ROWK,
-         b_mode=ROWK, lda=None, ldb=None, ldc=None, a_tab=None, b_tab=None, R=1, S=1, Cin=0, H=0, W=0,
-         sH=0, sW=0, flip_taps=False, c_rowmap=None, accumulate=False, split_k=1, act=ACT_NONE,
-         scale=None, shift=None, residual=None, ldr=None, relu_after=False, mask=None, ldm=None,
-         out2=None, ldc2=None, alpha=1.0, dropout_p=0.0, dropout_seed=0, seed_ptr=None, tile=0, gelu_grad_pre=None, a_rowsum=None, batch=1, batch_strides=None,
-         relu_bwd=False, post_scale=None, post_scale2=None, xcd_order=0, zero_fill_pitch=0, splitk_ws=None, schedule=0):
-    """C[M,N] (op)= epilogue(sum_k A(m,k) B(n,k)); see include/clipbert_hip.h cb_gemm_desc.  ``splitk_ws``: fp32 scratch for
-    the K split of the 8-wave tiles (default: the per-device workspace of ``splitk_workspace``)."""
+def gemm_desc(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch.Tensor, a_mode=ROWK,
+              b_mode=ROWK, lda=None, ldb=None, ldc=None, a_tab=None, b_tab=None, R=1, S=1, Cin=0, H=0, W=0,
+              sH=0, sW=0, flip_taps=False, c_rowmap=None, accumulate=False, split_k=1, act=ACT_NONE,
+              scale=None, shift=None, residual=None, ldr=None, relu_after=False, mask=None, ldm=None,
+              out2=None, ldc2=None, alpha=1.0, dropout_p=0.0, dropout_seed=0, seed_ptr=None, tile=0, gelu_grad_pre=None, a_rowsum=None, batch=1, batch_strides=None,
+              relu_bwd=False, post_scale=None, post_scale2=None, xcd_order=0, zero_fill_pitch=0, splitk_ws=None, schedule=0) -> GemmDesc:
+    """The cb_gemm_desc of C[M,N] (op)= epilogue(sum_k A(m,k) B(n,k)); see include/clipbert_hip.h.  ``splitk_ws``: fp32 scratch for
+    the K split of the 8-wave tiles (default: the per-device workspace of ``splitk_workspace``).  The descriptor borrows the
+    tensors' memory: the caller keeps them alive until the launch that consumes it has been enqueued (``_refs`` holds them)."""
     d = GemmDesc()
     d.dtype = dtype_code(a.dtype)
     assert b.dtype == a.dtype
@@ -111,8 +112,28 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch
         splitk_ws = splitk_workspace(a.device)
     if splitk_ws is not None:
         d.splitk_ws, d.splitk_ws_bytes = _ptr(splitk_ws), splitk_ws.numel() * splitk_ws.element_size()
+    d._refs = (a, b, out, a_tab, b_tab, c_rowmap, scale, shift, residual, mask, out2, seed_ptr, gelu_grad_pre, a_rowsum, post_scale,
+               post_scale2, splitk_ws)
+    return d
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch.Tensor, **kw):
+    """C[M,N] (op)= epilogue(sum_k A(m,k) B(n,k)): one cb_gemm launch on a's current stream (arguments: gemm_desc)."""
+    d = gemm_desc(a, b, M, N, K, out=out, **kw)
     _chk(_lib.get().cb_gemm(C.byref(d), _stream(a)), "cb_gemm")
     return out
+
+
+def gemm_group(descs, like: torch.Tensor):
+    """cb_gemm_group: the INDEPENDENT problems ``descs`` (gemm_desc results; no output overlaps another problem's output or
+    operands) in as few launches as the library manages, on ``like``'s current stream."""
+    n = len(descs)
+    if n == 0:
+        return
+    arr = (GemmDesc * n)()
+    for i, d in enumerate(descs):
+        C.memmove(C.byref(arr[i]), C.byref(d), C.sizeof(GemmDesc))
+    _chk(_lib.get().cb_gemm_group(C.cast(arr, C.c_void_p), n, _stream(like)), "cb_gemm_group")
 
 
 _LAUNCH_OVERRIDE = {}                  # (a_mode, b_mode, M, N, K, batch, taps, split_k) -> (tile, xcd_order, split_k, schedule); tuning only

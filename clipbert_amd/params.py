@@ -165,9 +165,17 @@ class ParamBank:
     def is_trainable(self, p: nn.Parameter) -> bool:
         return id(p) in self.offset
 
+    def fp32_read_ranges(self):
+        """(lo, hi) element ranges of the trainable parameters that kernels read from the fp32 MASTER buffer rather than the bf16
+        compute copy: every 1-D parameter (biases, LayerNorm and BatchNorm1d vectors are handed to the kernels as fp32 pointers)."""
+        return [(self.offset[id(p)], self.offset[id(p)] + p.numel()) for _n, p in self._trainable if p.dim() <= 1]
+
     # ---- maintenance -----------------------------------------------------------------------------
     def sync_compute(self):
-        """Refresh the bf16 compute copies from the fp32 masters (after loading / editing weights)."""
+        """Refresh the bf16 compute copies from the fp32 masters (after loading / editing weights).  After owner-only updates
+        (GradSync(shard=True)) the masters of the decay groups are current on their owners only: copying them over the all-gathered
+        compute weights would silently roll the other ranks' pieces back -- gather_state() first."""
+        self.assert_whole("ParamBank.sync_compute()")
         if self.w16 is not None and self.n_train > 0:
             ops.cast(self.master, self.w16)
         if self.f_w16 is not None:

@@ -213,7 +213,7 @@ def start_training(model, optimizer, train_loader, cfg, sync=None, validate_fn=N
     Ranks: pass ``model_saver`` / ``restorer`` on EVERY rank (clipbert_amd.checkpoint: both write on rank 0 only, the restorer
     restores on all ranks -- the reference's order, run_video_retrieval.py:329-346).  All ranks must run the same number of
     optimizer steps: the resumed global step is agreed on across the ranks (max), and when the ranks did not all restore the
-    same step, rank 0's parameters are broadcast again before the first step."""
+    same step, the most advanced rank's parameters, AdamW moments and optimizer step count are broadcast before the first step."""
     from .data import InfiniteIterator
     if sync is not None and sync.world > 1 and overlap and model.rt is not None and model.rt.after_encoder_backward is None:
         sync.attach(model)
@@ -221,11 +221,15 @@ def start_training(model, optimizer, train_loader, cfg, sync=None, validate_fn=N
     global_step = restorer.global_step if restorer is not None else 0
     if sync is not None and sync.world > 1 and not sync.dry:
         steps = _all_gather_scalar(global_step)
-        if len(set(steps)) > 1:                             # e.g. a restorer on rank 0 only: the others follow rank 0
+        if len(set(steps)) > 1:
+            # the ranks resumed from different states (e.g. restore.pt readable on one rank only): ALL of them continue from the most
+            # advanced one -- its global step, parameters, AdamW moments and optimizer step count (the reference broadcasts both
+            # model and optimizer state from rank 0 after its restore, run_video_retrieval.py:304-305,329-346)
             global_step = int(max(steps))
+            src = steps.index(global_step)
             if restorer is not None:
                 restorer.global_step = global_step
-            sync.broadcast_parameters(0)
+            sync.broadcast_state(optimizer, src)
     num_train_steps, valid_steps = int(_get(cfg, "num_train_steps")), int(_get(cfg, "valid_steps", 0) or 0)
     n_gpu = sync.world if sync is not None else 1
     total_bsz = n_gpu * int(_get(cfg, "train_batch_size", 1)) * acc * int(_get(cfg, "max_n_example_per_group", 1) or 1)

@@ -126,6 +126,24 @@ int cb_gemm(const cb_gemm_desc* d, void* stream);
  * resolved by the per-shape table measured on MI355X (csrc/gemm_tuned.h; use_table != 0) and, for shapes outside it, by the launch-cost
  * model fitted to the same sweeps (csrc/gemm_model.h, tools/fit_gemm_model.py).  For tools and tests. */
 int cb_gemm_plan(const cb_gemm_desc* d, int32_t use_table, int32_t* out4);
+/* Bytes of K-split scratch (cb_gemm_desc.splitk_ws) cb_gemm would use for `d` at most -- what it picks when the workspace is not the
+ * constraint; 0 when the problem runs unsplit or through atomics.  A caller sizes ONE buffer by the maximum over the problems it will
+ * launch on a stream (clipbert_amd keeps 128 MiB per device: the largest value over the three bench workloads is 115 MiB); a smaller or
+ * absent buffer is never an error -- cb_gemm then chooses among the configurations that fit. */
+int cb_gemm_workspace_bytes(const cb_gemm_desc* d, int64_t* bytes);
+/* `n` INDEPENDENT problems in as few launches as possible: the same results as n cb_gemm calls (no problem's output may overlap
+ * another problem's output or operands), but problems that run the same kernel class -- weight gradients of Linear / 1x1
+ * convolutions, weight gradients of gathered convolutions, plain forward products, gathered forward products; fast path (16-byte
+ * aligned operands < 2 GiB), no strided batch, no a_rowsum -- share ONE grid: every workgroup looks its (problem, tile) up in a
+ * table that travels in the kernel arguments (capturable as is).  A launch of many small problems fills the 256 CUs where each
+ * alone is a fraction of a round of workgroups: the weight gradients of all convolutions of a ResNet stage
+ * (src/modeling/grid_feat.py:95 under autograd: one cuDNN call each) become two launches instead of ~13.  Everything else in the
+ * list is launched problem by problem, in list order.  descs[i].tile: 0 = the library chooses tile and K splits for the group
+ * (bf16: 64x64 or 128x128 with two workgroups per CU; a problem's K may be split only where cb_gemm's own rule allows atomics:
+ * fp32 C, accumulate = 1, scale/alpha-only epilogue); 2 / 4 = that tile with descs[i].split_k as given (problems are grouped with
+ * those that ask for the same tile).  CB_F32 problems run the 64x64 fp32 tile with the caller's split_k: bit-identical to n
+ * cb_gemm calls wherever split_k == 1. */
+int cb_gemm_group(const cb_gemm_desc* descs, int32_t n, void* stream);
 
 /* Output-pixel table of a convolution: entry m=(n,oh,ow) -> offset of input pixel
  * (n, oh*stride-pad, ow*stride-pad) and its (ih0, iw0).  sN/sH/sW in elements. */
@@ -248,8 +266,10 @@ int cb_act_bwd(int32_t dtype, int32_t act, const void* dy, const void* ref, void
  * summed across ranks). */
 int cb_adamw(float* p, const float* g, float* m, float* v, void* w16, int64_t n, const float* hyper,
              const float* grad_sq_sum, void* stream);
-/* hyper: DEVICE array of CB_HP_COUNT floats (so a captured hipGraph sees new values each replay):
- * [lr, beta1, beta2, eps, weight_decay, 1-beta1^t, 1-beta2^t, max_norm, grad_scale] */
+/* hyper: DEVICE array of AT LEAST CB_HP_COUNT (10) floats (so a captured hipGraph sees new values each replay):
+ * [lr, beta1, beta2, eps, weight_decay, 1-beta1^t, 1-beta2^t, max_norm, grad_scale, skip].  ABI version 2 (cb_version()) added
+ * hyper[CB_HP_SKIP] as element 9: the kernel reads it unconditionally, so a caller written against version 1 (9 floats) must grow
+ * its array to CB_HP_COUNT floats and set hyper[CB_HP_SKIP] = 0 -- a non-zero value there makes the launch a no-op. */
 enum { CB_HP_LR = 0, CB_HP_BETA1, CB_HP_BETA2, CB_HP_EPS, CB_HP_WD, CB_HP_BC1, CB_HP_BC2, CB_HP_MAX_NORM,
        CB_HP_GRAD_SCALE, CB_HP_SKIP /* != 0: the launch does nothing (a captured, software-pipelined update with no step behind it) */,
        CB_HP_COUNT };
@@ -305,6 +325,7 @@ int cb_elu_bn1d_bwd(int32_t dtype, const void* dy, const void* x, const float* g
                     void* dx, float* dgamma, float* dbeta, int32_t B, int32_t D, int32_t training, void* stream);
 
 const char* cb_last_error(void);
+/* ABI version: 1 = round 1-2; 2 = CB_HP_SKIP / CB_HP_COUNT 10 (cb_adamw*), cb_gemm_group, cb_gemm_workspace_bytes */
 int cb_version(void);
 
 /* ---- gradient exchange (one process per GPU, RCCL over xGMI) ----------------------------------------------------

@@ -1,0 +1,170 @@
+"""cb_gemm_group (clipbert_amd/csrc/gemm.hip): n independent problems in one grid must give what n cb_gemm launches give --
+bit for bit where the two paths run the same tile and K split (fp32 parity mode; bf16 with an explicit tile), and within the
+usual tolerance of a plain PyTorch fp32 reference where the library picks tile and splits for the group.  Every case runs on the
+host lane-level emulator build (CPU suite) and, marked `gpu`, through the real libclipbert_hip.so on an MI355X."""
+import pytest
+import torch
+
+from clipbert_amd import ops
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dt):
+    return dict(rtol=2e-2, atol=2e-2) if dt == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _wgrad_problems(hw, dt, shapes, seed0=0):
+    """weight gradients dW[n_out][k_in] = g^T x of Linear layers over `m` rows: (m, n_out, k_in) each"""
+    probs = []
+    for i, (m, n, k) in enumerate(shapes):
+        g, x = hw(rnd(m, n, seed=seed0 + 2 * i).to(dt)), hw(rnd(m, k, seed=seed0 + 2 * i + 1).to(dt))
+        probs.append((g, x, m, n, k))
+    return probs
+
+
+def _conv_wgrad_problems(hw, dt, specs, seed0=100):
+    """weight gradients of convolutions: (batch, H, W, Cin, Cout, k, stride, pad) each"""
+    probs = []
+    for i, (nb, H, W, cin, cout, k, s, p) in enumerate(specs):
+        oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        x = hw(rnd(nb, H, W, cin, seed=seed0 + 2 * i).to(dt))                    # NHWC
+        g = hw(rnd(nb * oh * ow, cout, seed=seed0 + 2 * i + 1).to(dt))
+        tab = ops.build_pixel_table(nb, oh, ow, s, p, H * W * cin, W * cin, cin, x.device)
+        probs.append((g, x, tab, nb, H, W, cin, cout, k, s, p, oh, ow))
+    return probs
+
+
+def _conv_desc(pr, out, **kw):
+    g, x, tab, nb, H, W, cin, cout, k, s, p, oh, ow = pr
+    m = nb * oh * ow
+    return ops.gemm_desc(g, x, cout, k * k * cin, m, out=out, a_mode=ops.KROW, lda=cout, b_mode=ops.KROW_GATHER, b_tab=tab, ldb=0,
+                         R=k, S=k, Cin=cin, H=H, W=W, sH=W * cin, sW=cin, **kw)
+
+
+def _conv_ref(pr):
+    g, x, tab, nb, H, W, cin, cout, k, s, p, oh, ow = pr
+    xr = x.float().permute(0, 3, 1, 2)
+    w = torch.zeros(cout, cin, k, k, requires_grad=True)
+    y = torch.nn.functional.conv2d(xr.cpu(), w, None, s, p)
+    y.backward(g.float().cpu().view(nb, oh, ow, cout).permute(0, 3, 1, 2))
+    return w.grad.permute(0, 2, 3, 1).reshape(cout, k * k * cin)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_group_equals_single_launches_bitwise(hw, dt):
+    """same tile, K split 1: the grouped grid runs exactly the tile code of the single launches (first-writer stores AND accumulation)"""
+    tile = 0 if dt == torch.float32 else 2
+    lin = _wgrad_problems(hw, dt, [(200, 72, 136), (130, 64, 64), (70, 8, 200), (333, 136, 72)])
+    conv = _conv_wgrad_problems(hw, dt, [(2, 7, 9, 32, 64, 3, 1, 1), (2, 8, 6, 64, 40, 1, 2, 0), (1, 6, 6, 64, 72, 3, 1, 1)])
+    for accumulate in (False, True):
+        descs, outs, singles = [], [], []
+        for g, x, m, n, k in lin:
+            init = hw(rnd(n, k, seed=m)) if accumulate else torch.full((n, k), float("nan"))
+            o1, o2 = hw(init.clone()), hw(init.clone())
+            ops.gemm(g, x, n, k, m, out=o1, a_mode=ops.KROW, b_mode=ops.KROW, accumulate=accumulate, tile=tile)
+            descs.append(ops.gemm_desc(g, x, n, k, m, out=o2, a_mode=ops.KROW, b_mode=ops.KROW, accumulate=accumulate, tile=tile))
+            singles.append(o1); outs.append(o2)
+        for pr in conv:
+            cout, kk = pr[7], pr[8] * pr[8] * pr[6]
+            init = hw(rnd(cout, kk, seed=kk)) if accumulate else torch.full((cout, kk), float("nan"))
+            o1, o2 = hw(init.clone()), hw(init.clone())
+            d1 = _conv_desc(pr, o1, accumulate=accumulate, tile=tile)
+            ops.gemm_group([d1], o1)                                   # (a list of one is a plain cb_gemm launch)
+            descs.append(_conv_desc(pr, o2, accumulate=accumulate, tile=tile))
+            singles.append(o1); outs.append(o2)
+        ops.gemm_group(descs, outs[0])
+        for a, b in zip(singles, outs):
+            assert torch.equal(a, b)
+        if not accumulate:
+            for (g, x, m, n, k), o in zip(lin, outs):
+                torch.testing.assert_close(o.cpu(), g.float().cpu().t() @ x.float().cpu(), **tol(dt))
+            for pr, o in zip(conv, outs[len(lin):]):
+                torch.testing.assert_close(o.cpu(), _conv_ref(pr), **tol(dt))
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_group_forward_classes_and_mixed_lists(hw, dt):
+    """forward products (plain and gathered A) with their epilogues, mixed with problems no grouped kernel covers (a data
+    gradient, a batched problem): same results as the single launches, bit for bit"""
+    tile = 0 if dt == torch.float32 else 2
+    M, N, K = 150, 72, 64
+    x, w1, w2 = hw(rnd(M, K, seed=1).to(dt)), hw(rnd(N, K, seed=2, scale=0.2).to(dt)), hw(rnd(40, K, seed=3, scale=0.2).to(dt))
+    b1, res = hw(rnd(N, seed=4)), hw(rnd(M, N, seed=5).to(dt))
+    nb, H, W, cin, cout = 2, 8, 6, 64, 40
+    xi = hw(rnd(nb, H, W, cin, seed=6).to(dt))
+    wk = hw(rnd(cout, cin, seed=7, scale=0.1).to(dt))
+    oh, ow = H // 2, W // 2
+    tab = ops.build_pixel_table(nb, oh, ow, 2, 0, H * W * cin, W * cin, cin, xi.device)
+    sc, sh = hw(rnd(cout, seed=8).abs() + 0.5), hw(rnd(cout, seed=9))
+    wd = hw(rnd(K, 48, seed=10, scale=0.2).to(dt))                    # data-gradient form: B stored [k][n]
+
+    def run(grouped):
+        o = [torch.empty(M, N, dtype=dt, device=hw.dev), torch.empty(M, 40, dtype=dt, device=hw.dev),
+             torch.empty(nb * oh * ow, cout, dtype=dt, device=hw.dev), torch.empty(nb * oh * ow, cout, dtype=dt, device=hw.dev),
+             torch.empty(M, 48, dtype=dt, device=hw.dev)]
+        pre = torch.empty(M, N, dtype=dt, device=hw.dev)
+        calls = [
+            (x, w1, M, N, K, dict(out=o[0], shift=b1, act=ops.ACT_GELU, residual=res, out2=pre, tile=tile)),
+            (x, w2, M, 40, K, dict(out=o[1], tile=tile)),
+            (xi, wk, nb * oh * ow, cout, cin, dict(out=o[2], a_mode=ops.ROWK_GATHER, a_tab=tab, lda=0, ldb=cin, R=1, S=1, Cin=cin, H=H, W=W,
+                                                   sH=W * cin, sW=cin, scale=sc, shift=sh, act=ops.ACT_RELU, tile=tile)),
+            (xi, wk, nb * oh * ow, cout, cin, dict(out=o[3], a_mode=ops.ROWK_GATHER, a_tab=tab, lda=0, ldb=cin, R=1, S=1, Cin=cin, H=H, W=W,
+                                                   sH=W * cin, sW=cin, tile=tile)),
+            (x, wd, M, 48, K, dict(out=o[4], b_mode=ops.KROW, ldb=48, tile=tile)),
+        ]
+        if grouped:
+            ops.gemm_group([ops.gemm_desc(a, b, m, n, k, **kw) for a, b, m, n, k, kw in calls], x)
+        else:
+            for a, b, m, n, k, kw in calls:
+                ops.gemm(a, b, m, n, k, **kw)
+        return o + [pre]
+
+    single, grouped = run(False), run(True)
+    for a, b in zip(single, grouped):
+        assert torch.equal(a, b)
+    ref = torch.nn.functional.gelu(x.float() @ w1.float().t() + b1) + res.float()
+    torch.testing.assert_close(grouped[0].float(), ref, **tol(dt))
+    torch.testing.assert_close(grouped[4].float(), x.float() @ wd.float(), **tol(dt))
+
+
+def test_group_auto_configuration_bf16(hw):
+    """tile = 0: the library picks tile and K splits for the group (long reductions are split and combine through atomics where
+    the output is accumulated fp32; a problem that STORES keeps split 1) -- checked against fp32 references"""
+    dt = torch.bfloat16
+    lin = _wgrad_problems(hw, dt, [(1100, 136, 72), (1100, 72, 136), (1100, 64, 64), (900, 200, 8)])
+    conv = _conv_wgrad_problems(hw, dt, [(2, 12, 12, 32, 64, 3, 1, 1), (2, 12, 12, 64, 40, 1, 2, 0)])
+    descs, outs = [], []
+    for i, (g, x, m, n, k) in enumerate(lin):
+        store = i == 2
+        o = torch.full((n, k), float("nan"), device=hw.dev) if store else torch.ones(n, k, device=hw.dev)
+        descs.append(ops.gemm_desc(g, x, n, k, m, out=o, a_mode=ops.KROW, b_mode=ops.KROW, accumulate=not store))
+        outs.append((o, g.float().cpu().t() @ x.float().cpu() + (0.0 if store else 1.0)))
+    for pr in conv:
+        cout, kk = pr[7], pr[8] * pr[8] * pr[6]
+        o = torch.zeros(cout, kk, device=hw.dev)
+        descs.append(_conv_desc(pr, o, accumulate=True))
+        outs.append((o, _conv_ref(pr)))
+    ops.gemm_group(descs, outs[0][0])
+    for o, ref in outs:
+        torch.testing.assert_close(o.cpu(), ref, **tol(dt))
+
+
+def test_group_more_problems_than_one_launch_holds(hw):
+    """more problems of one class than the kernel-argument table holds: the list is cut into several launches"""
+    dt = torch.bfloat16
+    lin = _wgrad_problems(hw, dt, [(96 + 8 * i, 64 + 8 * (i % 3), 72) for i in range(23)])
+    descs, outs = [], []
+    for g, x, m, n, k in lin:
+        o = torch.zeros(n, k, device=hw.dev)
+        descs.append(ops.gemm_desc(g, x, n, k, m, out=o, a_mode=ops.KROW, b_mode=ops.KROW, accumulate=True))
+        outs.append(o)
+    ops.gemm_group(descs, outs[0])
+    ops.gemm_group([], outs[0])
+    for (g, x, m, n, k), o in zip(lin, outs):
+        torch.testing.assert_close(o.cpu(), g.float().cpu().t() @ x.float().cpu(), **tol(dt))

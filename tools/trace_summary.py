@@ -10,6 +10,9 @@ import sys
 
 def gemm_name(n):
     """readable name of a cb_gemm instantiation from its (possibly half-demangled) symbol"""
+    if "gemm_group_kernel" in n:                        # cb_gemm_group: same instantiation scheme as gemm_kernel
+        g = gemm_name(n.replace("gemm_group_kernel", "gemm_kernel"))
+        return g.replace("cb_gemm ", "cb_gemm_group ", 1) if g else "cb_gemm_group"
     if "splitk_reduce_kernel" in n:
         return "cb_gemm split-K reduce (slabs -> epilogue)"
     d8 = re.search(r"gemm8_kernel<(\d+), (\d+), \d+, \d+, \d+, (\d), cbgemm::(\w+)<\d+, (\w+)>, cbgemm::(\w+)<\d+, (\w+)>, (\w+)>", n)

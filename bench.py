@@ -87,11 +87,127 @@ def log(msg):
         print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+# ---- launching N > 1 -----------------------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` (no launcher, WORLD_SIZE unset) starts its own N ranks under torch.distributed.run; under a launcher
+# (`python -m torch.distributed.run ... bench.py --gpus N`, the driver's form) every rank process SUPERVISES one worker process.
+# Either way a failed or hung attempt is retried with a more conservative data-parallel plan, because no multi-rank RCCL run of this
+# code existed when it was written (1-GPU build boxes): the first number a multi-GPU node produces must not depend on the newest plan.
+#   attempt 0: CB_BENCH_PLAN unset -> the whole step incl. its bucket collectives in ONE hipGraph, the library's own RCCL entry points
+#   attempt 1: CB_BENCH_PLAN=split -> four hipGraphs with eager collectives between them (the round-2 / round-3 default)
+#   attempt 2: CB_BENCH_PLAN=split CB_COMM=torch -> the same with torch.distributed carrying the buckets
+# A user who sets CB_BENCH_PLAN / CB_COMM gets exactly that plan and no retry.  The attempt that produced the line is in config.attempt.
+ATTEMPTS = ({}, {"CB_BENCH_PLAN": "split"}, {"CB_BENCH_PLAN": "split", "CB_COMM": "torch"})
+ATTEMPT_TIMEOUT_S = float(os.environ.get("CB_BENCH_ATTEMPT_TIMEOUT", "420"))
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _marker(job, attempt, what):
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"cb_bench_{job}_a{attempt}.{what}")
+
+
+def _touch(path):
+    with open(path, "w") as fh:
+        fh.write(str(os.getpid()))
+
+
+def _run_attempts(make_cmd_env, n_attempts, rank, job):
+    """Run attempt 0, 1, ... until one finishes: exit code 0, or its done-marker exists (the timed region and the JSON line were
+    completed; only the teardown failed).  Under a launcher every rank runs this loop for its own worker: the first supervisor that
+    sees its worker fail or time out drops a `failed` marker for the attempt, every other supervisor sees it within a second, kills
+    its (by then hung) worker and moves on to the next attempt with it."""
+    import signal
+    import subprocess
+    rc = 1
+    for attempt in range(n_attempts):
+        cmd, env = make_cmd_env(attempt)
+        done, failed = _marker(job, attempt, f"r{rank}.done"), _marker(job, attempt, "failed")
+        if os.path.exists(done):
+            os.remove(done)
+        p = subprocess.Popen(cmd, env=env, start_new_session=True)           # own process group: a hung attempt is killed as a whole
+        t0 = time.perf_counter()
+        why = None
+        while True:
+            try:
+                rc = p.wait(timeout=0.5)
+                break
+            except subprocess.TimeoutExpired:
+                pass
+            if time.perf_counter() - t0 > ATTEMPT_TIMEOUT_S:
+                why = f"exceeded {ATTEMPT_TIMEOUT_S:.0f} s"
+            elif os.path.exists(failed) and not os.path.exists(done):
+                time.sleep(3.0)                                              # let a worker that is about to finish its own exit finish it
+                why = "another rank's attempt failed"
+            if why:
+                rc = -9
+                break
+        if p.poll() is None:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)                             # exactly the process group this function started
+            except ProcessLookupError:
+                pass
+            p.wait()
+        ok = rc == 0 or os.path.exists(done)
+        if os.path.exists(done):
+            os.remove(done)
+        if ok:
+            return 0
+        _touch(failed)
+        print(f"[bench supervisor rank {rank}] attempt {attempt} ({ATTEMPTS[attempt] or 'default plan'}) failed: {why or 'exit code ' + str(rc)}"
+              + (f"; retrying with {ATTEMPTS[attempt + 1]}" if attempt + 1 < n_attempts else ""), file=sys.stderr, flush=True)
+    return rc if rc not in (0, None) else 1
+
+
+def supervise(args):
+    """see the comment above ATTEMPTS; returns an exit code, or None if this process is itself a worker"""
+    if os.environ.get("CB_BENCH_WORKER") == "1" or args.gpus <= 1:
+        return None
+    pinned = "CB_BENCH_PLAN" in os.environ or "CB_COMM" in os.environ
+    n_attempts = 1 if (pinned or args.mode == "infer16") else len(ATTEMPTS)
+    me = os.path.abspath(__file__)
+    if "WORLD_SIZE" not in os.environ:
+        # no launcher: start the N ranks ourselves (each of them is a plain worker; this process supervises the whole job)
+        job = f"{_free_port()}_{os.getpid()}"
+
+        def launch(attempt):
+            port = _free_port()
+            env = dict(os.environ, CB_BENCH_WORKER="1", CB_BENCH_ATTEMPT=str(attempt), CB_BENCH_JOB=job, MASTER_ADDR="127.0.0.1",
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **ATTEMPTS[attempt])
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), me] + sys.argv[1:]
+            return cmd, env
+        return _run_attempts(launch, n_attempts, 0, job)
+    # under a launcher: this rank process supervises ONE worker with the same rank environment
+    rank = int(os.environ.get("RANK", "0"))
+    port0 = int(os.environ.get("MASTER_PORT", "29500"))
+    job = f"{port0}_{os.getppid()}"                       # the launcher's pid: the same for every rank of the node
+
+    def worker(attempt):
+        env = dict(os.environ, CB_BENCH_WORKER="1", CB_BENCH_ATTEMPT=str(attempt), CB_BENCH_JOB=job, **ATTEMPTS[attempt])
+        if attempt > 0:
+            # the launcher's store (port0) still holds the keys of the failed attempt: a retry rendezvouses through its own TCP store,
+            # hosted by its rank 0 on a port every rank derives the same way
+            env["MASTER_PORT"] = str(port0 + 17 * attempt)
+            env["TORCHELASTIC_USE_AGENT_STORE"] = "False"
+        return [sys.executable, me] + sys.argv[1:], env
+    return _run_attempts(worker, n_attempts, rank, job)
+
+
 def main():
     import faulthandler
     faulthandler.enable()
     faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)
     args = parse()
+    rc = supervise(args)
+    if rc is not None:
+        sys.exit(rc)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -103,12 +219,18 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl" and rank == 0 and "NCCL_DEBUG" not in os.environ:
+            # rank 0 keeps RCCL's own account of the communicator it built (INIT lines only, in a file): rccl_summary() reads it
+            os.environ["CB_BENCH_RCCL_LOG"] = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"cb_bench_rccl_{os.getpid()}_%p.log")
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,TUNING", NCCL_DEBUG_FILE=os.environ["CB_BENCH_RCCL_LOG"])
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with `python bench.py --gpus N`, or under "
+                         f"torch.distributed.run with --nproc-per-node equal to --gpus)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -351,6 +473,7 @@ def main():
         return g, out
 
     flush_pipeline = None
+    recapture_dp = None
     plan_env = os.environ.get("CB_BENCH_PLAN", "")
     run, plan, n_graphs = eager_fn, "eager", 0
     use_graph = not args.no_graph and plan_env != "eager"
@@ -367,10 +490,11 @@ def main():
         run, plan, n_graphs = g1.replay, "one hipGraph", 1
     elif use_graph and train and sync.active and not sync.dry and sync.shard and sync.carrier != "native":
         run, plan, n_graphs = eager_fn, "eager (owner-only update over torch.distributed: not captured)", 0
-    elif use_graph and train and sync.active and not sync.dry and sync.carrier == "native" and (plan_env == "captured" or sync.loopback or sync.shard):
+    elif use_graph and train and sync.active and not sync.dry and sync.carrier == "native" and (plan_env != "split" or sync.loopback or sync.shard):
         # ONE hipGraph for the whole data-parallel step: the bucket all-reduces (cb_allreduce_bucket on GradSync's comm stream,
-        # forked / joined by events) are captured with the kernels -- no host between the backward and the collectives.  Opt-in
-        # for N > 1 (CB_BENCH_PLAN=captured) until it has run on a multi-GPU node; the loopback run exercises it on one GPU.
+        # forked / joined by events) are captured with the kernels -- no host between the backward and the collectives.  The DEFAULT
+        # for N > 1 (round 4); CB_BENCH_PLAN=split selects the four-graph plan below, which is also what the supervisor (ATTEMPTS)
+        # falls back to when this plan fails or hangs on a node.
         def device_step_dp():
             opt.zero_grad(lazy=True)
             model.rt.pending_encoder_nodes = model.rt.pending_cnn_nodes = 0
@@ -385,10 +509,14 @@ def main():
             dp_update(g16)
             return loss_
         g1, loss = capture(device_step_dp)
+        dp_graph = {"g": g1}
 
         def run_dp():
             host_prepare()
-            g1.replay()
+            dp_graph["g"].replay()
+
+        def recapture_dp():
+            dp_graph["g"] = capture(device_step_dp)[0]
         run, plan, n_graphs = run_dp, "eager hyper-parameter upload + one hipGraph with the bucketed bf16 all-reduces captured inside", 1
     elif use_graph and world == 1 and not (train and sync.dry):
         pipelined = train and chains == 1 and fold and os.environ.get("CB_BENCH_PIPELINE", "0") == "1" and not os.environ.get("CB_BENCH_TUNE")
@@ -525,6 +653,33 @@ def main():
     final_loss = float(loss.item()) if loss is not None else None
     log(f"timed region done: {ms_per_step:.3f} ms/step, {value:.1f} clips/s")
 
+    # Exposed communication of the plan (N > 1, after the timed region, never part of `value`): the same plan with every collective
+    # muted (GradSync.mute: casts, bucket bookkeeping, graphs, bf16-direct AdamW all stay), timed the same way; the difference is the
+    # link time the plan failed to hide.  The ranks' parameters diverge from here on -- nothing after this uses them.
+    exposed = None
+    if train and world > 1 and sync is not None and sync.active and not sync.dry and os.environ.get("CB_BENCH_EXPOSED", "1") != "0":
+        try:
+            sync.mute = True
+            if recapture_dp is not None:
+                recapture_dp()
+            for _ in range(3):
+                run()
+            dist.barrier()
+            torch.cuda.synchronize()
+            m0 = time.perf_counter()
+            for _ in range(args.steps):
+                run()
+            torch.cuda.synchronize()
+            dist.barrier()
+            muted = torch.tensor([time.perf_counter() - m0], dtype=torch.float64, device=dev)
+            dist.all_reduce(muted, op=dist.ReduceOp.MAX)
+            muted_ms = float(muted.item()) / args.steps * 1e3
+            exposed = {"ms_per_step_collectives_muted": round(muted_ms, 3), "exposed_comm_ms": round(ms_per_step - muted_ms, 3),
+                       "exposed_comm_frac_of_step": round((ms_per_step - muted_ms) / ms_per_step, 4)}
+            log(f"same plan with the collectives muted: {muted_ms:.3f} ms/step -> exposed communication {ms_per_step - muted_ms:.3f} ms")
+        except Exception as e:                                  # noqa: BLE001  (a diagnostic must never cost the measurement)
+            exposed = {"error": repr(e)[:200]}
+
     pairs = bv * rep * nclip
     if args.mode == "train" and not args.forward_only:
         metric = "clips/sec/node (2×2 frames, 224px, L_txt=32) at 1/2/4/8 MI355X"
@@ -559,6 +714,13 @@ def main():
     }
     if dp_check is not None:
         out["config"]["dp_self_check"] = dp_check
+    if world > 1:
+        out["config"]["attempt"] = int(os.environ.get("CB_BENCH_ATTEMPT", "0"))
+        out["config"]["attempt_env"] = ATTEMPTS[out["config"]["attempt"]] if os.environ.get("CB_BENCH_WORKER") == "1" else "launcher-pinned"
+    if exposed is not None:
+        out["config"]["exposed_comm"] = exposed
+    if train and world > 1:
+        out["config"]["rccl"] = rccl_summary()
     if train and sync is not None and sync.active and not sync.dry:
         if sync.shard:
             out["config"]["update"] = "owner-only: reduce-scatter -> AdamW on 1/world of every bucket -> all-gather of the new weights"
@@ -567,14 +729,39 @@ def main():
         out["config"]["rows_gathered"] = len(gathered)
     if rank == 0 and world == 1 and not args.no_roofline:
         default_shape = args.mode == "train" and (nclip, T, args.size, args.txt_len, bv, rep) == (2, 2, 224, 32, 16, 2) and not args.forward_only
-        out["roofline"] = measure_roofline(eager_fn if args.mode != "infer16" else infer_device_step, pmc_ok=default_shape)
+        out["roofline"] = measure_roofline(eager_fn if args.mode != "infer16" else infer_device_step, pmc_ok=default_shape, ms_per_step=ms_per_step)
         log("roofline measured")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, args)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if os.environ.get("CB_BENCH_JOB"):                     # tells this rank's supervisor that everything that matters is done
+        _touch(_marker(os.environ["CB_BENCH_JOB"], int(os.environ.get("CB_BENCH_ATTEMPT", "0")), f"r{rank}.done"))
     if world > 1:
         dist.destroy_process_group()
+
+
+def rccl_summary():
+    """what RCCL said about itself (rank 0's NCCL_DEBUG=INFO log, written to NCCL_DEBUG_FILE by main()): version, channel count,
+    and which algorithms / protocols it set up -- the bench line records what carried the buckets, it does not choose it"""
+    import glob
+    import re
+    info = {"NCCL_ALGO": os.environ.get("NCCL_ALGO"), "NCCL_PROTO": os.environ.get("NCCL_PROTO")}
+    try:
+        path = os.environ.get("CB_BENCH_RCCL_LOG")
+        files = sorted(glob.glob(path.replace("%p", "*"))) if path else []
+        text = "".join(open(f, errors="replace").read() for f in files[:4])
+        ver = re.search(r"(RCCL|NCCL) version[ :]*([0-9][^\s]*)", text)
+        info["version"] = ver.group(0) if ver else None
+        ch = re.findall(r"(\d+) coll channels", text)
+        info["coll_channels"] = int(ch[-1]) if ch else None
+        info["rings_connected"] = "Connected all rings" in text
+        info["trees_connected"] = "Connected all trees" in text
+        algo = re.findall(r"Algo(?:rithm)?[ =:]+(\w+).{0,40}?Proto(?:col)?[ =:]+(\w+)", text)
+        info["algo_proto_seen"] = sorted({f"{a}/{p}" for a, p in algo})[:8] or None
+    except Exception as e:                                  # noqa: BLE001
+        info["error"] = repr(e)[:120]
+    return info
 
 
 def dp_self_check(bank, dist, dev, compute_weights=False):
@@ -594,84 +781,50 @@ def dp_self_check(bank, dist, dev, compute_weights=False):
     return f"MISMATCH: parameter checksums differ across ranks by {rel:.1e} ({lo.tolist()} vs {hi.tolist()})"
 
 
-def measure_roofline(step_fn, pmc_ok=True):
-    """Durations of the cb_gemm kernels of the step, by kernel family, against the dense bf16 MFMA peak with their
-    ALGORITHMIC flops (2*M*N*K per problem).
+def measure_roofline(step_fn, pmc_ok=True, ms_per_step=None):
+    """Every GEMM problem of the step, by family, each against THE ROOF THAT BOUNDS IT (clipbert_amd/gemm_log.py): the encoder linears,
+    the 3x3 / 7x7 convolutions, the ResNet 1x1 convolutions with K > 256 and all weight gradients against the dense bf16 MFMA peak with
+    their algorithmic flops (2*M*N*K); the ResNet 1x1 convolutions with K <= 256 against the HBM peak with their algorithmic bytes
+    (operands + output + the epilogue's M x N operands, each once).
 
-    A family = all cb_gemm launches of one form (forward / data gradient / weight gradient, linear or implicit-GEMM conv), whichever
-    kernel template serves them (4-wave gemm_kernel, 8-wave gemm8_kernel + its split-K reduce).
-
-    HIP events cost several microseconds each on this stack, so bracketing every ~20 us launch individually would
-    measure the markers.  Instead one eager step is recorded (every cb_gemm call with its live operands), then each
-    family's calls are replayed back to back -- captured in a hipGraph, `reps` times -- between ONE pair of HIP events
-    on the launch stream: avg launch duration = elapsed / (reps * launches), which is what rocprofv3's kernel trace of
-    the same command reports (profiles/)."""
-    from clipbert_amd import ops
-    calls = []
-    orig = ops.gemm
-
-    def logged(a, b, M, N, K, **kw):
-        form = ("wgrad" if kw.get("a_mode", 0) == ops.KROW else ("dgrad" if kw.get("b_mode", 0) in (ops.KROW, ops.KROW_TAPS) else "fwd"))
-        conv = kw.get("a_mode", 0) == ops.ROWK_GATHER or kw.get("b_mode", 0) == ops.KROW_GATHER
-        key = f"cb_gemm<bf16> {form}{' (implicit-GEMM conv)' if conv else ''}"
-        calls.append((key, 2.0 * M * N * K * kw.get("batch", 1), (a, b, M, N, K), kw))
-        return orig(a, b, M, N, K, **kw)
-
-    ops.gemm = logged
-    try:
-        step_fn()
-        torch.cuda.synchronize()
-    finally:
-        ops.gemm = orig
-    fams = {}
-    for key, fl, pos, kw in calls:
-        fams.setdefault(key, []).append((fl, pos, kw))
-    reps, outer = 3, 5
-    agg = {}
-    for key, lst in fams.items():
-        def replay():
-            for _ in range(reps):
-                for fl, pos, kw in lst:
-                    orig(*pos, **kw)
-        replay()
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            replay()
-        g.replay()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(outer):
-            g.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) * 1e-3 / (reps * outer)             # seconds for one pass over the family's launches
-        agg[key] = [sum(x[0] for x in lst), t, len(lst)]
-        del g
-    tot_fl = sum(a[0] for a in agg.values())
-    tot_t = sum(a[1] for a in agg.values())
-    dom = max(agg.items(), key=lambda kv: kv[1][1])
-    achieved = dom[1][0] / dom[1][1] / 1e12
-    # HBM bytes per launch of that kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-    # separate runs, gfx950 correction applied -- profiles/r02_pmc_traffic.json); null when no PMC data is committed
+    One eager step is recorded (every cb_gemm / cb_gemm_group call with its live operands); each family's calls are then replayed back
+    to back -- captured in a hipGraph, `reps` times -- between ONE pair of HIP events on the launch stream: avg launch duration =
+    elapsed / launches, the figure rocprofv3's kernel trace of the same command reports (profiles/).  `kernel` = the family with the
+    most time; `step` = all GEMM flops of the step over the measured wall time of the whole step."""
+    from clipbert_amd import gemm_log
+    fams = gemm_log.family_table(step_fn)
+    dom_name, dom = max(fams.items(), key=lambda kv: kv[1]["ms"])
+    mf = {k: v for k, v in fams.items() if v["bound"] == "mfma"}
+    tot_fl = sum(v["gflop"] for v in fams.values())
+    tot_ms = sum(v["ms"] for v in fams.values())
+    # HBM bytes per launch of the dominant family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+    # runs, gfx950 correction applied: tools/pmc_traffic.py); null when no PMC data is committed for this workload / family
     traffic, over = None, None
     try:
         if not pmc_ok:                       # the committed PMC passes were taken on the default (metric) workload only
             raise KeyError("no PMC data for this workload")
         with open(PMC_TRAFFIC_FILE) as fh:
-            fam = json.load(fh)["families"][dom[0]]
+            fam = json.load(fh)["families"][dom_name]
         traffic, over = fam["hbm_bytes_per_launch"], fam.get("hbm_over_algorithmic")
     except Exception:
         traffic = None
-    return {"bound": "mfma", "kernel": dom[0], "launches": dom[1][2], "avg_launch_us": round(dom[1][1] / dom[1][2] * 1e6, 2),
-            "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-            "traffic": traffic, "traffic_unit": f"HBM bytes per launch (PMC, {os.path.relpath(PMC_TRAFFIC_FILE, ROOT)})",
-            "hbm_over_algorithmic": over,
-            "algorithmic_flop_per_launch": round(dom[1][0] / dom[1][2]),
-            "all_gemm_kernels": {"achieved": round(tot_fl / tot_t / 1e12, 2), "frac": round(tot_fl / tot_t / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
-                                 "time_ms": round(tot_t * 1e3, 3), "gflop_per_step": round(tot_fl / 1e9, 1)},
-            "by_kernel": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms": round(v[1] * 1e3, 3), "launches": v[2]} for k, v in agg.items()}}
+    hbm = dom["bound"] == "hbm"
+    out = {"bound": dom["bound"], "kernel": f"cb_gemm<bf16> {dom_name}", "launches": dom["launches"], "avg_launch_us": dom["avg_launch_us"],
+           "achieved": dom["gbs"] if hbm else dom["tflops"], "peak": gemm_log.HBM_PEAK_GBS if hbm else BF16_MFMA_PEAK_TFLOPS,
+           "unit": "GB/s" if hbm else "TFLOP/s", "frac": dom["frac"],
+           "traffic": traffic, "traffic_unit": f"HBM bytes per launch (PMC, {os.path.relpath(PMC_TRAFFIC_FILE, ROOT)})",
+           "hbm_over_algorithmic": over,
+           "algorithmic_flop_per_launch": round(dom["gflop"] * 1e9 / dom["launches"]),
+           "algorithmic_bytes_per_launch": round(dom["algorithmic_mbytes"] * 1e6 / dom["launches"]),
+           "families": fams,
+           "all_gemm_kernels": {"achieved": round(tot_fl / tot_ms, 2), "frac": round(tot_fl / tot_ms / BF16_MFMA_PEAK_TFLOPS, 4),
+                                "time_ms": round(tot_ms, 3), "gflop_per_step": round(tot_fl, 1), "launches": sum(v["launches"] for v in fams.values()),
+                                "mfma_bound_families_frac": round(sum(v["gflop"] for v in mf.values()) / max(1e-9, sum(v["ms"] for v in mf.values())) / BF16_MFMA_PEAK_TFLOPS, 4)}}
+    if ms_per_step:
+        out["step"] = {"gflop": round(tot_fl, 1), "ms": round(ms_per_step, 3), "tflops": round(tot_fl / ms_per_step, 1),
+                       "frac": round(tot_fl / ms_per_step / BF16_MFMA_PEAK_TFLOPS, 4),
+                       "note": "GEMM / conv flops of the step (attention, LayerNorm, AdamW not counted) over the wall time of the WHOLE step, vs the dense bf16 MFMA peak"}
+    return out
 
 
 def cpu_baseline(cfg, args):

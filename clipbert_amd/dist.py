@@ -227,6 +227,9 @@ class GradSync:
         # sync.owned_pieces()) updates only those pieces, gather_updated() ALL-GATHERS the new compute weights (and the fp32 masters
         # of the groups kernels read in fp32).  Same bytes on the links as the all-reduce; the optimizer streams 1/world of the state.
         self.shard = bool(shard)
+        # mute (diagnostic, set by bench.py AFTER its timed region): every collective of the plan is skipped while everything else a
+        # rank does stays -- the step time with and without the links gives the EXPOSED communication time of the plan
+        self.mute = False
         self._owned_done: List = []         # ... of the exchange wait() completed last (what the optimizer / gather_updated use)
         self._buckets_done: List = []
         self._owned: List = []              # (lo, hi) pieces of the flat buffers this rank owns, from the buckets reduced since wait()
@@ -389,7 +392,7 @@ class GradSync:
         """one bucket: all-reduce, or (shard=True) reduce-scatter in place -- this rank's 1/world slice receives the sum"""
         if not self.shard:
             return self._all_reduce(t)
-        if self.dry:
+        if self.dry or self.mute:
             return None
         if self.native is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream(t.device))
@@ -409,7 +412,7 @@ class GradSync:
 
     def norm_all_reduce(self, sq: torch.Tensor):
         """sum over the ranks of the squared-gradient partial of the owned pieces (every rank then derives the same clip coefficient)"""
-        if not self.active or self.dry or (self.world == 1 and not self.loopback):
+        if not self.active or self.dry or self.mute or (self.world == 1 and not self.loopback):
             return sq
         if self.native is not None:
             self.native.all_reduce_(sq)                   # (on the current stream, between the partial sums and the update)
@@ -454,6 +457,8 @@ class GradSync:
             bank.owner_only_dirty = False
 
     def _gather(self, t: torch.Tensor):
+        if self.mute:
+            return
         if self.native is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream(t.device))
             self.native.all_gather_(t, self.comm_stream)
@@ -476,7 +481,7 @@ class GradSync:
             t[r * n:(r + 1) * n].copy_(p)
 
     def _all_reduce(self, t: torch.Tensor):
-        if self.dry:
+        if self.dry or self.mute:
             return None
         if self.native is None:
             return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)

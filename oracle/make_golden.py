@@ -37,8 +37,8 @@ CASES = {
                          cfg=dict(num_labels=2, loss_type="ce", margin=0.1)),
     "retrieval_rank": dict(head="retrieval", n_videos=2, n_frames=2, size=224, lt=32, repeat=2,
                            cfg=dict(num_labels=1, loss_type="rank", margin=0.1)),
-    # config 4: TGIF-QA action, multiple choice with 5 options, Lt=25
-    "tgif_mc": dict(head="multiple_choice", n_videos=2, n_frames=2, size=224, lt=25, repeat=5,
+    # config 4: TGIF-QA action, multiple choice with 5 options, Lt=25 (4 questions; the classifier is TRAINED, see HEAD_TRAIN)
+    "tgif_mc": dict(head="multiple_choice", n_videos=4, n_frames=2, size=224, lt=25, repeat=5,
                     cfg=dict(num_labels=5, loss_type="ce")),
     # frame-QA style open-ended classifier (a18); small label space to keep the fixture small
     "seqcls_ce": dict(head="sequence_classification", n_videos=2, n_frames=1, size=224, lt=16,
@@ -53,17 +53,44 @@ CLIP_CASES = {
     "msrvtt_lse_c4_448": dict(head="retrieval", n_videos=2, n_clips=4, n_frames=2, size=448, lt=20, repeat=2, pool="lse", mode="train",
                               cfg=dict(num_labels=2, loss_type="ce", margin=0.1)),
     # BASELINE configs[3]: TGIF-QA action at the JSON's native sizes (768 px, L_txt 25 -> L = 169), N_clip = 2, mean pooling
-    "tgif_mc_c2_768": dict(head="multiple_choice", n_videos=2, n_clips=2, n_frames=2, size=768, lt=25, repeat=5, pool="mean", mode="train",
+    "tgif_mc_c2_768": dict(head="multiple_choice", n_videos=4, n_clips=2, n_frames=2, size=768, lt=25, repeat=5, pool="mean", mode="train",
                            cfg=dict(num_labels=5, loss_type="ce")),
     # BASELINE configs[4]: retrieval inference, one video x 16 clips against 8 captions, LSE pooling, scores rounded to 4 places
     "msrvtt_infer_c16": dict(head="retrieval", n_videos=1, n_clips=16, n_frames=2, size=224, lt=32, repeat=8, pool="lse", mode="infer",
                              cfg=dict(num_labels=2, loss_type="ce", margin=0.1)),
 }
 
+# Heads with DECIDED margins.  A random-init model separates the five answer options of a question (and the
+# 30522 entries of the MLM head) by less than bf16 storage resolves, so "argmax-exact answer ids" could not be asserted in the
+# arithmetic that is timed.  For these cases the HEAD parameters listed here are trained for a few hundred steps of the REFERENCE's
+# own AdamW (src/optimization/adamw.py:40-103) through the reference's own head modules on the case's fixed batch (upstream features
+# frozen), and shipped as tests/golden/<case>_head.npz; build_case() overlays them on the synthetic state dict, so the GPU box rebuilds
+# the exact weights without the reference.  The golden outputs are then produced by the reference classes with those weights, as for
+# every other case.  Target: every top-1 / top-2 margin > 10x the bf16 error of the logits where the features allow it (oracle/make_bf16_yardstick.py records
+# margin and error per case).
+HEAD_TRAIN = {
+    "tgif_mc": dict(params=("transformer.classifier.2.",), steps=400, lr=2e-3),
+    # 768 px / L = 169: the five answer texts move the pooled features by rms 0.013 against 0.0044 of bf16 noise, so no head reaches
+    # 10x here (measured: the fully trained classifier, either layer or both, with or without noise injection, ends at a margin of
+    # 4-5x the bf16 error of the pooled logits); 2000 steps give 5.3x -- still decided: flipping an answer needs 2 x the error > margin
+    "tgif_mc_c2_768": dict(params=("transformer.classifier.2.",), steps=2000, lr=5e-3),
+    "pretrain_cfg1": dict(params=("transformer.cls.predictions.transform.",), steps=300, lr=1e-3),
+}
+
 _SD_CACHE = {}
 
 
-def build_case(name: str, seed: int = 42):
+def head_override_path(name: str) -> str:
+    return os.path.join(GOLDEN_DIR, name + "_head.npz")
+
+
+def mlm_train_targets(ids: torch.Tensor, seed: int = 42) -> torch.Tensor:
+    """targets of the pretraining head's training (HEAD_TRAIN): one fixed random token per TEXT POSITION, padding included (the
+    golden compares the MLM arg-max at every position)"""
+    return torch.randint(1000, 30522, ids.shape, generator=S._gen(seed, "mlm_target"), dtype=torch.long)
+
+
+def build_case(name: str, seed: int = 42, trained_head: bool = True):
     c = CASES[name] if name in CASES else dict(CLIP_CASES[name], n_frames=CLIP_CASES[name]["n_clips"] * CLIP_CASES[name]["n_frames"])
     cfg = dict(O.BASE_CONFIG)
     cfg.update(c["cfg"])
@@ -73,6 +100,14 @@ def build_case(name: str, seed: int = 42):
         _SD_CACHE.clear()
         _SD_CACHE[key] = S.full_state_dict(cfg, head, seed)
     sd = _SD_CACHE[key]
+    if trained_head and name in HEAD_TRAIN:
+        over = np.load(head_override_path(name))      # missing file = the fixture was not generated: fail loudly
+        sd = dict(sd)
+        for k in over.files:
+            assert k in sd and tuple(sd[k].shape) == over[k].shape, k
+            sd[k] = torch.from_numpy(over[k].astype(np.float32))
+        if "transformer.cls.predictions.bias" in sd:   # aliased keys of the tied decoder stay aliased
+            sd["transformer.cls.predictions.decoder.bias"] = sd["transformer.cls.predictions.bias"]
     frames = S.synthetic_frames(c["n_videos"], c["n_frames"], c["size"], seed)
     n_pairs = c["n_videos"] * c["repeat"]
     ids, mask = S.synthetic_text(n_pairs, c["lt"], seed)
@@ -105,6 +140,60 @@ def fingerprint(t: torch.Tensor, n: int = 32):
 REF_CLASS = dict(retrieval="ClipBertForVideoTextRetrieval", multiple_choice="ClipBertForMultipleChoice",
                  sequence_classification="ClipBertForSequenceClassification",
                  pretraining="ClipBertForPreTraining")
+
+
+def train_head(name: str, verbose: bool = True):
+    """HEAD_TRAIN: train the listed head parameters with the reference's AdamW through the reference's head modules on the frozen
+    upstream features of the case's batch; writes tests/golden/<name>_head.npz."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_ref_adamw", os.path.join(ref_shim.REFERENCE_ROOT, "src", "optimization", "adamw.py"))
+    ref_adamw = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_adamw)
+    ht = HEAD_TRAIN[name]
+    cfg, head, sd, batch = build_case(name, trained_head=False)
+    mo, _tr = ref_shim.load_reference_modeling()
+    model = getattr(mo, REF_CLASS[head])(ref_shim.make_config(cfg)).eval()
+    tsd = {k[len("transformer."):]: v for k, v in sd.items() if k.startswith("transformer.")}
+    missing, unexpected = model.load_state_dict(tsd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    c = CASES[name] if name in CASES else CLIP_CASES[name]
+    n_clips = c.get("n_clips", 1)
+    vis = batch["visual_inputs"]
+    vis = vis.view(c["n_videos"], n_clips, vis.shape[1] // n_clips, *vis.shape[2:])
+    feats = []                                       # frozen upstream features, one entry per clip
+    with torch.no_grad():
+        for k in range(n_clips):
+            grid = O.repeat_rows(O.grid_feat_backbone(sd, vis[:, k], "cnn."), batch["n_examples_list"])
+            seq, pooled = model.bert(text_input_ids=batch["text_input_ids"], visual_inputs=grid,
+                                     attention_mask=batch["text_input_mask"])[:2]
+            feats.append((seq, pooled))
+    named = {"transformer." + n: p for n, p in model.named_parameters()}
+    train = {n: p for n, p in named.items() if n.startswith(ht["params"])}
+    assert train, ht
+    for p in model.parameters():
+        p.requires_grad_(False)
+    for p in train.values():
+        p.requires_grad_(True)
+    opt = ref_adamw.AdamW(list(train.values()), lr=ht["lr"], betas=(0.9, 0.98), weight_decay=0.0)
+    lt = batch["text_input_mask"].shape[1]
+    import warnings
+    for step in range(ht["steps"]):
+        if head == "pretraining":
+            scores, _ = model.cls(feats[0][0][:, :lt], feats[0][1])
+            loss = torch.nn.functional.cross_entropy(scores.view(-1, cfg["vocab_size"]), mlm_train_targets(batch["text_input_ids"]).view(-1))
+        else:                                        # run_video_qa.py:484-501: mean of the clips' logits, then calc_loss
+            logits = torch.stack([model.classifier(pooled) for _seq, pooled in feats]).mean(0)
+            _, per = model.calc_loss(logits, batch["labels"])
+            loss = per.mean()
+        opt.zero_grad()
+        loss.backward()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")           # the reference's AdamW uses the deprecated add_(Number, Tensor) overloads
+            opt.step()
+        if verbose and (step % 50 == 0 or step == ht["steps"] - 1):
+            print(f"[train_head {name}] step {step} loss {float(loss):.5f}", flush=True)
+    np.savez_compressed(head_override_path(name), **{n: p.detach().numpy() for n, p in train.items()})
+    _SD_CACHE.clear()
 
 
 @torch.no_grad()
@@ -148,6 +237,8 @@ def run_reference(name: str):
         out["mlm_loss"] = res["mlm_loss"].numpy()
         out["mlm_argmax"] = res["mlm_scores"].argmax(-1).numpy()
         out["mlm_scores_strided"] = res["mlm_scores"][..., ::509].numpy()
+        top2 = res["mlm_scores"].topk(2, dim=-1)[0]
+        out["mlm_margin_min"] = np.float32((top2[..., 0] - top2[..., 1]).min().item())      # how decided the arg-max is
     else:
         out["logits"] = res["logits"].numpy()
         out["loss"] = res["loss"].numpy()
@@ -217,6 +308,8 @@ def main():
     for name in list(CASES) + list(CLIP_CASES):
         if only and name not in only:
             continue
+        if name in HEAD_TRAIN:
+            train_head(name)
         out = run_reference(name) if name in CASES else run_reference_clips(name)
         path = os.path.join(GOLDEN_DIR, name + ".npz")
         np.savez_compressed(path, **out)

@@ -4,8 +4,10 @@
 (2) the CPU oracle, on every BASELINE head / shape.
 
 Tolerances (north_star): fp32 parity mode -- ITM logits / retrieval scores within 1e-3 of the reference
-CPU forward, QA answer ids argmax-exact;  bf16 performance mode -- stated looser bound (3e-2 abs on
-logits whose scale is O(0.1..1)) plus argmax agreement.  Nothing here reads /root/reference.
+CPU forward (relative to the logit scale where a TRAINED head makes logits of O(10): 1e-3 x max(1, scale)), QA answer ids
+argmax-exact;  bf16 performance mode -- 1.5 x the error of the CPU oracle run with bf16 storage on the same case
+(tests/parity_bounds.py: a committed constant, nothing measured on the product), QA answer ids argmax-exact and MLM arg-max
+>= 0.99 on the decided-margin goldens.  Nothing here reads /root/reference.
 """
 import os
 
@@ -13,6 +15,7 @@ import numpy as np
 import pytest
 import torch
 
+import parity_bounds as PB
 from clipbert_amd import modeling as M
 from clipbert_amd import synthetic as S
 from oracle import clipbert_oracle as O
@@ -47,18 +50,19 @@ def test_forward_matches_reference_golden(name, dtype):
         out = model(to_dev(batch))
     torch.cuda.synchronize()
     f32 = dtype == torch.float32
-    tol = 1e-3 if f32 else 3e-2
     if head == "pretraining":
         itm = out["itm_scores"].float().cpu().numpy()
-        assert np.abs(itm - gold["itm_scores"]).max() < tol, np.abs(itm - gold["itm_scores"]).max()
+        assert np.abs(itm - gold["itm_scores"]).max() <= (1e-3 if f32 else PB.bf16_bound(name, "itm_scores")), np.abs(itm - gold["itm_scores"]).max()
         mlm = out["mlm_scores"].float().cpu().numpy()
-        assert np.abs(mlm[..., ::509] - gold["mlm_scores_strided"]).max() < (2e-3 if f32 else 1e-1)
+        scale = max(1.0, float(np.abs(gold["mlm_scores_strided"]).max()))                    # the trained transform makes logits of O(10)
+        assert np.abs(mlm[..., ::509] - gold["mlm_scores_strided"]).max() <= (2e-3 * scale if f32 else PB.bf16_bound(name, "mlm_scores_strided"))
         agree = (mlm.argmax(-1) == gold["mlm_argmax"]).mean()
-        assert agree == 1.0 if f32 else agree >= 0.9, agree
+        assert agree == 1.0 if f32 else agree >= 0.99, agree
     else:
         lg = out["logits"].float().cpu().numpy()
         err = np.abs(lg - gold["logits"]).max()
-        assert err < tol, (name, dtype, err)
+        tol = 1e-3 * max(1.0, float(np.abs(gold["logits"]).max())) if f32 else PB.bf16_bound(name, "logits")
+        assert err <= tol, (name, dtype, err, tol)
         if head == "multiple_choice":          # QA answer ids: argmax-exact (run_video_qa.py:273-275)
             assert (lg.argmax(-1) == gold["logits"].argmax(-1)).all()
         if f32:
@@ -171,9 +175,9 @@ def test_multi_clip_config_matches_reference_golden(name, dtype):
     cfg, head, sd, batch = G.build_case(name)
     model = build_model(cfg, head, sd, dtype)
     f32 = dtype == torch.float32
-    tol = 1e-3 if f32 else 3e-2
     b = to_dev(batch)
     if c["mode"] == "train":
+        tol = 1e-3 * max(1.0, float(np.abs(gold["stack"]).max())) if f32 else PB.bf16_bound(name, "logits")
         tcfg = SimpleNamespace(task="action" if head == "multiple_choice" else None, num_labels=cfg["num_labels"])
         if head == "multiple_choice":
             b["n_examples_list"] = [1] * c["n_videos"]                    # questions per video; x num_labels inside (run_video_qa.py:206)
@@ -184,9 +188,9 @@ def test_multi_clip_config_matches_reference_golden(name, dtype):
         st = stack.float().cpu().numpy()
         assert st.shape == gold["stack"].shape
         err = np.abs(st - gold["stack"]).max()
-        assert err < tol, (name, dtype, err)
-        assert abs(float(loss) - float(gold["loss"].mean())) < (1e-3 if f32 else 2e-2)
-        if head == "multiple_choice" and f32:                            # answer ids: argmax-exact after pooling
+        assert err <= tol, (name, dtype, err, tol)
+        assert abs(float(loss) - float(gold["loss"].mean())) <= (1e-3 if f32 else PB.bf16_bound(name, "loss"))
+        if head == "multiple_choice":                                    # answer ids: argmax-exact after pooling, in fp32 AND bf16
             pooled = st.mean(0)
             assert (pooled.argmax(-1) == gold["answer_ids"]).all()
             qcfg = SimpleNamespace(inference_n_clips=c["n_clips"], num_frm=c["n_frames"], score_agg_func=c["pool"], task="action",
@@ -202,5 +206,5 @@ def test_multi_clip_config_matches_reference_golden(name, dtype):
                                                  cache_cnn=True, max_pairs_per_pass=4 * c["repeat"])
         assert len(scores) == len(gold["scores"])
         err = max(abs(a - r) for a, r in zip(scores, gold["scores"].tolist()))
-        assert err <= (1.01e-4 if f32 else 1e-2), (name, dtype, err)      # rounded to 4 places: one unit of the last place
+        assert err <= (1.01e-4 if f32 else PB.bf16_bound(name, "scores")), (name, dtype, err)      # rounded to 4 places: one unit of the last place
         assert all(round(s, 4) == s for s in scores)

@@ -1,10 +1,14 @@
-"""bf16 (the benchmarked arithmetic) against the reference's goldens and the oracle's autograd, with MEASURED numbers.
+"""bf16 (the benchmarked arithmetic) against the reference's goldens and the oracle's autograd, held to an INDEPENDENT yardstick.
 
 Every full-size golden case is run in bf16 on the MI355X; the max |delta| of its logits / clip stack / retrieval scores against the
-golden vector is (a) recorded -- gpurun_out/r03_bf16_parity.json on the GPU box, copied to profiles/ by the builder -- and (b) held to
-a per-case tolerance of 2x the value measured when tests/golden/bf16_tolerances.json was written (a case without an entry falls
-back to the stated bound 3e-2).  The bf16 GRADIENTS of the retrieval training forward are compared with autograd through the CPU
-ORACLE (not with the product's own fp32 mode): cosine of the full flat gradient and per-tensor relative L2 error.
+golden vector is (a) recorded -- gpurun_out/r04_bf16_parity.json on the GPU box, copied to profiles/ by the builder -- and (b) held to
+1.5 x the error of the CPU ORACLE run with bf16 storage on the same case (tests/parity_bounds.py, tests/golden/bf16_yardstick.json:
+a committed constant computed from the oracle and the goldens alone -- no number measured on the product enters a bound, and no
+round-end script rewrites one).  QA answer ids and the MLM arg-max are asserted in bf16 on goldens whose margins are DECIDED (heads
+trained with the reference's AdamW, oracle/make_golden.py HEAD_TRAIN): answer ids exact (run_video_qa.py:273-275), MLM arg-max >= 0.99
+(modeling.py:283-285).  The bf16 GRADIENTS of the retrieval training forward are compared with autograd through the CPU ORACLE in fp32
+and held to 1.5 x what the bf16 oracle's own autograd shows against the same reference: cosine of the flat gradient, per-tensor
+relative L2 error (median, worst, and tensor by tensor).
 
 north_star tolerances stay where they are for the fp32 parity mode (1e-3, argmax-exact QA ids: tests/test_gpu_full.py)."""
 import json
@@ -15,6 +19,7 @@ import numpy as np
 import pytest
 import torch
 
+import parity_bounds as PB
 from clipbert_amd import modeling as M  # noqa: F401
 from clipbert_amd import tasks
 from oracle import clipbert_oracle as O
@@ -23,16 +28,8 @@ from test_gpu_full import DEV, GOLDEN, build_model, to_dev
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TOL_FILE = os.path.join(GOLDEN, "bf16_tolerances.json")
-RECORD = os.path.join(ROOT, "gpurun_out", "r03_bf16_parity.json")
-FALLBACK = 3e-2
-
-
-def _tolerances():
-    if os.path.exists(TOL_FILE):
-        with open(TOL_FILE) as fh:
-            return json.load(fh)
-    return {}
+RECORD = os.path.join(ROOT, "gpurun_out", "r04_bf16_parity.json")
+INFO_KEYS = ("logit_scale", "answer_ids_decided", "margin_over_yardstick_error", "questions")
 
 
 def _record(key, value):
@@ -46,15 +43,14 @@ def _record(key, value):
         json.dump(data, fh, indent=1, sort_keys=True)
 
 
-def _answer_agreement(ours, gold, err):
-    """QA answer ids in bf16: agreement with the golden argmax, overall and over the questions whose golden top-2 margin exceeds
-    twice the measured logit error (a random-init model separates its options by less than bf16 resolves; the fp32 parity mode
-    is the one held to argmax-exact, tests/test_gpu_full.py)."""
+def _answer_agreement(name, ours, gold):
+    """QA answer ids in bf16 against the golden arg-max (run_video_qa.py:273-275).  A question is DECIDED when its golden top-2 margin
+    exceeds 2 x the bound of the logit error (two options moving against each other by the whole bound cannot swap)."""
     top2 = np.sort(gold, axis=-1)[..., -2:]
-    decided = (top2[..., 1] - top2[..., 0]) > 2 * err
+    decided = (top2[..., 1] - top2[..., 0]) > 2 * PB.bf16_bound(name, "logits")
     same = ours.argmax(-1) == gold.argmax(-1)
-    return {"answer_ids_agree_raw": float(same.mean()), "answer_ids_decided": int(decided.sum()),
-            "answer_ids_agree": float(same[decided].mean()) if decided.any() else 1.0}
+    return {"answer_ids_agree": float(same.mean()), "answer_ids_decided": int(decided.sum()), "questions": int(same.size),
+            "margin_over_yardstick_error": round(PB.margin_over_error(name), 2)}
 
 
 @pytest.mark.parametrize("name", list(G.CASES) + list(G.CLIP_CASES))
@@ -72,12 +68,13 @@ def test_bf16_error_against_reference_goldens_is_recorded_and_bounded(name):
                 mlm = out["mlm_scores"].float().cpu().numpy()
                 rec["mlm_scores_strided"] = float(np.abs(mlm[..., ::509] - gold["mlm_scores_strided"]).max())
                 rec["mlm_argmax_agreement"] = float((mlm.argmax(-1) == gold["mlm_argmax"]).mean())
+                rec["margin_over_yardstick_error"] = round(PB.margin_over_error(name), 2)
             else:
                 lg = out["logits"].float().cpu().numpy()
                 rec["logits"] = float(np.abs(lg - gold["logits"]).max())
                 rec["logit_scale"] = float(np.abs(gold["logits"]).max())
                 if head == "multiple_choice":
-                    rec.update(_answer_agreement(lg, gold["logits"], rec["logits"]))
+                    rec.update(_answer_agreement(name, lg, gold["logits"]))
         else:
             c = G.CLIP_CASES[name]
             if c["mode"] == "train":
@@ -91,27 +88,34 @@ def test_bf16_error_against_reference_goldens_is_recorded_and_bounded(name):
                 rec["logit_scale"] = float(np.abs(gold["stack"]).max())
                 rec["loss"] = abs(float(loss) - float(gold["loss"].mean()))
                 if head == "multiple_choice":
-                    rec.update(_answer_agreement(st.mean(0), gold["stack"].mean(0), rec["logits"]))
+                    rec.update(_answer_agreement(name, st.mean(0), gold["stack"].mean(0)))
+                    qcfg = SimpleNamespace(inference_n_clips=c["n_clips"], num_frm=c["n_frames"], score_agg_func=c["pool"], task="action",
+                                           num_labels=cfg["num_labels"])
+                    rec["qa_predict_equals_golden_answer_ids"] = float(tasks.qa_predict(model, dict(b), qcfg, fold_clips=True) == gold["answer_ids"].tolist())
             else:
                 icfg = SimpleNamespace(inference_n_clips=c["n_clips"], num_frm=c["n_frames"], score_agg_func=c["pool"], inference_batch_size=c["repeat"])
                 scores = tasks.inference_retrieval_video(model, b["visual_inputs"], b["text_input_ids"], b["text_input_mask"], icfg,
                                                          cache_cnn=True, max_pairs_per_pass=4 * c["repeat"])
                 rec["scores"] = float(max(abs(a - r) for a, r in zip(scores, gold["scores"].tolist())))
     torch.cuda.synchronize()
+    rec["bounds"] = {k: PB.bf16_bound(name, k) for k in rec if k in ("logits", "loss", "scores", "itm_scores", "mlm_scores_strided")}
     _record(name, rec)
-    tol = _tolerances().get(name, {})
-    for k, v in rec.items():
-        if k in ("logit_scale", "answer_ids_agree_raw", "answer_ids_decided"):
-            continue
-        if k.endswith("agreement") or k.endswith("agree"):
-            assert v >= tol.get(k, 0.9 if k != "answer_ids_agree" else 1.0), (name, k, v)
-        else:
-            assert v <= tol.get(k, FALLBACK if k != "mlm_scores_strided" else 1e-1), (name, k, v, tol.get(k))
+    for k, bound in rec["bounds"].items():
+        assert rec[k] <= bound, (name, k, rec[k], "bound = 1.5 x the bf16 oracle's error", bound)
+    if head == "multiple_choice":
+        # configs[3]: the answer id IS the output (run_video_qa.py:273-275) -- every question decided, every answer exact, in bf16
+        assert rec["answer_ids_decided"] == rec["questions"], rec
+        assert rec["answer_ids_agree"] == 1.0, rec
+        assert rec.get("qa_predict_equals_golden_answer_ids", 1.0) == 1.0, rec
+    if head == "pretraining":
+        assert rec["mlm_argmax_agreement"] >= 0.99, rec
 
 
 def test_bf16_gradients_against_oracle_autograd():
     """All parameter gradients of the full-size retrieval training forward + backward in bf16 against autograd through the CPU oracle
-    (fp32): cosine of the flat gradient, relative L2 error per tensor (recorded; bounded by 2x the committed measurement)."""
+    (fp32), held to 1.5 x the error the bf16 ORACLE's autograd shows against the same fp32 gradients (tests/golden/bf16_yardstick.json):
+    flat cosine, median / 90th-percentile / worst per-tensor relative L2, and tensor by tensor (at most 5 % of the tensors may exceed
+    1.5 x their own yardstick -- one draw of rounding noise each -- and none 3 x)."""
     cfg, head, sd, batch = G.build_case("retrieval_ce")
     model = build_model(cfg, head, sd, torch.bfloat16)
     out = model(to_dev(batch))
@@ -122,9 +126,9 @@ def test_bf16_gradients_against_oracle_autograd():
     sdr = {k: v.clone().requires_grad_(v.is_floating_point() and ".norm." not in k) for k, v in sd.items()}
     ref = O.clipbert_forward(sdr, batch, cfg, head)
     ref["loss"].mean().backward()
+    Y = PB.grad_yardstick()
     dot = n1 = n2 = 0.0
-    worst, worst_name = 0.0, ""
-    rel = []
+    per = {}
     for name, p in model.named_parameters():
         if not p.requires_grad:
             continue
@@ -134,15 +138,22 @@ def test_bf16_gradients_against_oracle_autograd():
         r = g_ref.double()
         dot += float((g * r).sum()); n1 += float((g * g).sum()); n2 += float((r * r).sum())
         if float(r.norm()) > 1e-8:
-            e = float((g - r).norm() / r.norm())
-            rel.append(e)
-            if e > worst:
-                worst, worst_name = e, name
+            per[name] = float((g - r).norm() / r.norm())
     cos = dot / (n1 ** 0.5 * n2 ** 0.5)
-    rec = {"flat_gradient_cosine": cos, "worst_tensor_rel_l2": worst, "worst_tensor": worst_name, "median_tensor_rel_l2": float(np.median(rel)),
-           "tensors": len(rel)}
+    vals = np.array(list(per.values()))
+    worst = max(per, key=per.get)
+    ratio = {k: v / max(Y["per_tensor"][k], 1e-4) for k, v in per.items() if k in Y["per_tensor"]}
+    assert len(ratio) >= 0.95 * len(per), (len(ratio), len(per))
+    over = sorted((k for k in ratio if ratio[k] > PB.FACTOR), key=lambda k: -ratio[k])
+    rec = {"flat_gradient_cosine": cos, "worst_tensor_rel_l2": per[worst], "worst_tensor": worst, "median_tensor_rel_l2": float(np.median(vals)),
+           "p90_tensor_rel_l2": float(np.quantile(vals, 0.9)), "tensors": len(per),
+           "yardstick": {k: v for k, v in Y.items() if k != "per_tensor"}, "factor": PB.FACTOR,
+           "tensors_over_factor_x_own_yardstick": len(over), "largest_ratio_to_own_yardstick": {k: round(ratio[k], 2) for k in over[:5]},
+           "median_ratio_to_own_yardstick": float(np.median(list(ratio.values())))}
     _record("grad_retrieval_ce_vs_oracle_autograd", rec)
-    tol = _tolerances().get("grad_retrieval_ce_vs_oracle_autograd", {})
-    assert cos >= tol.get("flat_gradient_cosine_min", 0.99), rec
-    assert worst <= tol.get("worst_tensor_rel_l2", 0.5), rec
-    assert rec["median_tensor_rel_l2"] <= tol.get("median_tensor_rel_l2", 0.1), rec
+    assert 1.0 - cos <= PB.FACTOR * Y["one_minus_cosine"], rec
+    assert rec["median_tensor_rel_l2"] <= PB.FACTOR * Y["median_tensor_rel_l2"], rec
+    assert rec["p90_tensor_rel_l2"] <= PB.FACTOR * Y["p90_tensor_rel_l2"], rec
+    assert rec["worst_tensor_rel_l2"] <= PB.FACTOR * Y["worst_tensor_rel_l2"], rec
+    assert len(over) <= 0.05 * len(per), rec
+    assert max(ratio.values()) <= 3.0, rec

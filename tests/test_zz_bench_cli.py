@@ -28,6 +28,57 @@ def test_default_workload_is_the_metric_configuration(monkeypatch):
     assert (c.head, c.n_clips, c.repeat, c.txt_len) == ("multiple_choice", 2, 5, 25)
 
 
+def test_supervisor_retries_with_the_next_plan_and_honours_the_done_marker(monkeypatch, tmp_path):
+    """bench.py's N > 1 supervisor: a failed attempt is retried with the next, more conservative plan; a hung one is
+    killed at the deadline; an attempt that completed its timed region and JSON line (done marker) but died in teardown counts as done."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    monkeypatch.setattr(bench, "ATTEMPT_TIMEOUT_S", 3.0)
+    log = tmp_path / "log.txt"
+
+    def job(script_for_attempt):
+        def make(attempt):
+            env = dict(os.environ, CB_ATT=str(attempt), CB_LOG=str(log), CB_PLAN=bench.ATTEMPTS[attempt].get("CB_BENCH_PLAN", "captured"))
+            return [sys.executable, "-c", script_for_attempt[attempt]], env
+        return make
+    note = "import os; open(os.environ['CB_LOG'], 'a').write(os.environ['CB_ATT'] + ':' + os.environ['CB_PLAN'] + '\\n');"
+    # attempt 0 exits 3, attempt 1 succeeds: two attempts ran, the second under the split plan
+    assert bench._run_attempts(job([note + "raise SystemExit(3)", note + "pass", note + "pass"]), 3, 0, "jobA") == 0
+    assert log.read_text().split() == ["0:captured", "1:split"]
+    # attempt 0 hangs (killed at the deadline), attempt 1 too, attempt 2 succeeds
+    log.write_text("")
+    hang = note + "import time; time.sleep(60)"
+    assert bench._run_attempts(job([hang, hang, note + "pass"]), 3, 0, "jobB") == 0
+    assert log.read_text().split() == ["0:captured", "1:split", "2:split"]
+    # every attempt fails: the exit code is not 0
+    assert bench._run_attempts(job(["raise SystemExit(2)"] * 3), 3, 0, "jobC") != 0
+    # done marker written, then a crash in teardown: success, no retry
+    log.write_text("")
+    marker = bench._marker("jobD", 0, "r5.done")
+    crash_after_done = note + f"open({marker!r}, 'w').write('x'); os._exit(11)"
+    assert bench._run_attempts(job([crash_after_done, note + "pass"]), 2, 5, "jobD") == 0
+    assert log.read_text().split() == ["0:captured"]
+    # another rank's failure marker ends this rank's (hung) attempt early and both move on together
+    log.write_text("")
+    open(bench._marker("jobE", 0, "failed"), "w").write("x")
+    import time
+    t0 = time.perf_counter()
+    monkeypatch.setattr(bench, "ATTEMPT_TIMEOUT_S", 60.0)
+    assert bench._run_attempts(job([hang, note + "pass"]), 2, 1, "jobE") == 0
+    assert time.perf_counter() - t0 < 20 and log.read_text().split() == ["0:captured", "1:split"]
+
+
+def test_supervise_is_a_no_op_for_one_gpu_and_for_workers(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    assert bench.supervise(bench.parse()) is None
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    monkeypatch.setenv("CB_BENCH_WORKER", "1")
+    assert bench.supervise(bench.parse()) is None
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -54,6 +105,59 @@ def test_two_rank_dry_run_on_one_gpu(mode):
         assert out["config"]["n_graphs"] in (1, 2, 3, 4) and out["config"]["hip_graph"] is True      # machine fields only: never prose
     else:
         assert out["config"]["rows_gathered"] == 2 * 2 * 64       # 2 ranks x 2 timed steps x 64 captions
+
+
+@pytest.mark.gpu
+def test_bare_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher starts its own two ranks (here both on GPU 0 with gloo collectives)
+    and prints rank 0's single JSON line."""
+    env = dict(os.environ, CB_BENCH_SHARE_GPU="1", CB_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "CB_BENCH_WORKER"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True,
+                       text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["dp_self_check"].startswith("ok")
+    assert out["config"]["attempt"] == 0 and "exposed_comm" in out["config"]
+
+
+def _multi_gpu_bench(extra_env, n=2):
+    env = dict(os.environ, **extra_env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "CB_BENCH_WORKER"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1"], env=env, capture_output=True,
+                       text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("plan", ["captured", "split", "owner_only", "torch_carrier"])
+def test_real_rccl_ranks_when_the_box_has_two_gpus(plan):
+    """on a box with >= 2 GPUs the data-parallel plans run over real RCCL ranks -- the library's own carrier
+    (cb_allreduce_bucket) captured in one graph, the four-graph plan, the owner-only RS -> AdamW -> AG update, torch.distributed as the
+    carrier -- and every one of them ends with bit-identical parameters on all ranks.  Skipped (not failed) on 1-GPU boxes."""
+    if _n_gpus() < 2:
+        pytest.skip("needs >= 2 GPUs (the build boxes have one)")
+    env = {"captured": {"CB_BENCH_PLAN": "captured"}, "split": {"CB_BENCH_PLAN": "split"}, "owner_only": {"CB_BENCH_SHARD": "1", "CB_BENCH_PLAN": "captured"},
+           "torch_carrier": {"CB_BENCH_PLAN": "split", "CB_COMM": "torch"}}[plan]
+    out = _multi_gpu_bench(env, n=min(_n_gpus(), 8))
+    cfg = out["config"]
+    assert out["n_gpus"] >= 2 and out["value"] > 0
+    assert cfg["dp_self_check"].startswith("ok"), cfg["dp_self_check"]
+    assert cfg["grad_exchange"].startswith("torch" if plan == "torch_carrier" else "native"), cfg["grad_exchange"]
+    assert cfg["n_graphs"] == (1 if plan in ("captured", "owner_only") else 4)
+    if plan == "owner_only":
+        assert cfg["update"].startswith("owner-only")
+    assert 0.0 < cfg["final_loss"] < 5.0
 
 
 @pytest.mark.gpu

@@ -24,6 +24,7 @@
 // * Measured bound: L2 -> LDS bandwidth of the tile (profiles/r01_gemm_l2_analysis.md).
 
 #include "gemm8_impl.h"
+#include "gemm_stream_impl.h"
 #include <stdio.h>
 #include <cmath>
 #include <vector>
@@ -171,6 +172,20 @@ ModelPick model_pick(const cb_gemm_desc* d, const GP& p, bool can8, int64_t ws_b
     return best;
 }
 
+// Streaming structure (gemm_stream_impl.h, cb_gemm_desc.tile = 8): the instantiation that covers this problem, or -1.
+// Covered: bf16 fast path, forward form (A and B CB_ROWK), K <= 64 with N a multiple of 256 or K <= 128 with N a multiple of 128,
+// bf16 C through the row-contiguous epilogue with any of scale / shift / activation / residual / relu_after.
+int stream_variant(const cb_gemm_desc* d, const GP& p, bool fast, bool cv8) {
+    if (!fast || !cv8 || d->dtype != CB_BF16 || d->a_mode != CB_ROWK || d->b_mode != CB_ROWK || p.batch > 1 || p.split_k > 1) return -1;
+    if (d->c_f32 || d->accumulate || d->c_rowmap || d->zero_fill_pitch || d->a_rowsum || d->gelu_grad_pre || d->dropout_p > 0.f || d->mask || d->relu_bwd ||
+        d->C2) return -1;
+    if (d->K % 8 != 0 || d->M < 64) return -1;
+    if ((int64_t)d->M * (d->N > d->K ? d->N : d->K) * 2 >= 0x7fffffffll) return -1;       // (32-bit byte offsets of the DMA loaders)
+    if (p.ktiles == 1 && d->N % 256 == 0) return 0;
+    if (p.ktiles == 2 && d->N % 128 == 0) return 1;
+    return -1;
+}
+
 template <int BM, int BN, int WGM, int WGN, int NST>
 int launch8(int form, const GP& p, int mode, float* ws, hipStream_t st) {
     if (form == 1) return launch_gemm8_fwd<BM, BN, WGM, WGN, NST>(p, mode, ws, st);
@@ -269,7 +284,7 @@ int gemm_prepare(const cb_gemm_desc* d, Prepared& out) {
     }
     p.a_bytes = (uint32_t)(fast ? d->a_bytes : 0);
     p.b_bytes = (uint32_t)(fast ? d->b_bytes : 0);
-    CB_REQUIRE(d->tile >= 0 && d->tile <= 7, "cb_gemm: bad tile %d", d->tile);
+    CB_REQUIRE(d->tile >= 0 && d->tile <= 8, "cb_gemm: bad tile %d", d->tile);
     CB_REQUIRE(d->xcd_order >= 0 && d->xcd_order <= 2, "cb_gemm: bad xcd_order %d", d->xcd_order);
     CB_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "cb_gemm: dropout_p out of range");
     // vector epilogue: every touched row pointer must be 16-byte (fp32) / 8-byte (bf16) aligned at n%4==0
@@ -307,6 +322,22 @@ int gemm_run(const cb_gemm_desc* d, void* stream, int32_t* plan, bool use_table)
     static const bool no_remap = getenv("CB_GEMM_NO_XCD_REMAP") != nullptr;
     static const bool no_tuned = getenv("CB_GEMM_NO_TUNED") != nullptr;
     int tile = d->tile, xcd = d->xcd_order;
+    // ---- streaming structure (tile 8): asked for, or chosen for the HBM-bound shapes it was built for -- short reduction, many rows
+    // (measured on MI355X, profiles/r04c_stream_probe.json; CB_GEMM_NO_STREAM=1 restores the one-workgroup-per-tile kernels)
+    {
+        static const bool no_stream = getenv("CB_GEMM_NO_STREAM") != nullptr;
+        static const int min_rows = getenv("CB_GEMM_STREAM_MIN_ROWS") ? atoi(getenv("CB_GEMM_STREAM_MIN_ROWS")) : 32768;
+        const int sv = stream_variant(d, p, fast, cv8);
+        CB_REQUIRE(tile != 8 || sv >= 0, "cb_gemm: tile 8 (streaming) does not cover this problem (M=%d N=%d K=%d modes %d/%d)", d->M, d->N, d->K, d->a_mode, d->b_mode);
+        if (tile == 8 || (tile == 0 && use_table && !no_stream && sv >= 0 && d->M >= min_rows && d->N <= 512)) {
+            p.c_vec8 = 1;
+            p.xcd_remap = 0;
+            if (plan) { plan[0] = 8; plan[1] = 1; plan[2] = sv; plan[3] = 2; return 0; }
+            static const bool trace_s = getenv("CB_GEMM_TRACE") != nullptr;
+            if (trace_s) fprintf(stderr, "cb_gemm: M=%d N=%d K=%d modes=%d/%d tile=8 (asked %d) stream variant %d\n", d->M, d->N, d->K, d->a_mode, d->b_mode, d->tile, sv);
+            return launch_gemm_stream(p, sv, cb_stream(stream));
+        }
+    }
     const int split_caller = p.split_k;
     int split_tuned = 0, sched_tuned = 0;      // K split / K-loop schedule measured best for the table's tile (0: none recorded)
     if (d->dtype == CB_BF16 && !no_tuned && use_table && (tile == 0 || xcd == 0)) {

@@ -88,7 +88,10 @@ typedef struct {
                                  4 = 128x128 with its registers capped so that two blocks share a CU  (bf16; fp32 parity mode
                                  always runs 64x64); 5 = 256x256, 6 = 128x256, 7 = 256x128: the 8-wave LDS-DMA kernels
                                  (bf16, 16-byte-aligned operands and 8-column output chunks; anything else falls back
-                                 to auto)                                                             */
+                                 to auto); 8 = the streaming structure for HBM-bound products with K <= 256 and 10^4+
+                                 rows (persistent workgroups, weights resident in LDS, next A tile and the epilogue's
+                                 operands in flight while a tile is stored: the ResNet's 1x1 convolutions of res2 / res3
+                                 and their data gradients; an error where it does not cover the problem)  */
     int32_t xcd_order;        /* workgroup -> tile order: 0 auto, 1 = XCD-compact (each XCD, with its own L2, owns a
                                  contiguous run of tiles), 2 = dispatch order (consecutive tiles round-robin over XCDs) */
     int64_t a_bytes, b_bytes; /* sizes of the A / B buffers in bytes (0 = unknown).  When both are known, < 2 GiB

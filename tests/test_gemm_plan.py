@@ -71,6 +71,19 @@ def test_explicit_requests_are_kept_and_table_entries_win():
     assert with_table[0] in (1, 2, 3, 4, 5, 6, 7) and without[0] in (1, 2, 3, 4, 5, 6, 7)
 
 
+def test_streaming_structure_takes_the_hbm_bound_forward_shapes_only():
+    """cb_gemm tile 8 (gemm_stream_impl.h): chosen by itself for the ResNet 1x1 convolutions it was measured on -- res2 conv3 / shortcut
+    (K = 64, N = 256) and res3 conv3 (K = 128, N = 512) over >= 32768 pixel rows -- and for nothing else"""
+    assert plan(200704, 256, 64)[0] == 8 and plan(200704, 256, 64)[2] == 0
+    assert plan(50176, 512, 128)[0] == 8 and plan(50176, 512, 128)[2] == 1
+    assert plan(50176, 2304, 128)[0] != 8                          # wide output: not the measured regime
+    assert plan(12544, 256, 64)[0] != 8                            # few rows: one workgroup per tile
+    assert plan(200704, 256, 256)[0] != 8 and plan(200704, 64, 64)[0] != 8
+    assert plan(200704, 256, 64, use_table=0)[0] != 8              # (the model-only path the sweeps are checked against is left alone)
+    assert plan(200704, 256, 64, b_mode=2)[0] != 8                 # data-gradient form
+    assert plan(200704, 256, 64, tile=8)[0] == 8 and plan(64, 256, 64, tile=8)[0] == 8       # explicit requests inside its coverage
+
+
 def test_model_choices_against_the_committed_sweep():
     fit = json.load(open(os.path.join(ROOT, "profiles", "r03m_gemm_model_fit.json")))
     probs = F.load([os.path.join(ROOT, p) for p in fit["sweeps"]])
@@ -95,7 +108,7 @@ def test_random_calls_get_legal_plans():
     import random
     rng = random.Random(7)
     forms = [(0, 0, False), (0, 2, False), (2, 2, True)]                      # (a_mode, b_mode, fp32 accumulate): fwd, dgrad, wgrad
-    seen8 = seen_split4 = 0
+    seen8 = seen_split4 = seen_stream = 0
     for _ in range(1500):
         a_mode, b_mode, wg = rng.choice(forms)
         M = rng.choice([1, 4, 63, 64, 200, 777, 1312, 2624, 5000, 12544, 50176, 200704])
@@ -106,8 +119,12 @@ def test_random_calls_get_legal_plans():
             continue                                                             # (row-contiguous loads of the KROW forms want 8-element rows)
         tile, split, sched, xcd = plan(M, N, K, a_mode=a_mode, b_mode=b_mode, c_f32=wg, accumulate=wg, ws=ws, use_table=rng.random() < 0.5)
         ktiles = -(-K // 64)
-        assert tile in (1, 2, 3, 4, 5, 6, 7) and 1 <= split <= max(1, ktiles) and xcd in (1, 2), (M, N, K, tile, split)
-        if tile >= 5:
+        assert tile in (1, 2, 3, 4, 5, 6, 7, 8) and 1 <= split <= max(1, ktiles) and xcd in (1, 2), (M, N, K, tile, split)
+        if tile == 8:                                              # the streaming structure: only what it was built for
+            seen_stream += 1
+            assert (a_mode, b_mode) == (0, 0) and not wg and K <= 128 and N % 128 == 0 and N <= 512 and M >= 32768 and split == 1, (M, N, K)
+            assert sched == (0 if K <= 64 else 1) and (K > 64 or N % 256 == 0)
+        elif tile >= 5:
             seen8 += 1
             assert N % 8 == 0 and sched in (1, 2, 3)
             if split > 1:
@@ -119,4 +136,5 @@ def test_random_calls_get_legal_plans():
                 assert wg, (M, N, K, a_mode, b_mode, split)
             if N <= 64:
                 assert tile in (2, 3)
-    assert seen8 > 50 and seen_split4 > 5                      # (the sample reaches both regimes)
+    assert seen8 > 50 and seen_split4 > 5                      # (the sample reaches both regimes; the streaming one: next test)
+    assert seen_stream >= 0

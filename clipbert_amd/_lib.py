@@ -60,6 +60,8 @@ _SIGNATURES = {
     "cb_visual_embed_fwd": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
                             i32, i32, i32, f32, vp, vp],
     "cb_text_embed_bwd": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i32, vp],
+    "cb_head_loss": [i32, vp, vp, vp, vp, vp, i64, i32, f32, vp],
+    "cb_retrieval_scores": [vp, vp, i64, i32, vp],
     "cb_mean_fwd": [vp, i64, vp, vp],
     "cb_mean_bwd": [vp, i64, vp, vp],
     "cb_counter_add": [vp, i64, vp],

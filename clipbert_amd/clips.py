@@ -105,8 +105,5 @@ def lse_inference_logits(logits_bnc: torch.Tensor) -> torch.Tensor:
 
 def retrieval_scores(logits_bc: torch.Tensor) -> List[float]:
     """run_video_retrieval.py:681-690: softmax[:, 1] (2-way) or sigmoid (1 logit), rounded to 4 places."""
-    if logits_bc.shape[1] == 2:
-        probs = torch.softmax(logits_bc.float(), dim=1)[:, 1].tolist()
-    else:
-        probs = torch.sigmoid(logits_bc.float().squeeze()).reshape(-1).tolist()
+    probs = ops.retrieval_scores(logits_bc.float().contiguous()).tolist()          # softmax[:, 1] (two logits) or sigmoid (one): cb_retrieval_scores
     return [round(s, 4) for s in probs]

@@ -257,6 +257,60 @@ __global__ void __launch_bounds__(256) lse_loss_kernel(const float* x, const int
 
 inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
+
+// ---- element-wise head losses and retrieval scores (fp32 logits; a handful of values per step, but part of the path: a16 / a18) ----
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// kind 0 / 1: one thread per element; kind 2 (sigmoid margin ranking): one thread per row of `group` logits (first = the positive)
+__global__ void __launch_bounds__(256) head_loss_kernel(int kind, const float* x, const float* y, float* loss, const float* dloss, float* dx,
+                                                        int64_t n, int group, float margin) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (kind == 2) {
+        const int64_t rows = n / group;
+        if (i >= rows) return;
+        const float* xr = x + i * group;
+        const float s0 = sigmoidf_(xr[0]);
+        float d0 = 0.f;
+        for (int j = 1; j < group; ++j) {
+            const float sj = sigmoidf_(xr[j]);
+            const float l = margin + sj - s0;
+            const bool on = l > 0.f;
+            if (loss) loss[i * (group - 1) + j - 1] = on ? l : 0.f;
+            if (dx) {
+                const float g = on ? (dloss ? dloss[i * (group - 1) + j - 1] : 1.0f) : 0.f;
+                dx[i * group + j] = g * sj * (1.0f - sj);
+                d0 -= g;
+            }
+        }
+        if (dx) dx[i * group] = d0 * s0 * (1.0f - s0);
+        return;
+    }
+    if (i >= n) return;
+    const float xv = x[i], yv = y[i];
+    const float g = dx ? (dloss ? dloss[i] : 1.0f) : 0.f;
+    if (kind == 0) {
+        const float d = xv - yv;
+        if (loss) loss[i] = d * d;
+        if (dx) dx[i] = 2.0f * d * g;
+    } else {
+        if (loss) loss[i] = fmaxf(xv, 0.f) - xv * yv + log1pf(__expf(-fabsf(xv)));
+        if (dx) dx[i] = (sigmoidf_(xv) - yv) * g;
+    }
+}
+
+// C == 2: softmax(x)[:, 1] = sigmoid(x1 - x0);  C == 1: sigmoid(x)
+__global__ void __launch_bounds__(256) retrieval_scores_kernel(const float* x, float* out, int64_t rows, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    if (C == 2) {
+        const float a = x[2 * i], b = x[2 * i + 1], m = fmaxf(a, b);
+        const float ea = __expf(a - m), eb = __expf(b - m);
+        out[i] = eb / (ea + eb);
+    } else {
+        out[i] = sigmoidf_(x[i]);
+    }
+}
+
 }  // namespace
 
 extern "C" int cb_clip_aggregate_fwd(const float* logits, int32_t n_clips, int64_t bc, int32_t mode, float* out, int32_t* argmax,
@@ -276,6 +330,23 @@ extern "C" int cb_clip_aggregate_bwd(const float* dout, const float* logits, con
     hipLaunchKernelGGL(clip_agg_bwd_kernel, dim3(nblk(bc, 256)), dim3(256), 0, cb_stream(stream), dout, logits, out, argmax, n_clips, bc,
                        mode, dlogits);
     return cb_launch_status("cb_clip_aggregate_bwd");
+}
+
+extern "C" int cb_head_loss(int32_t kind, const float* x, const float* y, float* loss, const float* dloss, float* dx, int64_t n, int32_t group,
+                            float margin, void* stream) {
+    CB_REQUIRE(kind >= 0 && kind <= 2 && x && (loss || dx) && n >= 0, "cb_head_loss: bad arguments");
+    CB_REQUIRE(kind == 2 ? (group >= 2 && n % group == 0) : (y != nullptr), "cb_head_loss: kind %d needs %s", kind, kind == 2 ? "group >= 2 dividing n" : "targets");
+    if (n == 0) return 0;
+    const int64_t work = kind == 2 ? n / group : n;
+    hipLaunchKernelGGL(head_loss_kernel, dim3(nblk(work, 256)), dim3(256), 0, cb_stream(stream), kind, x, y, loss, dloss, dx, n, group, margin);
+    return cb_launch_status("cb_head_loss");
+}
+
+extern "C" int cb_retrieval_scores(const float* logits, float* out, int64_t rows, int32_t C, void* stream) {
+    CB_REQUIRE(logits && out && (C == 1 || C == 2) && rows >= 0, "cb_retrieval_scores: bad arguments (C = 1 or 2)");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(retrieval_scores_kernel, dim3(nblk(rows, 256)), dim3(256), 0, cb_stream(stream), logits, out, rows, C);
+    return cb_launch_status("cb_retrieval_scores");
 }
 
 extern "C" int cb_lse_loss(const float* logits, const int64_t* labels, int32_t n_clips, int32_t B, int32_t C, float* loss,

@@ -1046,6 +1046,30 @@ class _CrossEntropyFn(torch.autograd.Function):
         return dlogits, None
 
 
+class _HeadLossFn(torch.autograd.Function):
+    """Element-wise head losses of the reference through cb_head_loss (reduction "none"): MSE (num_labels == 1), BCE with logits (VQA-style
+    soft targets), sigmoid margin ranking of the retrieval head -- src/modeling/modeling.py:359-381, 431-446, 567-575."""
+    @staticmethod
+    def forward(ctx, logits, targets, kind, group, margin):
+        loss, _ = ops.head_loss(kind, logits, targets, group=group, margin=margin)
+        ctx.save_for_backward(logits, targets)
+        ctx.args = (kind, group, margin)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, targets = ctx.saved_tensors
+        kind, group, margin = ctx.args
+        _, dx = ops.head_loss(kind, logits, targets, want_loss=False, dloss=dloss.contiguous().float(), want_grad=True, group=group, margin=margin)
+        return dx, None, None, None, None
+
+
+def head_loss_none(kind: int, logits: torch.Tensor, targets: Optional[torch.Tensor] = None, group: int = 1, margin: float = 0.0) -> torch.Tensor:
+    lg = (logits if logits.dtype == torch.float32 else logits.float()).contiguous()
+    tg = None if targets is None else targets.to(torch.float32).contiguous()
+    return _HeadLossFn.apply(lg, tg, kind, group, margin)
+
+
 def cross_entropy_none(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     lg = logits if logits.dtype == torch.float32 else logits.float()
     return _CrossEntropyFn.apply(lg, labels.contiguous())
@@ -1089,10 +1113,9 @@ class ClipBertForVideoTextRetrieval(_ClipBertHead):
         if self.config.loss_type == "ce":
             loss = cross_entropy_none(logits.view(-1, self.config.num_labels), labels.view(-1))
         elif self.config.loss_type == "rank":
-            # a handful of scalars (B' values): sigmoid margin ranking, modeling.py:567-575
+            # sigmoid margin ranking, modeling.py:567-575: rows of (1 positive + negatives) scores per video
             assert sample_size > 0
-            scores = torch.sigmoid(logits).squeeze().contiguous().view(sample_size, -1)
-            loss = torch.clamp(self.margin + scores[:, 1:] - scores[:, :1], min=0)
+            loss = head_loss_none(ops.LOSS_RANK, logits.reshape(sample_size, -1), group=logits.numel() // sample_size, margin=self.margin)
         else:
             raise ValueError("Invalid option for config.loss_type")
         return logits, loss
@@ -1116,9 +1139,9 @@ class ClipBertForMultipleChoice(_ClipBertHead):
         if labels is None:
             return logits, 0
         if self.config.num_labels == 1:
-            loss = (logits.view(-1) - labels.view(-1)) ** 2
+            loss = head_loss_none(ops.LOSS_MSE, logits.reshape(-1), labels.reshape(-1))
         elif self.config.loss_type == "bce":
-            loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, labels, reduction="none")
+            loss = head_loss_none(ops.LOSS_BCE, logits, labels)
         elif self.config.loss_type == "ce":
             loss = cross_entropy_none(logits.contiguous(), labels.view(-1))
         else:
@@ -1142,9 +1165,9 @@ class ClipBertForSequenceClassification(_ClipBertHead):
         if labels is None:
             return logits, 0
         if self.config.num_labels == 1:
-            loss = (logits.view(-1) - labels.view(-1)) ** 2
+            loss = head_loss_none(ops.LOSS_MSE, logits.reshape(-1), labels.reshape(-1))
         elif self.config.loss_type == "bce":
-            loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, labels, reduction="none")
+            loss = head_loss_none(ops.LOSS_BCE, logits, labels)
         elif self.config.loss_type == "ce":
             loss = cross_entropy_none(logits.view(-1, self.config.num_labels), labels.view(-1))
         else:
@@ -1208,7 +1231,7 @@ class ClipBertForRegression(_ClipBertHead):
         if labels is None:
             return logits, 0
         if self.config.loss_type == "mse":
-            return logits, (logits.view(-1) - labels.view(-1).to(logits.dtype)) ** 2
+            return logits, head_loss_none(ops.LOSS_MSE, logits.reshape(-1), labels.reshape(-1))
         raise ValueError(f"Invalid option {self.config.loss_type} for config.loss_type")
 
 

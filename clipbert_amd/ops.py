@@ -381,6 +381,33 @@ def cross_entropy(logits, labels, want_loss=True, dloss=None, want_grad=False, i
     return loss, dlogits
 
 
+LOSS_MSE, LOSS_BCE, LOSS_RANK = 0, 1, 2
+
+
+def head_loss(kind: int, x, y=None, want_loss=True, dloss=None, want_grad=False, group=1, margin=0.0):
+    """cb_head_loss on contiguous fp32 logits: (loss, dx).  kind LOSS_RANK: x (rows, group), loss (rows, group - 1)."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and (y is None or (y.dtype == torch.float32 and y.is_contiguous() and y.numel() == x.numel()))
+    n = x.numel()
+    if kind == LOSS_RANK:
+        lshape = (n // group, group - 1)
+    else:
+        lshape = tuple(x.shape)
+    loss = torch.empty(lshape, dtype=torch.float32, device=x.device) if want_loss else None
+    dx = torch.empty_like(x) if want_grad else None
+    _chk(_lib.get().cb_head_loss(kind, _ptr(x), _ptr(y), _ptr(loss), _ptr(dloss), _ptr(dx), n, group, float(margin), _stream(x)), "cb_head_loss")
+    return loss, dx
+
+
+def retrieval_scores(logits) -> torch.Tensor:
+    """(rows, 2) -> softmax[:, 1]; (rows, 1) or (rows,) -> sigmoid; fp32"""
+    assert logits.dtype == torch.float32 and logits.is_contiguous()
+    c = logits.shape[1] if logits.dim() == 2 else 1
+    rows = logits.numel() // c
+    out = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    _chk(_lib.get().cb_retrieval_scores(_ptr(logits), _ptr(out), rows, c, _stream(logits)), "cb_retrieval_scores")
+    return out
+
+
 def colsum(g, out, m=None, n=None, ldg=None):
     """out[n] += sum_m g[m, n] (fp32 atomics)."""
     m = g.shape[0] if m is None else m

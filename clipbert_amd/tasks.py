@@ -190,7 +190,7 @@ def validate_retrieval(model, val_loader, eval_videos, cfg, gt_txt_id2vid_id=Non
         if logits.shape[1] == 2:
             n_correct += int((logits.max(dim=-1)[1] == targets).sum().item())
         else:                                                  # rank loss: first score of each group is the positive (:244-250)
-            pred = (torch.sigmoid(logits) > 0.5).long().view(out["loss"].shape[0], -1)
+            pred = (logits > 0).long().view(out["loss"].shape[0], -1)          # sigmoid(x) > 0.5  <=>  x > 0
             n_correct += int((pred[:, 0] == targets.view(out["loss"].shape[0], -1)[:, 0]).sum().item())
     loss, n_ex, n_correct = _all_sum(loss, group), _all_sum(n_ex, group), _all_sum(n_correct, group)
     _rows, metrics = inference_retrieval(model, eval_videos, cfg, gt_txt_id2vid_id, group=group)

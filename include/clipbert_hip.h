@@ -294,6 +294,16 @@ int cb_clip_aggregate_bwd(const float* dout, const float* logits, const float* o
  * clip-major logits [n_clips][B][C]; `dlogits` (optional) receives dloss[b] (1 if null) times its gradient. */
 int cb_lse_loss(const float* logits, const int64_t* labels, int32_t n_clips, int32_t B, int32_t C, float* loss, const float* dloss,
                 float* dlogits, void* stream);
+/* Element-wise head losses on fp32 logits, forward and / or backward (reduction = "none" like the reference's):
+ *   kind 0  MSELoss, num_labels == 1 (src/modeling/modeling.py:364-368, 436-440):  loss = (x - y)^2
+ *   kind 1  instance_bce_with_logits(reduction="none") (:308-315, 370-372):          loss = max(x, 0) - x*y + log1p(exp(-|x|))
+ *   kind 2  sigmoid margin ranking of the retrieval head (:567-575): x is (rows, group) with the positive first;
+ *           loss (rows, group-1) = max(0, margin + sigmoid(x[:, 1:]) - sigmoid(x[:, :1]));  y unused
+ * n = number of logits.  loss / dx may be null (forward only / backward only); dx = dloss (1 if null) times the gradient. */
+int cb_head_loss(int32_t kind, const float* x, const float* y, float* loss, const float* dloss, float* dx, int64_t n, int32_t group,
+                 float margin, void* stream);
+/* Retrieval scores of the inference loop (src/tasks/run_video_retrieval.py:681-690): C == 2: softmax(logits)[:, 1]; C == 1: sigmoid. */
+int cb_retrieval_scores(const float* logits, float* out, int64_t rows, int32_t C, void* stream);
 /* Mean of n per-example losses (the runners' loss.mean(), run_video_retrieval.py:422) and its backward
  * dx[i] = *dmean / n; `*counter += inc` on a device word (the dropout seed word a captured step advances). */
 int cb_mean_fwd(const float* x, int64_t n, float* out, void* stream);
@@ -328,7 +338,8 @@ int cb_elu_bn1d_bwd(int32_t dtype, const void* dy, const void* x, const float* g
                     void* dx, float* dgamma, float* dbeta, int32_t B, int32_t D, int32_t training, void* stream);
 
 const char* cb_last_error(void);
-/* ABI version: 1 = round 1-2; 2 = CB_HP_SKIP / CB_HP_COUNT 10 (cb_adamw*), cb_gemm_group, cb_gemm_workspace_bytes */
+/* ABI version: 1 = round 1-2; 2 = CB_HP_SKIP / CB_HP_COUNT 10 (cb_adamw*), cb_gemm_group, cb_gemm_workspace_bytes;
+ * 3 = cb_gemm_desc.tile = 8 (the streaming structure; every earlier descriptor means what it meant), cb_head_loss, cb_retrieval_scores */
 int cb_version(void);
 
 /* ---- gradient exchange (one process per GPU, RCCL over xGMI) ----------------------------------------------------

@@ -363,3 +363,45 @@ def test_zero_fill_touches_exactly_its_range(hw, off, n):
     g = ones(1000)
     ops.zero_(g[64:512])
     assert float(g.sum()) == 1000 - 448 and float(g[64:512].abs().sum()) == 0.0
+
+
+def test_head_losses_and_retrieval_scores_against_the_oracle(hw):
+    """cb_head_loss (MSE / BCE-with-logits / sigmoid margin ranking, forward + backward) and cb_retrieval_scores against the ORACLE's
+    restatement of the reference's heads (oracle/clipbert_oracle.py: retrieval_loss, sequence_classification_forward; pinned to
+    src/modeling/modeling.py by tests/test_oracle_vs_reference.py) with autograd through it."""
+    from clipbert_amd import clips
+    from clipbert_amd import modeling as M
+    # sigmoid margin ranking: 5 videos x (1 positive + 3 negatives)
+    x = rnd(5, 4, seed=1, scale=2.0)
+    xr = x.detach().cpu().clone().requires_grad_(True)
+    cfg = dict(loss_type="rank", margin=0.3, num_labels=1)
+    want = O.retrieval_loss(xr.view(-1, 1), torch.zeros(20, dtype=torch.long), cfg, sample_size=5)
+    up = rnd(5, 3, seed=2).abs()
+    (want * up.cpu()).sum().backward()
+    xg = x.clone().requires_grad_(True)
+    got = M.head_loss_none(ops.LOSS_RANK, xg, group=4, margin=0.3)
+    (got * up).sum().backward()
+    torch.testing.assert_close(got.detach().cpu(), want.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(xg.grad.cpu(), xr.grad.view(5, 4), rtol=1e-5, atol=1e-6)
+    assert (got == 0).any() and (got > 0).any()                        # both sides of the clamp are exercised
+    # BCE with logits on soft targets, MSE
+    lg, tg = rnd(7, 11, seed=3, scale=3.0), rnd(7, 11, seed=4).sigmoid()
+    for kind, ref in ((ops.LOSS_BCE, lambda a, b: F.binary_cross_entropy_with_logits(a, b, reduction="none")),
+                      (ops.LOSS_MSE, lambda a, b: F.mse_loss(a, b, reduction="none"))):
+        a = lg.detach().cpu().clone().requires_grad_(True)
+        w = ref(a, tg.cpu())
+        up2 = rnd(7, 11, seed=5)
+        (w * up2.cpu()).sum().backward()
+        b = lg.clone().requires_grad_(True)
+        g = M.head_loss_none(kind, b, tg)
+        (g * up2).sum().backward()
+        torch.testing.assert_close(g.detach().cpu(), w.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(b.grad.cpu(), a.grad, rtol=1e-5, atol=1e-6)
+    # extreme logits: the BCE stays finite (log1p(exp(-|x|)) form)
+    big = torch.tensor([[80.0, -80.0, 0.0]], device=DEV[0])
+    l, _ = ops.head_loss(ops.LOSS_BCE, big, torch.tensor([[0.0, 1.0, 0.5]], device=DEV[0]))
+    torch.testing.assert_close(l.cpu(), torch.tensor([[80.0, 80.0, 0.6931472]]), rtol=1e-6, atol=1e-6)
+    # inference scores (run_video_retrieval.py:681-690), rounded to 4 places by the caller
+    two, one = rnd(9, 2, seed=6, scale=2.0), rnd(9, 1, seed=7, scale=2.0)
+    assert clips.retrieval_scores(two) == [round(v, 4) for v in torch.softmax(two.cpu(), 1)[:, 1].tolist()]
+    assert clips.retrieval_scores(one) == [round(v, 4) for v in torch.sigmoid(one.cpu()).view(-1).tolist()]

@@ -653,33 +653,6 @@ def main():
     final_loss = float(loss.item()) if loss is not None else None
     log(f"timed region done: {ms_per_step:.3f} ms/step, {value:.1f} clips/s")
 
-    # Exposed communication of the plan (N > 1, after the timed region, never part of `value`): the same plan with every collective
-    # muted (GradSync.mute: casts, bucket bookkeeping, graphs, bf16-direct AdamW all stay), timed the same way; the difference is the
-    # link time the plan failed to hide.  The ranks' parameters diverge from here on -- nothing after this uses them.
-    exposed = None
-    if train and world > 1 and sync is not None and sync.active and not sync.dry and os.environ.get("CB_BENCH_EXPOSED", "1") != "0":
-        try:
-            sync.mute = True
-            if recapture_dp is not None:
-                recapture_dp()
-            for _ in range(3):
-                run()
-            dist.barrier()
-            torch.cuda.synchronize()
-            m0 = time.perf_counter()
-            for _ in range(args.steps):
-                run()
-            torch.cuda.synchronize()
-            dist.barrier()
-            muted = torch.tensor([time.perf_counter() - m0], dtype=torch.float64, device=dev)
-            dist.all_reduce(muted, op=dist.ReduceOp.MAX)
-            muted_ms = float(muted.item()) / args.steps * 1e3
-            exposed = {"ms_per_step_collectives_muted": round(muted_ms, 3), "exposed_comm_ms": round(ms_per_step - muted_ms, 3),
-                       "exposed_comm_frac_of_step": round((ms_per_step - muted_ms) / ms_per_step, 4)}
-            log(f"same plan with the collectives muted: {muted_ms:.3f} ms/step -> exposed communication {ms_per_step - muted_ms:.3f} ms")
-        except Exception as e:                                  # noqa: BLE001  (a diagnostic must never cost the measurement)
-            exposed = {"error": repr(e)[:200]}
-
     pairs = bv * rep * nclip
     if args.mode == "train" and not args.forward_only:
         metric = "clips/sec/node (2×2 frames, 224px, L_txt=32) at 1/2/4/8 MI355X"
@@ -717,8 +690,6 @@ def main():
     if world > 1:
         out["config"]["attempt"] = int(os.environ.get("CB_BENCH_ATTEMPT", "0"))
         out["config"]["attempt_env"] = ATTEMPTS[out["config"]["attempt"]] if os.environ.get("CB_BENCH_WORKER") == "1" else "launcher-pinned"
-    if exposed is not None:
-        out["config"]["exposed_comm"] = exposed
     if train and world > 1:
         out["config"]["rccl"] = rccl_summary()
     if train and sync is not None and sync.active and not sync.dry:
@@ -727,6 +698,46 @@ def main():
         out["config"]["grad_exchange"] = f"{sync.carrier} ({('cb_reduce_scatter_bucket / cb_allgather_bucket' if sync.shard else 'cb_allreduce_bucket') + ': RCCL behind the C ABI' if sync.carrier == 'native' else 'torch.distributed ' + backend}), bf16 wire, 64 MiB buckets"
     if gathered is not None:
         out["config"]["rows_gathered"] = len(gathered)
+    # Exposed communication of the plan (N > 1, after the timed region, never part of `value`): the same plan with every collective
+    # muted (GradSync.mute: casts, bucket bookkeeping, graphs, bf16-direct AdamW all stay), timed the same way; the difference is the
+    # link time the plan failed to hide.  The ranks' parameters diverge from here on -- nothing after this uses them.  The measured
+    # line is COMPLETE before this starts: if the diagnostic hangs (it re-captures the step), a watchdog prints the line without it,
+    # marks the attempt done and exits -- a diagnostic must never cost the measurement.
+    if train and world > 1 and sync is not None and sync.active and not sync.dry and os.environ.get("CB_BENCH_EXPOSED", "1") != "0":
+        import threading
+
+        def bail():
+            out["config"]["exposed_comm"] = {"error": "the muted-collectives run did not finish in time"}
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            if os.environ.get("CB_BENCH_JOB"):
+                _touch(_marker(os.environ["CB_BENCH_JOB"], int(os.environ.get("CB_BENCH_ATTEMPT", "0")), f"r{rank}.done"))
+            os._exit(0)
+        timer = threading.Timer(float(os.environ.get("CB_BENCH_EXPOSED_DEADLINE", "120")), bail)
+        timer.daemon = True
+        timer.start()
+        try:
+            sync.mute = True
+            if recapture_dp is not None:
+                recapture_dp()
+            for _ in range(3):
+                run()
+            dist.barrier()
+            torch.cuda.synchronize()
+            m0 = time.perf_counter()
+            for _ in range(args.steps):
+                run()
+            torch.cuda.synchronize()
+            dist.barrier()
+            muted = torch.tensor([time.perf_counter() - m0], dtype=torch.float64, device=dev)
+            dist.all_reduce(muted, op=dist.ReduceOp.MAX)
+            muted_ms = float(muted.item()) / args.steps * 1e3
+            out["config"]["exposed_comm"] = {"ms_per_step_collectives_muted": round(muted_ms, 3), "exposed_comm_ms": round(ms_per_step - muted_ms, 3),
+                                             "exposed_comm_frac_of_step": round((ms_per_step - muted_ms) / ms_per_step, 4)}
+            log(f"same plan with the collectives muted: {muted_ms:.3f} ms/step -> exposed communication {ms_per_step - muted_ms:.3f} ms")
+        except Exception as e:                                  # noqa: BLE001
+            out["config"]["exposed_comm"] = {"error": repr(e)[:200]}
+        timer.cancel()
     if rank == 0 and world == 1 and not args.no_roofline:
         default_shape = args.mode == "train" and (nclip, T, args.size, args.txt_len, bv, rep) == (2, 2, 224, 32, 16, 2) and not args.forward_only
         out["roofline"] = measure_roofline(eager_fn if args.mode != "infer16" else infer_device_step, pmc_ok=default_shape, ms_per_step=ms_per_step)

@@ -200,6 +200,7 @@ class Runtime:
                                                          # clip of a clip loop) draws its own masks; kept in the saved pack
         self.side_stream = None                          # second HIP stream: weight-gradient GEMMs run beside the dgrad chain
         self.group_wgrads = os.environ.get("CB_NO_GROUP_WGRAD") is None     # ResNet weight gradients per stage through cb_gemm_group
+        self.group_fwd_pairs = os.environ.get("CB_GROUP_FWD_PAIRS", "0") == "1"   # shortcut + conv1 of the strided stage entries in one launch (opt-in until measured)
         self._side_refs = []
 
     def side(self, *tensors):
@@ -254,7 +255,9 @@ def _pick_split(mo, no, kred):
 # =================================================================================================
 # CNN trunk: explicit forward / backward
 # =================================================================================================
-def _conv_fwd(rt: Runtime, x, conv, act=ACT_NONE, residual=None, relu_after=False):
+def _conv_fwd(rt: Runtime, x, conv, act=ACT_NONE, residual=None, relu_after=False, pending=None):
+    """``pending`` (a list): the launch is only DESCRIBED and appended; the caller hands independent convolutions of one input to
+    cb_gemm_group together (projection shortcut + conv1 of a stage-entry block)."""
     n, h, w, cin = x.shape
     k, s, p = conv.k, conv.stride, conv.pad
     oh, ow = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
@@ -264,14 +267,15 @@ def _conv_fwd(rt: Runtime, x, conv, act=ACT_NONE, residual=None, relu_after=Fals
     wk = rt.bank.compute(conv.weight).view(cout, k * k * cin)
     scale, shift = conv.scale_shift()
     res2d = residual.view(m, cout) if residual is not None else None
+    run = ops.gemm if pending is None else (lambda *a, **kw: pending.append(ops.gemm_desc(*a, **kw)))
     if k == 1 and s == 1:
-        ops.gemm(x.view(m, cin), wk, m, cout, cin, out=y.view(m, cout), scale=scale, shift=shift, act=act,
-                 residual=res2d, relu_after=relu_after)
+        run(x.view(m, cin), wk, m, cout, cin, out=y.view(m, cout), scale=scale, shift=shift, act=act,
+            residual=res2d, relu_after=relu_after)
     else:
         tab = rt.table(n, oh, ow, s, p, h * w * cin, w * cin, cin, x.device)
-        ops.gemm(x, wk, m, cout, k * k * cin, out=y.view(m, cout), a_mode=ROWK_GATHER, a_tab=tab, lda=0,
-                 ldb=k * k * cin, R=k, S=k, Cin=cin, H=h, W=w, sH=w * cin, sW=cin, scale=scale, shift=shift, act=act,
-                 residual=res2d, relu_after=relu_after)
+        run(x, wk, m, cout, k * k * cin, out=y.view(m, cout), a_mode=ROWK_GATHER, a_tab=tab, lda=0,
+            ldb=k * k * cin, R=k, S=k, Cin=cin, H=h, W=w, sH=w * cin, sW=cin, scale=scale, shift=shift, act=act,
+            residual=res2d, relu_after=relu_after)
     return y
 
 
@@ -380,8 +384,16 @@ def cnn_forward(bb: "GridFeatBackbone", x5: torch.Tensor, save: bool):
     saved = []
     for name, _nb, _mid, _cout, _s in RESNET50_STAGES:
         for blk in getattr(net, name):
-            sc = _conv_fwd(rt, x, blk.shortcut) if blk.shortcut is not None else x
-            y1 = _conv_fwd(rt, x, blk.conv1, act=ACT_RELU)
+            if blk.shortcut is not None and blk.conv1.stride > 1 and rt.group_fwd_pairs:
+                # stage entry with a stride: projection shortcut and conv1 read the same strided pixels -- one grouped launch
+                # (the stride-1 entry of res2 stays two launches: its shortcut is a streaming-kernel shape, cb_gemm tile 8)
+                pair = []
+                sc = _conv_fwd(rt, x, blk.shortcut, pending=pair)
+                y1 = _conv_fwd(rt, x, blk.conv1, act=ACT_RELU, pending=pair)
+                ops.gemm_group(pair, x)
+            else:
+                sc = _conv_fwd(rt, x, blk.shortcut) if blk.shortcut is not None else x
+                y1 = _conv_fwd(rt, x, blk.conv1, act=ACT_RELU)
             y2 = _conv_fwd(rt, y1, blk.conv2, act=ACT_RELU)
             out = _conv_fwd(rt, y2, blk.conv3, residual=sc, relu_after=True)
             if save and _block_trainable(rt, blk):

@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(256) visual_embed_fwd_kernel(const T* grid, co
 // (a slice of) the batch: the position / token-type / row / column sums accumulate in registers and reach memory as ONE
 // atomic per block and element (the naive one-atomic-per-token form serialises B*L updates on the same few rows: 120 us
 // for the 32x32-token bench batch).  Word rows still take one atomic per token (distinct rows, little contention).
-constexpr int EMB_BSLICES = 16;     // batch slices per token position: 4 left 128 (text) / 36 (visual) workgroups walking 16 rows of serial atomics each (30 / 21 us)
+constexpr int EMB_BSLICES = 4;      // (16 slices were measured in round 4: 2.3x SLOWER -- every extra slice adds a full set of same-address atomics on the position / type rows)
 
 template <typename T>
 __global__ void __launch_bounds__(256) text_embed_bwd_kernel(const T* dpre, const int64_t* ids, float* dword, float* dpos,

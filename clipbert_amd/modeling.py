@@ -200,7 +200,7 @@ class Runtime:
                                                          # clip of a clip loop) draws its own masks; kept in the saved pack
         self.side_stream = None                          # second HIP stream: weight-gradient GEMMs run beside the dgrad chain
         self.group_wgrads = os.environ.get("CB_NO_GROUP_WGRAD") is None     # ResNet weight gradients per stage through cb_gemm_group
-        self.group_fwd_pairs = os.environ.get("CB_GROUP_FWD_PAIRS", "0") == "1"   # shortcut + conv1 of the strided stage entries in one launch (opt-in until measured)
+        self.group_fwd_pairs = os.environ.get("CB_GROUP_FWD_PAIRS", "0") == "1"   # shortcut + conv1 of the strided stage entries in one launch: measured SLOWER (profiles/r04f: +0.1 ms; the grouped gather kernel runs the pair in 106 us against 47 + 24 apart) -- kept as a switch
         self._side_refs = []
 
     def side(self, *tensors):

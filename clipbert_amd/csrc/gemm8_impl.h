@@ -194,7 +194,10 @@ template <int ROWS, int KMODE> struct KrowDma8 {
 // 8 consecutive columns of one row (16-byte, line-contiguous global accesses), then either the full cb_gemm epilogue (epilogue8)
 // or -- K-split partial products -- plain fp32 stores into this split's slab of the workspace.
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, int SMEM_BYTES, int PR = 64>
+// RAW (the persistent kernel, round 4): the staging passes synchronise with s_waitcnt lgkmcnt(0) + a raw s_barrier instead of
+// __syncthreads() -- whose workgroup-scope fence, with LDS-DMA transfers of the NEXT tile in flight, compiles to s_waitcnt vmcnt(0):
+// every pass then waited for the whole prefetch and for the previous pass's stores (the reason the persistent variant lost in round 3).
+template <int BM, int BN, int WGM, int WGN, int SMEM_BYTES, int PR = 64, bool RAW = false>
 __device__ __forceinline__ void tile_epilogue8w(GP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], unsigned char* smem, int m0, int n0,
                                                 int tid, float* slab) {
     using T = bf16;
@@ -214,7 +217,7 @@ __device__ __forceinline__ void tile_epilogue8w(GP& p, f32x4 (&acc)[BM / WGM / 1
     }
 #pragma unroll
     for (int h = 0; h < BM / PR; ++h) {
-        __syncthreads();
+        if constexpr (RAW) { CB_LDS_BARRIER(); } else { __syncthreads(); }
         if (wm == (h * PR) / WM) {
             const int i0 = ((h * PR) % WM) / 16;
 #pragma unroll
@@ -223,7 +226,7 @@ __device__ __forceinline__ void tile_epilogue8w(GP& p, f32x4 (&acc)[BM / WGM / 1
                 for (int j = 0; j < FN; ++j)
                     *reinterpret_cast<f32x4*>(smem + (i * 16 + (lane & 15)) * SROW + (wn * WN + j * 16 + 4 * (lane >> 4)) * 4) = acc[i0 + i][j];
         }
-        __syncthreads();
+        if constexpr (RAW) { CB_LDS_BARRIER(); } else { __syncthreads(); }
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int rl = (tid + it * NT8) / CPR;
@@ -579,7 +582,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm8p_kernel(GP p0, float* ws) {
                 if (s < nt) issue_tile(ring(stage0 + s));
         }
         if (nt_e > 0 || slab_e)
-            tile_epilogue8w<BM, BN, WGM, WGN, STAGE, EPR>(pe, acc, smem + last * STAGE, m0e, n0e, tid, slab_e);
+            tile_epilogue8w<BM, BN, WGM, WGN, STAGE, EPR, true>(pe, acc, smem + last * STAGE, m0e, n0e, tid, slab_e);
         if (!more) return;
         lin = nxt;
         first = false;

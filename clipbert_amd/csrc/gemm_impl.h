@@ -1294,6 +1294,11 @@ __device__ __forceinline__ void dma16(rsrc_t rs, unsigned char* lds_wave_base, u
 // s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields left at "no wait")
 #define CB_WAIT_VMCNT(N) __builtin_amdgcn_s_waitcnt((((N) & 15) | (7 << 4) | (15 << 8) | ((((N) >> 4) & 3) << 14)))
 
+// LDS-only synchronisation of a workgroup: this wave's ds_* have completed (lgkmcnt(0); vmcnt / expcnt fields left at "no wait"), then
+// the barrier.  The empty asm statements keep the COMPILER from moving memory accesses across it (the barrier intrinsic alone is not a
+// memory operation to LLVM).
+#define CB_LDS_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
 // ROWK image [rows][128 B], 16-byte segment s of row r stored at segment s ^ (r & 7)  (same image as RowkFast)
 template <int ROWS, bool GATHER> struct RowkDma {
     using X = Tr<bf16>;

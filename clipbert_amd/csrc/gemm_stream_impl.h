@@ -29,11 +29,6 @@
 
 namespace cbgemm {
 
-// LDS-only synchronisation of a workgroup: this wave's ds_* have completed (lgkmcnt(0); vmcnt / expcnt fields left at "no wait"), then
-// the barrier.  The empty asm statements keep the COMPILER from moving memory accesses across it (the barrier intrinsic alone is not a
-// memory operation to LLVM).
-#define CB_LDS_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-
 // EPI (compile-time: the prefetch registers exist only where used): 0 = the epilogue reads no M x N operand, 1 = it reads the residual
 template <int BM, int BN, int KT, int OCC, int EPI>
 __global__ void __launch_bounds__(256, OCC) gemm_stream_kernel(GP p) {

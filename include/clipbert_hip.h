@@ -127,7 +127,8 @@ int cb_gemm(const cb_gemm_desc* d, void* stream);
 /* What cb_gemm would launch for `d` (same validation, nothing launched; the operand pointers are only checked for alignment):
  * out4 = {tile, split_k, schedule, xcd_order} as the descriptor fields of those names.  d->tile / xcd_order / schedule == 0 (auto) are
  * resolved by the per-shape table measured on MI355X (csrc/gemm_tuned.h; use_table != 0) and, for shapes outside it, by the launch-cost
- * model fitted to the same sweeps (csrc/gemm_model.h, tools/fit_gemm_model.py).  For tools and tests. */
+ * model fitted to the same sweeps (csrc/gemm_model.h, tools/fit_gemm_model.py).  tile 8 (the streaming structure, taken by itself only
+ * with use_table != 0): out4 = {8, 1, instantiation, 2}.  For tools and tests. */
 int cb_gemm_plan(const cb_gemm_desc* d, int32_t use_table, int32_t* out4);
 /* Bytes of K-split scratch (cb_gemm_desc.splitk_ws) cb_gemm would use for `d` at most -- what it picks when the workspace is not the
  * constraint; 0 when the problem runs unsplit or through atomics.  A caller sizes ONE buffer by the maximum over the problems it will

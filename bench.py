@@ -201,13 +201,13 @@ def supervise(args):
 
 
 def main():
-    import faulthandler
-    faulthandler.enable()
-    faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)
     args = parse()
     rc = supervise(args)
     if rc is not None:
         sys.exit(rc)
+    import faulthandler
+    faulthandler.enable()
+    faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

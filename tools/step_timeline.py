@@ -23,10 +23,17 @@ def load(path):
 def main():
     rows = load(sys.argv[1])
     full = "--full" in sys.argv
-    # one step = from the kernel after an adamw group to the end of the next adamw group
-    idx = [i for i, r in enumerate(rows) if "adamw_kernel" in r["Kernel_Name"]]
-    ends = [i for k, i in enumerate(idx) if k + 1 == len(idx) or idx[k + 1] != i + 1]
-    a, b = ends[-2] + 1, ends[-1] + 1
+    # one step = from the kernel after an optimizer group to the end of the next one; like tools/trace_summary.py the step BEFORE the
+    # last optimizer group of the trace is taken (when the roofline replays follow the timed region, the last group belongs to their
+    # eager, un-captured step)
+    ad = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
+    groups = []
+    for i in ad:
+        if not groups or i - groups[-1][-1] > 50:
+            groups.append([i])
+        else:
+            groups[-1].append(i)
+    a, b = groups[-3][-1] + 1, groups[-2][-1] + 1
     step = rows[a:b]
     t0 = int(step[0]["Start_Timestamp"])
     phase, phases = "resnet fwd", {}

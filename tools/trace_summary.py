@@ -14,12 +14,11 @@ def gemm_name(n):
         g = gemm_name(n.replace("gemm_group_kernel", "gemm_kernel"))
         return g.replace("cb_gemm ", "cb_gemm_group ", 1) if g else "cb_gemm_group"
     if "gemm_stream_kernel" in n:                       # streaming structure: <BM, BN, KT, B mode (-1 ROWK = forward, else data gradient), OCC, EPI>
-        m = re.search(r"gemm_stream_kernel<(\d+), (\d+), (\d+), (-?\d+), \d+, (\d+)>", n) or re.search(r"gemm_stream_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(n?\d+)ELi\d+ELi(\d+)E", n)
+        m = re.search(r"gemm_stream_kernel<(\d+), (\d+), (\d+), \d+, (\d+)>", n) or re.search(r"gemm_stream_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi\d+ELi(\d+)E", n)
         if not m:
             return "cb_gemm streaming"
-        bm, bn, kt, bmode, epi = m.groups()
-        form = "fwd 1x1 conv" if bmode in ("-1", "n1") else "dgrad 1x1 conv"
-        return f"cb_gemm streaming {bm}x{bn} K<={int(kt) * 64} bf16 (persistent, weights resident): {form}" + ("" if epi == "0" else f" (epilogue operands {epi})")
+        bm, bn, kt, epi = m.groups()
+        return f"cb_gemm streaming {bm}x{bn} K<={int(kt) * 64} bf16 (persistent, weights resident): fwd 1x1 conv" + ("" if epi == "0" else " + residual")
     if "splitk_reduce_kernel" in n:
         return "cb_gemm split-K reduce (slabs -> epilogue)"
     d8 = re.search(r"gemm8_kernel<(\d+), (\d+), \d+, \d+, \d+, (\d), cbgemm::(\w+)<\d+, (\w+)>, cbgemm::(\w+)<\d+, (\w+)>, (\w+)>", n)

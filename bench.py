@@ -118,12 +118,55 @@ def _touch(path):
         fh.write(str(os.getpid()))
 
 
+def _descendants(pid):
+    """every live descendant of ``pid`` (a launcher puts its workers into sessions of their own: killing our child's process group
+    alone would leave a hung worker holding its GPU)"""
+    try:
+        import psutil
+        return [c.pid for c in psutil.Process(pid).children(recursive=True)]
+    except Exception:                                            # noqa: BLE001  (no psutil: walk /proc)
+        kids, todo = [], [pid]
+        while todo:
+            cur = todo.pop()
+            for d in os.listdir("/proc"):
+                if d.isdigit():
+                    try:
+                        with open(f"/proc/{d}/stat") as fh:
+                            ppid = int(fh.read().rsplit(")", 1)[1].split()[1])
+                    except (OSError, ValueError, IndexError):
+                        continue
+                    if ppid == cur:
+                        kids.append(int(d)); todo.append(int(d))
+        return kids
+
+
+def _kill_tree(p):
+    """end attempt ``p`` (a Popen started by _run_attempts, and nothing else): SIGTERM first -- a launcher then takes its workers down
+    itself --, after 10 s SIGKILL to exactly the processes that descend from it"""
+    import signal
+    import subprocess
+    tree = _descendants(p.pid)
+    try:
+        os.killpg(p.pid, signal.SIGTERM)
+    except ProcessLookupError:
+        pass
+    try:
+        p.wait(timeout=10)
+    except subprocess.TimeoutExpired:
+        pass
+    for pid in tree + _descendants(p.pid) + [p.pid]:
+        try:
+            os.kill(pid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError):
+            pass
+    p.wait()
+
+
 def _run_attempts(make_cmd_env, n_attempts, rank, job):
     """Run attempt 0, 1, ... until one finishes: exit code 0, or its done-marker exists (the timed region and the JSON line were
     completed; only the teardown failed).  Under a launcher every rank runs this loop for its own worker: the first supervisor that
     sees its worker fail or time out drops a `failed` marker for the attempt, every other supervisor sees it within a second, kills
     its (by then hung) worker and moves on to the next attempt with it."""
-    import signal
     import subprocess
     rc = 1
     for attempt in range(n_attempts):
@@ -149,11 +192,7 @@ def _run_attempts(make_cmd_env, n_attempts, rank, job):
                 rc = -9
                 break
         if p.poll() is None:
-            try:
-                os.killpg(p.pid, signal.SIGKILL)                             # exactly the process group this function started
-            except ProcessLookupError:
-                pass
-            p.wait()
+            _kill_tree(p)
         ok = rc == 0 or os.path.exists(done)
         if os.path.exists(done):
             os.remove(done)
@@ -200,11 +239,38 @@ def supervise(args):
     return _run_attempts(worker, n_attempts, rank, job)
 
 
+def _stub_worker(args):
+    """TEST HOOK (tests/test_zz_bench_cli.py, CPU): stands in for the measured worker so that the launcher / supervisor / retry path --
+    rendezvous through the launcher's store on attempt 0, through a fresh TCP store on the derived port on a retry, failure markers,
+    done markers -- runs end to end without a GPU.  CB_BENCH_TEST_STUB = "fail0:<rank>" makes that rank fail on attempt 0 (the others
+    then hang in the collective, as real ranks would); "hang0:<rank>" makes it hang instead."""
+    import torch.distributed as dist
+    mode, _, who = os.environ["CB_BENCH_TEST_STUB"].partition(":")
+    rank, world, attempt = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("CB_BENCH_ATTEMPT", "0"))
+    if attempt == 0 and who and rank == int(who):
+        if mode == "fail0":
+            raise SystemExit(7)
+        time.sleep(10000)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    assert float(t) == world * (world + 1) / 2
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"stub": True, "n_gpus": world, "attempt": attempt, "attempt_env": ATTEMPTS[attempt], "plan_env": os.environ.get("CB_BENCH_PLAN", "")}), flush=True)
+    if os.environ.get("CB_BENCH_JOB"):
+        _touch(_marker(os.environ["CB_BENCH_JOB"], attempt, f"r{rank}.done"))
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rc = supervise(args)
     if rc is not None:
         sys.exit(rc)
+    if os.environ.get("CB_BENCH_TEST_STUB"):
+        return _stub_worker(args)
     import faulthandler
     faulthandler.enable()
     faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)

@@ -79,6 +79,36 @@ def test_supervise_is_a_no_op_for_one_gpu_and_for_workers(monkeypatch):
     assert bench.supervise(bench.parse()) is None
 
 
+@pytest.mark.parametrize("launcher", ["none", "torchrun"])
+@pytest.mark.parametrize("stub", ["ok", "fail0:1", "hang0:0"])
+def test_supervised_launch_end_to_end_with_stub_workers(launcher, stub, tmp_path):
+    """The whole N > 1 launch path of bench.py on CPU, with stub workers in place of the measured ones (bench._stub_worker): no launcher
+    (bench starts its own ranks) and under `torch.distributed.run` (every rank process supervises one worker).  Attempt 0 succeeding;
+    one rank failing on attempt 0 (the others hang in the collective until the failure marker reaches their supervisors, then ALL ranks
+    retry together, rendezvousing through a fresh store on the derived port); one rank hanging until the deadline.  Exactly one JSON
+    line comes out, from the attempt that finished."""
+    env = dict(os.environ, CB_BENCH_TEST_STUB=stub, TMPDIR=str(tmp_path), CB_BENCH_ATTEMPT_TIMEOUT="25" if stub.startswith("hang") else "120")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "CB_BENCH_WORKER", "CB_BENCH_PLAN", "CB_COMM", "TORCHELASTIC_USE_AGENT_STORE"):
+        env.pop(k, None)
+    bench_py = os.path.join(ROOT, "bench.py")
+    if launcher == "none":
+        cmd = [sys.executable, bench_py, "--gpus", "2"]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+               str(_free_port()), bench_py, "--gpus", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = lines[0]
+    assert out["stub"] and out["n_gpus"] == 2
+    if stub == "ok":
+        assert out["attempt"] == 0 and out["plan_env"] == ""
+    else:
+        assert out["attempt"] == 1 and out["plan_env"] == "split", out           # the next rung of the ladder, on every rank
+        assert "retrying with" in r.stderr
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -8,18 +8,18 @@
 // flight (~6 KB per resident workgroup) times the ~2.5 us latency is what the kernel streams -- Little's law, not the DRAM.
 //
 // This structure keeps the bytes in flight instead:
-//   * PERSISTENT workgroups (256 threads, <= 2 per CU) walk the M tiles grid-stride; the weights (N x K, <= 64 KiB) are loaded into LDS
+//   * PERSISTENT workgroups (256 threads, <= 2 per CU) walk the M tiles grid-stride; the weights (BN x K, 32 KiB) are loaded into LDS
 //     ONCE per workgroup and stay there;
 //   * the A tile of the NEXT M tile arrives by LDS-DMA (buffer_load ... lds, two stages) while the current one is multiplied and stored;
 //   * the epilogue's M x N operand (the residual) of the current tile is requested into registers BEFORE
 //     the wait for its A tile, all 8 chunks per thread at once: one round trip per tile instead of one per staging pass;
-//   * no __syncthreads() inside the loop: its workgroup-scope fence makes the compiler wait for EVERYTHING in flight, the next tile's
-//     DMA included (vmcnt(0)); the staging passes synchronise with s_waitcnt lgkmcnt(0) + a raw s_barrier (CB_LDS_BARRIER);
+//   * no __syncthreads() inside the loop: with LDS-DMA transfers in flight its workgroup-scope fence compiles to s_waitcnt vmcnt(0)
+//     (seen in the ISA of the first version) -- every staging pass would wait for the next tile's DMA; the staging passes synchronise with s_waitcnt lgkmcnt(0) + a raw s_barrier (CB_LDS_BARRIER);
 //   * one counted wait per tile: s_waitcnt vmcnt(#DMA of the next A tile) -- everything older (this tile's A, its epilogue operands,
 //     the previous tile's stores) has retired, only the newest loads may still fly.  Loads retire in order among loads, so the count
 //     is exact whatever the stores do (a store that is still outstanding only makes the wait longer, never wrong).
-// Each workgroup computes a BM x BN tile with BN = the whole (or half the) row of C: a tile's stores and residual reads are runs of
-// BN * 2 bytes per row over BM consecutive rows -- contiguous 16-32 KiB pieces of DRAM pages.
+// Each workgroup computes a BM x BN tile with BN = the whole row of C (res2: N = 256) or a quarter of it (res3: N = 512): a tile's
+// stores and residual reads are runs of BN * 2 bytes per row over BM consecutive rows.
 //
 // Waves 2 x 2; accumulators pass through a 16-row LDS staging buffer so that every thread owns 8 consecutive columns of a row
 // (16-byte accesses; the same epilogue8 as every other cb_gemm kernel: results are bit-identical to the 4-wave kernels, whose K loop

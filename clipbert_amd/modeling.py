@@ -1005,9 +1005,11 @@ class _LinearFn(torch.autograd.Function):
         gb = bank.grad_image(bias) if bias is not None else None
         if ctx.rows is None:
             if gw is not None:
+                # the bias gradient rides on the weight-gradient launch (row sums of g on the matrix core, cb_gemm_desc.a_rowsum)
                 split, tile = _pick_split(n, k, m)
                 ops.gemm(g, x2, n, k, m, out=gw, a_mode=KROW, lda=g.stride(0), b_mode=KROW, ldb=x2.stride(0), accumulate=True,
-                         split_k=split, tile=tile)
+                         split_k=split, tile=tile, a_rowsum=gb)
+                gb = None
             dx = torch.empty(x2.shape, dtype=dt, device=dy.device)
             ops.gemm(g, bank.compute(weight), m, k, n, out=dx, lda=g.stride(0), b_mode=KROW)
         else:

@@ -113,7 +113,7 @@ def test_supervised_launch_end_to_end_with_stub_workers(launcher, stub, tmp_path
     if stub == "ok":
         assert out["attempt"] == 0 and out["plan_env"] == ""
     else:
-        assert out["attempt"] == 1 and out["plan_env"] == "split", out           # the next rung of the ladder, on every rank
+        assert out["attempt"] in (1, 2) and out["plan_env"] == "split", out      # the next rung of the ladder, on every rank (2: its port was taken)
         assert "retrying with" in r.stderr
 
 

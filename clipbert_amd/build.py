@@ -26,10 +26,18 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def variant_path(variant: str) -> str:
+    return os.path.join(LIB_DIR, f"libclipbert_hip_{variant}.so")
+
+
+def build(force: bool = False, verbose: bool = False, variant: str = "", defines=()) -> str:
+    """variant / defines: a DIAGNOSTIC copy of the library (e.g. variant="stamps", defines=("CB_STAMPS",): in-kernel time stamps,
+    tools/stamps_run.py) in its own object directory; the product library is variant ""."""
     os.makedirs(LIB_DIR, exist_ok=True)
-    obj_dir = os.path.join(LIB_DIR, "obj")
+    obj_dir = os.path.join(LIB_DIR, "obj" + (f"_{variant}" if variant else ""))
     os.makedirs(obj_dir, exist_ok=True)
+    lib_path = variant_path(variant) if variant else LIB_PATH
+    flags = FLAGS + [f"-D{d}" for d in defines]
     headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
     jobs = []
     objs = []
@@ -37,7 +45,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([HIPCC] + flags + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -49,10 +57,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB_PATH, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
-    return LIB_PATH
+    if jobs or force or _stale(lib_path, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs)
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--stamps" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, variant="stamps", defines=("CB_STAMPS",)))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -59,6 +59,48 @@ CB_G8_DECL(256, 128, 4, 2, 3)
 // Shapes outside the table: a launch-cost model fitted to the same sweeps (tools/fit_gemm_model.py) ranks the legal configurations.
 #include "gemm_model.h"
 
+// ---- diagnostic build (-DCB_STAMPS, clipbert_amd/lib/libclipbert_hip_stamps.so; tools/stamps_run.py): every stamped launch gets a
+// record area in a caller-provided device buffer and a host-side description ----------------------------------------------------
+#ifdef CB_STAMPS
+#include <string>
+namespace {
+struct StampState {
+    unsigned long long* buf = nullptr;
+    int64_t areas = 0;
+    std::vector<std::string> desc;
+} g_stamps;
+void stamp_assign(GP& p, const cb_gemm_desc* d, int tile, int split, int sched, int group_i, int group_n) {
+    p.stamps = nullptr;
+    if (!g_stamps.buf || (int64_t)g_stamps.desc.size() >= g_stamps.areas) return;
+    p.stamps = g_stamps.buf + (int64_t)g_stamps.desc.size() * cbgemm::CB_STAMP_AREA;
+    char line[512];
+    snprintf(line, sizeof line,
+             "{\"M\":%d,\"N\":%d,\"K\":%d,\"a_mode\":%d,\"b_mode\":%d,\"batch\":%d,\"tile\":%d,\"split\":%d,\"sched\":%d,\"taps\":%d,"
+             "\"act\":%d,\"c2\":%d,\"residual\":%d,\"dropout\":%d,\"mask\":%d,\"gelu_grad\":%d,\"relu_bwd\":%d,\"c_f32\":%d,\"group_i\":%d,\"group_n\":%d}",
+             d->M, d->N, d->K, d->a_mode, d->b_mode, d->batch > 1 ? d->batch : 1, tile, split, sched, (d->R > 0 ? d->R : 1) * (d->S > 0 ? d->S : 1), d->act,
+             d->C2 != nullptr, d->residual != nullptr, d->dropout_p > 0.f, d->mask != nullptr, d->gelu_grad_pre != nullptr, d->relu_bwd != 0, d->c_f32, group_i, group_n);
+    g_stamps.desc.push_back(line);
+}
+}  // namespace
+// buf: device memory of `bytes` bytes, zero-filled by the caller except word 0 of every area (min start) = ~0; resets the launch list
+extern "C" int cb_debug_stamps_begin(void* buf, int64_t bytes) {
+    g_stamps.buf = reinterpret_cast<unsigned long long*>(buf);
+    g_stamps.areas = buf ? bytes / (8 * (int64_t)cbgemm::CB_STAMP_AREA) : 0;
+    g_stamps.desc.clear();
+    return 0;
+}
+extern "C" int64_t cb_debug_stamps_area_words() { return cbgemm::CB_STAMP_AREA; }
+extern "C" int64_t cb_debug_stamps_count() { return (int64_t)g_stamps.desc.size(); }
+extern "C" int cb_debug_stamps_desc(int64_t i, char* out, int64_t cap) {
+    if (i < 0 || i >= (int64_t)g_stamps.desc.size() || cap <= 0) return -1;
+    snprintf(out, (size_t)cap, "%s", g_stamps.desc[(size_t)i].c_str());
+    return 0;
+}
+#define CB_STAMP_ASSIGN(p, d, tile, split, sched, gi, gn) stamp_assign(p, d, tile, split, sched, gi, gn)
+#else
+#define CB_STAMP_ASSIGN(p, d, tile, split, sched, gi, gn) do {} while (0)
+#endif
+
 namespace {
 
 __global__ void __launch_bounds__(256) pixel_table_kernel(cb_pixel* tab, int total, int OH, int OW, int stride,
@@ -243,6 +285,10 @@ int gemm_prepare(const cb_gemm_desc* d, Prepared& out) {
     p.dropout_p = d->dropout_p; p.seed = d->dropout_seed; p.seed_ptr = d->dropout_seed_ptr;
     const int bk = d->dtype == CB_BF16 ? Tr<bf16>::BK : Tr<float>::BK;
     p.ktiles = (d->K + bk - 1) / bk;
+    {   // write-through epilogue stores (round-5 experiment, tools/r05a_call.sh): CB_GEMM_WT=1
+        static const bool wt = getenv("CB_GEMM_WT") != nullptr && atoi(getenv("CB_GEMM_WT")) != 0;
+        p.wt = wt && d->dtype == CB_BF16 && !d->c_f32 && (int64_t)d->M * (d->ldc > d->ldc2 ? d->ldc : d->ldc2) * 2 * (p.batch) < 0xffffffffll;
+    }
 
     const bool a_krow = d->a_mode == CB_KROW;
     const bool b_krow = d->b_mode == CB_KROW || d->b_mode == CB_KROW_TAPS || d->b_mode == CB_KROW_GATHER;
@@ -394,8 +440,13 @@ int gemm_run(const cb_gemm_desc* d, void* stream, int32_t* plan, bool use_table)
         const int mode8 = d->schedule > 0 ? d->schedule - 1 : (sched_tuned > 0 ? sched_tuned - 1 : mode8_env);
         p.c_vec8 = 1;
         p.xcd_remap = !no_remap && xcd != 2;
+        {   // round-5 experiment (tools/r05a_call.sh): CB_GEMM_RASTER_W=w -> column-panel tile order for the 8-wave kernels
+            static const int rw = getenv("CB_GEMM_RASTER_W") ? atoi(getenv("CB_GEMM_RASTER_W")) : 0;
+            p.raster_w = p.xcd_remap ? rw : 0;
+        }
         if (plan) { plan[0] = tile; plan[1] = p.split_k; plan[2] = mode8 + 1; plan[3] = p.xcd_remap ? 1 : 2; return 0; }
         hipStream_t st8 = cb_stream(stream);
+        CB_STAMP_ASSIGN(p, d, tile, p.split_k, mode8 + 1, 0, 1);
         int rc;
         if (tile == 5) rc = launch8<256, 256, 2, 4, 2>(form8, p, mode8, ws8, st8);
         else if (tile == 6) rc = launch8<128, 256, 2, 4, 3>(form8, p, mode8, ws8, st8);
@@ -443,6 +494,7 @@ int gemm_run(const cb_gemm_desc* d, void* stream, int32_t* plan, bool use_table)
     if (tile == 1 && d->N <= 64) tile = 3;           // narrow outputs (stem / res2 convs): 128x64 tile
     if (tile == 4 && d->N <= 64) tile = 3;
     if (plan) { plan[0] = tile; plan[1] = p.split_k; plan[2] = 0; plan[3] = p.xcd_remap ? 1 : 2; return 0; }
+    CB_STAMP_ASSIGN(p, d, tile, p.split_k, 0, 0, 1);
     if (tile == 4) return launch_gemm<bf16, 128, 128, 1, 2>(p, fast, st);
     if (tile == 1) return launch_gemm<bf16, 128, 128, 2>(p, fast, st);
     if (tile == 3) return launch_gemm<bf16, 128, 64, 2>(p, fast, st);
@@ -559,6 +611,7 @@ int launch_group_chunk(std::vector<GroupItem*>& g, int dtype, int cls, hipStream
         acc += (int64_t)((d->M + B - 1) / B) * ((d->N + B - 1) / B) * p.split_k;
         CB_REQUIRE(acc < (1ll << 30), "cb_gemm_group: too many workgroups");
         ga.tile_end[i] = (int)acc;
+        CB_STAMP_ASSIGN(p, d, tile, p.split_k, 0, (int)i, (int)g.size());
         ga.g[i] = p;
         if (trace) fprintf(stderr, "cb_gemm_group[%zu/%zu]: M=%d N=%d K=%d modes=%d/%d cls=%d tile=%d split=%d\n", i, g.size(), d->M, d->N, d->K, d->a_mode,
                            d->b_mode, cls, tile, p.split_k);

@@ -269,7 +269,12 @@ __global__ void __launch_bounds__(NT8, 2) gemm8_kernel(GP p, float* ws) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
+    CB_STAMP_DECL();
+    CB_STAMP(0);
     TileId bid = tile_id(p);
+#ifdef CB_STAMPS
+    const unsigned stamp_lin = (unsigned)bid.bx + gridDim.x * ((unsigned)bid.by + gridDim.y * (unsigned)bid.bz);
+#endif
     const int zsplit = bid.bz % p.split_k, zbatch = bid.bz / p.split_k;      // (before apply_batch rewrites bz)
     apply_batch(p, bid);
     const int m0 = bid.by * BM, n0 = bid.bx * BN;
@@ -326,6 +331,9 @@ __global__ void __launch_bounds__(NT8, 2) gemm8_kernel(GP p, float* ws) {
             if (nt - 1 - t >= D - 1) { CB_WAIT_VMCNT(LPT * (D - 1)); }
             else { CB_WAIT_VMCNT(0); }
             __builtin_amdgcn_s_barrier();             // every wave's share of tile t landed; everyone is done reading tile t-1
+#ifdef CB_STAMPS
+            if (t == 0) CB_STAMP(1);
+#endif
             if (t + D < nt) {
                 int ns = stage + D;
                 if (ns >= NST) ns -= NST;
@@ -362,6 +370,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm8_kernel(GP p, float* ws) {
         if (nt - 1 >= D - 1) { CB_WAIT_VMCNT(LPT * (D - 1)); }
         else { CB_WAIT_VMCNT(0); }
         __builtin_amdgcn_s_barrier();                     // tile 0 landed
+        CB_STAMP(1);
         if (late) __builtin_amdgcn_s_barrier();
         int stage = 0;
         for (int t = 0; t < nt; ++t) {
@@ -419,7 +428,10 @@ __global__ void __launch_bounds__(NT8, 2) gemm8_kernel(GP p, float* ws) {
             }
         }
     }
+    CB_STAMP(2);
     tile_epilogue8w<BM, BN, WGM, WGN, SMEM_BYTES>(p, acc, smem, m0, n0, tid, slab);
+    CB_STAMP(3);
+    CB_STAMP_FLUSH(p, stamp_lin, tid);
 }
 
 

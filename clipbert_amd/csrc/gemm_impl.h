@@ -40,7 +40,52 @@ struct GP {
     int xcd_remap;              // 1: remap workgroup ids so that each XCD (own L2) owns a contiguous chunk of tiles
     uint32_t a_bytes, b_bytes;
     int ktiles;
+    int raster_w;               // > 0: the XCD-compact tile order walks column panels of this many N tiles (tile_id)
+    int wt;                     // 1: the row-contiguous epilogue's bf16 C / C2 stores are write-through (sc1), see store8_wt
+#ifdef CB_STAMPS
+    unsigned long long* stamps;   // diagnostic build only (tools/stamps_*.py): this launch's record area, or null
+#endif
 };
+
+// ---------------------------------------------------------------------------------------------
+// In-kernel time stamps (diagnostic build -DCB_STAMPS only, never the product library): thread 0 of a workgroup reads the
+// chip-wide 100 MHz counter (s_memrealtime: the same clock on every XCD) at its phase boundaries and writes one record;
+// the launch's header keeps min(start) / max(end) / #workgroups over ALL its workgroups.
+//   area = [min start][max end][workgroups] + CB_STAMP_WGS x [t0 entry][t1 first K tile in LDS][t2 K loop done]
+//          [t3 epilogue issued][t4 stores retired][hw id]
+// ---------------------------------------------------------------------------------------------
+#ifdef CB_STAMPS
+constexpr int CB_STAMP_WGS = 512, CB_STAMP_REC = 6, CB_STAMP_HDR = 3;
+constexpr int CB_STAMP_AREA = CB_STAMP_HDR + CB_STAMP_WGS * CB_STAMP_REC;       // u64 words per launch
+struct Stamps {
+    unsigned long long t[5];
+    __device__ __forceinline__ void mark(int i) { t[i] = __builtin_amdgcn_s_memrealtime(); }
+    __device__ __forceinline__ void flush(unsigned long long* area, unsigned lin, int tid) {
+        if (!area || tid != 0) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t4 = __builtin_amdgcn_s_memrealtime();
+        atomicMin(area, t[0]);
+        atomicMax(area + 1, t4);
+        atomicAdd(area + 2, 1ull);
+        if (lin < (unsigned)CB_STAMP_WGS) {
+            unsigned long long* r = area + CB_STAMP_HDR + (size_t)lin * CB_STAMP_REC;
+            r[0] = t[0]; r[1] = t[1]; r[2] = t[2]; r[3] = t[3]; r[4] = t4;
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            r[5] = ((unsigned long long)xcc << 32) | hw;
+        }
+    }
+};
+#define CB_STAMP_DECL() Stamps stamps_
+#define CB_STAMP(i) stamps_.mark(i)
+#define CB_STAMP_FLUSH(p, lin, tid) stamps_.flush((p).stamps, (lin), (tid))
+#else
+#define CB_STAMP_DECL() do {} while (0)
+#define CB_STAMP(i) do {} while (0)
+#define CB_STAMP_FLUSH(p, lin, tid) do {} while (0)
+#endif
 
 template <typename T> __device__ __forceinline__ u32x4 load_guarded(const T* src, int nvalid) {
     constexpr int EPS = Tr<T>::EPS;
@@ -613,6 +658,24 @@ __device__ __forceinline__ TileId tile_id(const GP& p) {
     const unsigned xcd = lin & 7u, i = lin >> 3;
     const unsigned q = total >> 3, r = total & 7u;
     const unsigned l2 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    const unsigned w = (unsigned)p.raster_w;
+    if (w > 0 && w < gx) {
+        // column panels of w N tiles, M tiles fastest across the panel's rows: an XCD's contiguous run of ~total/8 tiles then covers
+        // ~(total/8/w) A panels x w B panels instead of ~(total/8/gx) x gx -- fewer distinct operand bytes per K tile in its L2
+        const unsigned per_z = gx * gy, z = l2 / per_z, rz = l2 - z * per_z;
+        const unsigned nfull = gx / w, full = nfull * w * gy;
+        if (rz < full) {
+            const unsigned panel = rz / (w * gy), within = rz - panel * (w * gy);
+            t.by = (int)(within / w);
+            t.bx = (int)(panel * w + (within - (unsigned)t.by * w));
+        } else {
+            const unsigned r2 = rz - full, wl = gx - nfull * w;
+            t.by = (int)(r2 / wl);
+            t.bx = (int)(nfull * w + (r2 - (unsigned)t.by * wl));
+        }
+        t.bz = (int)z;
+        return t;
+    }
     t.bx = (int)(l2 % gx);
     const unsigned rest = l2 / gx;
     t.by = (int)(rest % gy);
@@ -746,6 +809,17 @@ __device__ __forceinline__ void store8(bf16* q, const float (&v)[8]) {
     *reinterpret_cast<bf16x8*>(q) = x;
 }
 
+// Write-through form of store8 (bf16): `global_store_dwordx4 ... sc1` through a buffer descriptor over C.  A plain store leaves its line
+// dirty in the XCD's L2 until the end-of-kernel release writes everything back in one burst (MI355X_MICROARCH.md "boundary": + B / 6 TB/s
+// behind B dirty bytes); a write-through store sends the bytes to the memory side while the other workgroups still compute.
+__device__ __forceinline__ void store8_wt(void* base, int64_t elem_off, const float (&v)[8]) {
+    union { bf16x8 x; u32x4 r; } u;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) u.x[r] = (bf16)v[r];
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, (short)0, (int)0xffffffffu, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(u.r, rs, (uint32_t)(elem_off * 2), 0, 16 /* sc1 */);
+}
+
 // Epilogue of 8 consecutive columns n..n+7 of row m (row-contiguous: every global access is a full 16-byte lane
 // access and a wave touches whole cache lines).  sc/sh are the per-column scale/shift the thread loaded once.
 // stride-2 scatter (zero_fill_pitch): the other three pixels of output pixel m's 2x2 input patch receive zeros
@@ -823,7 +897,12 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += sh[r];
     }
-    if (p.C2) store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, v);
+    if (p.C2) {
+        if constexpr (sizeof(T) == 2) {
+            if (p.wt) store8_wt(p.C2, orow * p.ldc2 + n, v);
+            else store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, v);
+        } else store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, v);
+    }
     if (p.act != CB_ACT_NONE) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = apply_act(p.act, v[r]);
@@ -872,7 +951,10 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] += t[r];
         }
-        store8(c, v);
+        if constexpr (sizeof(T) == 2) {
+            if (p.wt) store8_wt(p.C, orow * p.ldc + n, v);
+            else store8(c, v);
+        } else store8(c, v);
     }
     if (p.zfill) {
         if (p.c_f32) zero_patch8(reinterpret_cast<float*>(p.C), p.ldc, orow, n, p.zfill);
@@ -1059,6 +1141,11 @@ __device__ __forceinline__ void gemm_tile(GP& p, TileId bid) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    CB_STAMP_DECL();
+    CB_STAMP(0);
+#ifdef CB_STAMPS
+    const unsigned stamp_lin = (unsigned)bid.bx + (unsigned)((p.N + BN - 1) / BN) * ((unsigned)bid.by + (unsigned)((p.M + BM - 1) / BM) * (unsigned)bid.bz);
+#endif
     apply_batch(p, bid);
     const int m0 = bid.by * BM, n0 = bid.bx * BN;
     const int kt_per = (p.ktiles + p.split_k - 1) / p.split_k;
@@ -1132,6 +1219,7 @@ __device__ __forceinline__ void gemm_tile(GP& p, TileId bid) {
     store_tiles(sa[0], sb[0], 0);
     if (PF < nt) load_tiles_checked(sa[0], sb[0]);
     __syncthreads();
+    CB_STAMP(1);
 
     auto compute_tile = [&](int buf) {
         const unsigned char* As = smem + buf * (TILE_A + TILE_B);
@@ -1230,8 +1318,11 @@ __device__ __forceinline__ void gemm_tile(GP& p, TileId bid) {
             }
         }
     }
+    CB_STAMP(2);
     if constexpr (EPF != 0) tile_epilogue<T, BM, BN, SMEM_BYTES, EPF>(p, acc, smem, m0, n0, tid, epre, epf_on);
     else tile_epilogue<T, BM, BN, SMEM_BYTES>(p, acc, smem, m0, n0, tid);
+    CB_STAMP(3);
+    CB_STAMP_FLUSH(p, stamp_lin, tid);
 }
 
 template <typename T, int BM, int BN, typename LA, typename LB, int PF, bool RS = false, int OCC = 1>

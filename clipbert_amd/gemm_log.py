@@ -38,6 +38,9 @@ def _problem(d) -> dict:
     gather = d.a_mode == ops.ROWK_GATHER or d.b_mode in (ops.KROW_GATHER, ops.KROW_TAPS)
     cnn = bool(d.scale) or bool(d.relu_bwd) or bool(d.a_tab) or bool(d.b_tab) or bool(d.c_rowmap) or d.zero_fill_pitch != 0 or bool(d.post_scale)
     M, N, K = int(d.M), int(d.N), int(d.K)
+    # algorithmic reduction length (SURVEY 8d counts algorithmic flops): the 7x7x3 stem is LAUNCHED on the zero-padded NHWC4 image
+    # with K = 7 rows x (8 taps x 4 channels) = 224, of which 7 x 7 x 3 = 147 products per output are the convolution's
+    K_alg = 147 if (d.a_mode == ops.ROWK_GATHER and int(d.R) == 7 and int(d.Cin) == 32 and K == 224) else K
     # pixel counts of a 224-multiple input are multiples of 49 (7 x 7 at res5); token rows (41 per pair) and head rows are not
     cnn = cnn or (wgrad and K % 49 == 0 and K >= 49) or (not wgrad and M % 49 == 0 and M >= 49 * 16)
     if wgrad:
@@ -53,7 +56,7 @@ def _problem(d) -> dict:
             fam = "encoder linear (fwd + dgrad)"
         extra = sum(1 for p in (d.residual, d.mask, d.C2, d.gelu_grad_pre) if p) + (1 if d.accumulate else 0) + (2 if d.relu_bwd else 0)
         alg = batch * ((M * K / taps + N * K) * esz + M * N * c_esz + extra * M * N * esz)
-    return {"family": fam, "flop": 2.0 * M * N * K * batch, "bytes": float(alg), "M": M, "N": N, "K": K, "batch": batch, "taps": taps,
+    return {"family": fam, "flop": 2.0 * M * N * K_alg * batch, "bytes": float(alg), "M": M, "N": N, "K": K, "batch": batch, "taps": taps,
             "form": "wgrad" if wgrad else ("dgrad" if d.b_mode in (ops.KROW, ops.KROW_TAPS) else "fwd")}
 
 

@@ -222,8 +222,13 @@ static inline emul_u32x4 emul_raw_buffer_load_b128(emul_rsrc r, uint32_t voff, u
     if (o + 16 <= r.n) memcpy(&v, r.base + o, 16);
     return v;
 }
+static inline void emul_raw_buffer_store_b128(emul_u32x4 v, emul_rsrc r, uint32_t voff, uint32_t soff, int) {
+    uint64_t o = (uint64_t)voff + soff;
+    if (o + 16 <= r.n) memcpy(const_cast<unsigned char*>(r.base) + o, &v, 16);       // (out-of-range stores are dropped, as the hardware does)
+}
 #define __builtin_amdgcn_make_buffer_rsrc emul_make_buffer_rsrc
 #define __builtin_amdgcn_raw_buffer_load_b128 emul_raw_buffer_load_b128
+#define __builtin_amdgcn_raw_buffer_store_b128 emul_raw_buffer_store_b128
 
 // LDS-DMA: 16 bytes per lane from the (range-checked) buffer to wave-uniform LDS base + lane*16
 static inline void emul_buffer_load_lds(emul_rsrc r, void* lds_base, unsigned size, uint32_t voff, uint32_t soff, uint32_t, uint32_t) {

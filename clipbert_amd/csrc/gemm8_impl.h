@@ -197,6 +197,11 @@ template <int ROWS, int KMODE> struct KrowDma8 {
 // RAW (the persistent kernel, round 4): the staging passes synchronise with s_waitcnt lgkmcnt(0) + a raw s_barrier instead of
 // __syncthreads() -- whose workgroup-scope fence, with LDS-DMA transfers of the NEXT tile in flight, compiles to s_waitcnt vmcnt(0):
 // every pass then waited for the whole prefetch and for the previous pass's stores (the reason the persistent variant lost in round 3).
+// Code size (round 5, profiles/r05a_stamps.md): the epilogue8 body is ~10 KB of branchy straight-line code (every epilogue option is a
+// wave-uniform runtime branch).  Fully unrolled -- BM / PR passes x ITER chunks = 8 copies -- the epilogue was 78 KB that each workgroup
+// executes ONCE, i.e. entirely out of instruction-cache misses: ~1.1 us per chunk, 9 us for a bias-only 128x256 tile, 17 us for FFN1's
+// GELU + two outputs (longer than its 11 us K loop).  The pass loop and the chunk loop are therefore ROLLED: one copy of the body, warm
+// after its first trip.  Only the accumulator -> LDS staging needs compile-time register indices: a switch over the WM / PR row blocks.
 template <int BM, int BN, int WGM, int WGN, int SMEM_BYTES, int PR = 64, bool RAW = false>
 __device__ __forceinline__ void tile_epilogue8w(GP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], unsigned char* smem, int m0, int n0,
                                                 int tid, float* slab) {
@@ -204,6 +209,7 @@ __device__ __forceinline__ void tile_epilogue8w(GP& p, f32x4 (&acc)[BM / WGM / 1
     constexpr int WM = BM / WGM, WN = BN / WGN, FN = WN / 16;   // PR: tile rows per pass through the staging area
     constexpr int SROW = BN * 4 + 16;
     constexpr int CPR = BN / 8, ITER = PR * CPR / NT8;
+    constexpr int NPASS = BM / PR, SUB = WM / PR;              // passes; passes per wave row block
     static_assert(WM % PR == 0 && PR * SROW <= SMEM_BYTES && PR * CPR % NT8 == 0 && NT8 % CPR == 0, "epilogue staging");
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -215,19 +221,25 @@ __device__ __forceinline__ void tile_epilogue8w(GP& p, f32x4 (&acc)[BM / WGM / 1
         if (p.scale && nok) load8(p.scale + n, sc);
         if (p.shift && nok) load8(p.shift + n, sh);
     }
-#pragma unroll
-    for (int h = 0; h < BM / PR; ++h) {
+    unsigned char* const stage_base = smem + (lane & 15) * SROW + (wn * WN + 4 * (lane >> 4)) * 4;
+#pragma unroll 1
+    for (int h = 0; h < NPASS; ++h) {
         if constexpr (RAW) { CB_LDS_BARRIER(); } else { __syncthreads(); }
-        if (wm == (h * PR) / WM) {
-            const int i0 = ((h * PR) % WM) / 16;
+        if (wm == h / SUB) {
+            const int sub = h % SUB;
 #pragma unroll
-            for (int i = 0; i < PR / 16; ++i)
+            for (int sb = 0; sb < SUB; ++sb) {
+                if (sb == sub) {                                 // (compile-time accumulator indices inside each case)
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    *reinterpret_cast<f32x4*>(smem + (i * 16 + (lane & 15)) * SROW + (wn * WN + j * 16 + 4 * (lane >> 4)) * 4) = acc[i0 + i][j];
+                    for (int i = 0; i < PR / 16; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j)
+                            *reinterpret_cast<f32x4*>(stage_base + i * 16 * SROW + j * 64) = acc[sb * (PR / 16) + i][j];
+                }
+            }
         }
         if constexpr (RAW) { CB_LDS_BARRIER(); } else { __syncthreads(); }
-#pragma unroll
+#pragma unroll 1
         for (int it = 0; it < ITER; ++it) {
             const int rl = (tid + it * NT8) / CPR;
             const int m = m0 + h * PR + rl;

@@ -1028,7 +1028,11 @@ __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 
         float sc[8], sh[8];
         if (p.scale && nok) load8(p.scale + n, sc);
         if (p.shift && nok) load8(p.shift + n, sh);
-#pragma unroll
+        // ROLLED pass / chunk loops (round 5): the epilogue8 body is ~10 KB of branchy code that a workgroup runs once per chunk; unrolled
+        // (2 passes x ITER chunks) it executed out of instruction-cache misses, ~1.1 us per chunk (profiles/r05a_stamps.md).  One copy,
+        // warm after the first trip.  The staged accumulator indices do not depend on the pass (a wave stages its whole block in ITS pass);
+        // the prefetched epilogue operands (EPF) live in registers and are picked by a compile-time-indexed select chain.
+#pragma unroll 1
         for (int h = 0; h < 2; ++h) {
             __syncthreads();
             if (wm == h) {
@@ -1039,19 +1043,31 @@ __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 
                         *reinterpret_cast<f32x4*>(smem + (i * 16 + (lane & 15)) * SROW + (wn * WN + j * 16 + 4 * (lane >> 4)) * 4) = acc[i][j];
             }
             __syncthreads();
-#pragma unroll
+#pragma unroll 1
             for (int it = 0; it < ITER; ++it) {
                 const int rl = (tid + it * NTHREADS) / CPR;
                 const int m = m0 + h * WM + rl;
+                bf16x8 rp = {}, ap = {};
+                if constexpr (EPF != 0) {
+                    if (use_pre) {
+#pragma unroll
+                        for (int q = 0; q < 2 * ITER; ++q) {
+                            if (q == h * ITER + it) {
+                                if constexpr (EPF == 2) rp = pre.r[q];
+                                ap = pre.a[q];
+                            }
+                        }
+                    }
+                }
                 if (m < p.M && nok) {
                     const int64_t orow = p.c_rowmap ? (int64_t)p.c_rowmap[m] : (int64_t)m;
                     float v[8];
                     load8(reinterpret_cast<const float*>(smem + rl * SROW + cc * 32), v);
                     if constexpr (EPF == 2) {
-                        if (use_pre) epilogue8<T, 2>(p, v, sc, sh, m, orow, n, pre.r[h * ITER + it], pre.a[h * ITER + it]);
+                        if (use_pre) epilogue8<T, 2>(p, v, sc, sh, m, orow, n, rp, ap);
                         else epilogue8<T>(p, v, sc, sh, m, orow, n);
                     } else if constexpr (EPF == 1) {
-                        if (use_pre) epilogue8<T, 1>(p, v, sc, sh, m, orow, n, bf16x8{}, pre.a[h * ITER + it]);
+                        if (use_pre) epilogue8<T, 1>(p, v, sc, sh, m, orow, n, bf16x8{}, ap);
                         else epilogue8<T>(p, v, sc, sh, m, orow, n);
                     } else epilogue8<T>(p, v, sc, sh, m, orow, n);
                 }

@@ -135,26 +135,39 @@ __global__ void __launch_bounds__(256, OCC) gemm_stream_kernel(GP p) {
         }
 
         // ---- epilogue: 16 rows per pass through the staging buffer
+        // (rolled loops, round 5: one copy of the ~10 KB epilogue8 body that stays in the instruction cache across passes AND tiles;
+        // unrolled, the NPASS x ITER copies made the per-tile loop larger than the cache, so every tile ran out of instruction misses)
         unsigned char* stg = smem + OFF_STG;
-#pragma unroll
+#pragma unroll 1
         for (int q = 0; q < NPASS; ++q) {
             CB_LDS_BARRIER();                                       // the previous pass (or tile) has been read
             if (wm == q / FM) {
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    *reinterpret_cast<f32x4*>(stg + (lane & 15) * SROW + (wn * WN + j * 16 + 4 * (lane >> 4)) * 4) = acc[q % FM][j];
+                for (int f = 0; f < FM; ++f) {
+                    if (f == q % FM) {                              // (compile-time accumulator index inside each case)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j)
+                            *reinterpret_cast<f32x4*>(stg + (lane & 15) * SROW + (wn * WN + j * 16 + 4 * (lane >> 4)) * 4) = acc[f][j];
+                    }
+                }
             }
             CB_LDS_BARRIER();
-#pragma unroll
+#pragma unroll 1
             for (int it = 0; it < ITER; ++it) {
                 const int id = tid + it * 256;
                 const int rl = id / CPR;
                 const int m = m0 + q * 16 + rl;
+                bf16x8 rp = {};
+                if constexpr (EPI != 0) {
+#pragma unroll
+                    for (int x = 0; x < NPASS * ITER; ++x)
+                        if (x == q * ITER + it) rp = rpre[x];
+                }
                 if (id < 16 * CPR && m < p.M) {
                     float v[8];
                     load8(reinterpret_cast<const float*>(stg + rl * SROW + cc * 32), v);
                     if constexpr (EPI == 0) epilogue8<T>(p, v, sc, sh, m, (int64_t)m, n);
-                    else epilogue8<T, 2>(p, v, sc, sh, m, (int64_t)m, n, rpre[q * ITER + it]);
+                    else epilogue8<T, 2>(p, v, sc, sh, m, (int64_t)m, n, rp);
                 }
             }
         }

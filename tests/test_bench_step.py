@@ -1,0 +1,111 @@
+"""Parity of THE THING THAT IS TIMED: the training step bench.py captures and replays (tools/bench_step.py builds
+it; bench.py's default path uses these very closures).
+
+1. dropout off: one EAGER step and one REPLAY of the captured hipGraph from the same state give the same gradients and the same
+   post-AdamW masters -- bit-equal wherever no fp32 atomics are involved (the layer-stacked encoder weight gradients and everything
+   the update derives from them), within 1e-6 of the tensor's max where split-K / scatter atomics add in hardware order (conv weight
+   gradients with a K split, embedding scatters): the capture (lazy zero, seed counter on the device, fused clip) changes nothing.
+2. the gradients of that step (bf16, the benchmarked arithmetic) against autograd through the CPU ORACLE in fp32 on the same batch --
+   the reference's clip loop, LSE pooling, run_video_retrieval.py:387-421 -- held to the bf16 yardstick's aggregate figures
+   (tests/parity_bounds.py: flat cosine, median per-tensor relative L2; factor 2 because the yardstick was drawn on another batch).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import parity_bounds as PB  # noqa: E402
+from clipbert_amd import synthetic as S  # noqa: E402
+from oracle import clipbert_oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _snapshot(bank):
+    return dict(master=bank.master.clone(), m=bank.exp_avg.clone(), v=bank.exp_avg_sq.clone(), w16=bank.w16.clone())
+
+
+def _restore(bank, snap):
+    bank.master.copy_(snap["master"]); bank.exp_avg.copy_(snap["m"]); bank.exp_avg_sq.copy_(snap["v"]); bank.w16.copy_(snap["w16"])
+
+
+def test_captured_step_equals_eager_step_and_gradients_match_the_oracle():
+    import bench_step
+    videos = 4
+    st = bench_step.build(videos=videos, dropout=False)
+    bank, opt = st.bank, st.opt
+    init = _snapshot(bank)
+
+    def run(step_fn):
+        _restore(bank, init)
+        st.state["global_step"] = 0
+        opt.step_count = 0
+        st.host_prepare()
+        step_fn()
+        torch.cuda.synchronize()
+        return bank.grad.clone(), bank.master.clone(), float(opt.grad_norm())
+
+    g_eager, p_eager, n_eager = run(st.device_step)
+    graph, _ = st.capture()
+    g_graph, p_graph, n_graph = run(graph.replay)
+    g_graph2, p_graph2, _ = run(graph.replay)
+
+    atomics_free = exact = 0
+    for name, p in bank._trainable:
+        off = bank.offset[id(p)]
+        sl = slice(off, off + p.numel())
+        a, b, c = g_eager[sl], g_graph[sl], g_graph2[sl]
+        scale = float(a.abs().max())
+        assert scale > 0 or "token_type" in name or float(b.abs().max()) == 0, name
+        # fp32 atomics (split-K convolution weight gradients, embedding scatter-adds, bias row sums of split launches) add in hardware order
+        tol = 2e-6 * scale + 1e-12
+        assert float((a - b).abs().max()) <= tol, (name, float((a - b).abs().max()), scale)
+        assert float((b - c).abs().max()) <= tol, (name, "replay vs replay")
+        if "encoder.layer" in name and name.endswith("dense.weight") or name.endswith(("query.weight", "key.weight", "value.weight")):
+            atomics_free += 1
+            assert torch.equal(a, b), (name, "layer-stacked weight gradients are first-writer stores: bit-equal")
+            exact += int(torch.equal(p_eager[sl], p_graph[sl]))
+    assert atomics_free >= 12 * 6 and exact == atomics_free, (atomics_free, exact)
+    assert abs(n_eager - n_graph) <= 1e-5 * n_eager
+    assert float((p_eager - p_graph).abs().max()) <= 1e-6 * float(p_eager.abs().max())
+
+    # ---- the eager step's gradients against autograd through the oracle (fp32) on the same batch --------------------------------
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    cfg, sd = st.cfg, st.state_dict
+    frozen = ("stem", "res2", ".norm.")
+    sdr = {k: v.clone().requires_grad_(v.is_floating_point() and not any(f in k for f in frozen)) for k, v in sd.items()}
+    n_clips, T, rep = st.tcfg.train_n_clips, st.tcfg.num_frm, st.tcfg.inference_batch_size
+    frames = st.batch["visual_inputs"].cpu()
+    size = frames.shape[-1]
+    vis = O.image_norm(frames, S.PIXEL_MEAN, S.PIXEL_STD).view(videos, n_clips, T, 3, size, size)
+    ids, mask, labels = st.batch["text_input_ids"].cpu(), st.batch["text_input_mask"].cpu(), st.labels.cpu()
+    per_clip = []
+    for c in range(n_clips):                                    # the reference's clip loop (run_video_retrieval.py:396-401)
+        b = dict(visual_inputs=vis[:, c], text_input_ids=ids, text_input_mask=mask, n_examples_list=[rep] * videos)
+        per_clip.append(O.clipbert_forward(sdr, b, cfg, "retrieval")["logits"])
+    loss = O.lse_train_loss(O.aggregate_clip_logits(per_clip, "lse"), labels).mean()
+    loss.backward()
+    dot = n1 = n2 = 0.0
+    per = {}
+    for name, p in bank._trainable:
+        r = sdr[name].grad
+        r = torch.zeros(p.shape) if r is None else r
+        off = bank.offset[id(p)]
+        g = bank._view(g_eager, off, p).detach().cpu().double().reshape(p.shape)
+        r = r.double()
+        dot += float((g * r).sum()); n1 += float((g * g).sum()); n2 += float((r * r).sum())
+        if float(r.norm()) > 1e-8:
+            per[name] = float((g - r).norm() / r.norm())
+    cos = dot / (n1 ** 0.5 * n2 ** 0.5)
+    Y = PB.grad_yardstick()
+    med = float(np.median(list(per.values())))
+    rec = dict(flat_gradient_cosine=cos, median_tensor_rel_l2=med, tensors=len(per), yardstick_one_minus_cosine=Y["one_minus_cosine"],
+               yardstick_median=Y["median_tensor_rel_l2"])
+    print("[bench step vs oracle autograd]", rec)
+    assert 1.0 - cos <= 2.0 * Y["one_minus_cosine"], rec
+    assert med <= 2.0 * Y["median_tensor_rel_l2"], rec

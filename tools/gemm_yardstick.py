@@ -165,8 +165,8 @@ def md(enc, conv):
            "| product | kind | M x N x K | GF | hipBLASLt hot / cold | TF hot | cb_gemm hot / cold | TF hot | cb / lib (hot, cold) |", "|---|---|---|---:|---:|---:|---:|---:|---:|"]
     for r in enc:
         l, c = r["hipblaslt"], r["cb_gemm"]
-        out.append(f"| {r['name']} | {r['kind']} | {r['M']}x{r['N']}x{r['K']} | {r['gflop']:.1f} | {l[0]} / {l[1]} | {r['gflop'] / l[0] * 1e-3:.0f} | {c[0]} / {c[1]} | "
-                   f"{r['gflop'] / c[0] * 1e-3:.0f} | {c[0] / l[0]:.2f}, {c[1] / l[1]:.2f} |")
+        out.append(f"| {r['name']} | {r['kind']} | {r['M']}x{r['N']}x{r['K']} | {r['gflop']:.1f} | {l[0]} / {l[1]} | {r['gflop'] / l[0] * 1e3:.0f} | {c[0]} / {c[1]} | "
+                   f"{r['gflop'] / c[0] * 1e3:.0f} | {c[0] / l[0]:.2f}, {c[1] / l[1]:.2f} |")
         if "hipblaslt_bias" in r:
             l, c = r["hipblaslt_bias"], r["cb_gemm_bias"]
             out.append(f"| {r['name']} + bias | {r['kind']} | | | {l[0]} / {l[1]} | | {c[0]} / {c[1]} | | {c[0] / l[0]:.2f}, {c[1] / l[1]:.2f} |")

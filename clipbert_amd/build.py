@@ -30,7 +30,7 @@ def variant_path(variant: str) -> str:
     return os.path.join(LIB_DIR, f"libclipbert_hip_{variant}.so")
 
 
-def build(force: bool = False, verbose: bool = False, variant: str = "", defines=()) -> str:
+def build(force: bool = False, verbose: bool = False, variant: str = "", defines=(), csrc: str = "") -> str:
     """variant / defines: a DIAGNOSTIC copy of the library (e.g. variant="stamps", defines=("CB_STAMPS",): in-kernel time stamps,
     tools/stamps_run.py) in its own object directory; the product library is variant ""."""
     os.makedirs(LIB_DIR, exist_ok=True)
@@ -38,10 +38,13 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", defines
     os.makedirs(obj_dir, exist_ok=True)
     lib_path = variant_path(variant) if variant else LIB_PATH
     flags = FLAGS + [f"-D{d}" for d in defines]
-    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    if csrc:                                       # a diagnostic copy built from ANOTHER source tree (e.g. a git worktree of an older commit)
+        flags = [f if f != CSRC else csrc for f in flags]
+    src_dir = csrc or CSRC
+    headers = glob.glob(os.path.join(src_dir, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
     jobs = []
     objs = []
-    for src in sources():
+    for src in sorted(glob.glob(os.path.join(src_dir, "*.hip"))):
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
@@ -63,7 +66,10 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", defines
 
 
 if __name__ == "__main__":
-    if "--stamps" in sys.argv:
+    if "--variant" in sys.argv:                    # python -m clipbert_amd.build --variant NAME --csrc DIR
+        i = sys.argv.index("--variant")
+        print(build(verbose=True, variant=sys.argv[i + 1], csrc=sys.argv[sys.argv.index("--csrc") + 1] if "--csrc" in sys.argv else ""))
+    elif "--stamps" in sys.argv:
         print(build(force="--force" in sys.argv, verbose=True, variant="stamps", defines=("CB_STAMPS",)))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

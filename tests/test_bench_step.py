@@ -6,8 +6,8 @@ it; bench.py's default path uses these very closures).
    the update derives from them), within 1e-6 of the tensor's max where split-K / scatter atomics add in hardware order (conv weight
    gradients with a K split, embedding scatters): the capture (lazy zero, seed counter on the device, fused clip) changes nothing.
 2. the gradients of that step (bf16, the benchmarked arithmetic) against autograd through the CPU ORACLE in fp32 on the same batch --
-   the reference's clip loop, LSE pooling, run_video_retrieval.py:387-421 -- held to the bf16 yardstick's aggregate figures
-   (tests/parity_bounds.py: flat cosine, median per-tensor relative L2; factor 2 because the yardstick was drawn on another batch).
+   the reference's clip loop, LSE pooling, run_video_retrieval.py:387-421 -- held to 1.5 x what the ORACLE's own bf16-storage modes
+   show against the same fp32 gradients ON THIS BATCH (flat cosine, median per-tensor relative L2).
 """
 import os
 import sys
@@ -75,37 +75,45 @@ def test_captured_step_equals_eager_step_and_gradients_match_the_oracle():
     assert float((p_eager - p_graph).abs().max()) <= 1e-6 * float(p_eager.abs().max())
 
     # ---- the eager step's gradients against autograd through the oracle (fp32) on the same batch --------------------------------
+    # The bound is drawn ON THIS BATCH by the oracle itself in its two bf16-storage modes (what an independent, correct bf16
+    # implementation of the path costs here): product error <= 1.5 x the larger of the two, as everywhere else (tests/parity_bounds.py).
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     cfg, sd = st.cfg, st.state_dict
     frozen = ("stem", "res2", ".norm.")
-    sdr = {k: v.clone().requires_grad_(v.is_floating_point() and not any(f in k for f in frozen)) for k, v in sd.items()}
     n_clips, T, rep = st.tcfg.train_n_clips, st.tcfg.num_frm, st.tcfg.inference_batch_size
     frames = st.batch["visual_inputs"].cpu()
     size = frames.shape[-1]
-    vis = O.image_norm(frames, S.PIXEL_MEAN, S.PIXEL_STD).view(videos, n_clips, T, 3, size, size)
     ids, mask, labels = st.batch["text_input_ids"].cpu(), st.batch["text_input_mask"].cpu(), st.labels.cpu()
-    per_clip = []
-    for c in range(n_clips):                                    # the reference's clip loop (run_video_retrieval.py:396-401)
-        b = dict(visual_inputs=vis[:, c], text_input_ids=ids, text_input_mask=mask, n_examples_list=[rep] * videos)
-        per_clip.append(O.clipbert_forward(sdr, b, cfg, "retrieval")["logits"])
-    loss = O.lse_train_loss(O.aggregate_clip_logits(per_clip, "lse"), labels).mean()
-    loss.backward()
-    dot = n1 = n2 = 0.0
-    per = {}
-    for name, p in bank._trainable:
-        r = sdr[name].grad
-        r = torch.zeros(p.shape) if r is None else r
-        off = bank.offset[id(p)]
-        g = bank._view(g_eager, off, p).detach().cpu().double().reshape(p.shape)
-        r = r.double()
-        dot += float((g * r).sum()); n1 += float((g * g).sum()); n2 += float((r * r).sum())
-        if float(r.norm()) > 1e-8:
-            per[name] = float((g - r).norm() / r.norm())
-    cos = dot / (n1 ** 0.5 * n2 ** 0.5)
-    Y = PB.grad_yardstick()
-    med = float(np.median(list(per.values())))
-    rec = dict(flat_gradient_cosine=cos, median_tensor_rel_l2=med, tensors=len(per), yardstick_one_minus_cosine=Y["one_minus_cosine"],
-               yardstick_median=Y["median_tensor_rel_l2"])
+
+    def oracle_grads(mode):
+        sdr = {k: v.clone().requires_grad_(v.is_floating_point() and not any(f in k for f in frozen)) for k, v in sd.items()}
+        with O.precision(mode):
+            vis = O.image_norm(frames, S.PIXEL_MEAN, S.PIXEL_STD).view(videos, n_clips, T, 3, size, size)
+            per_clip = []
+            for c in range(n_clips):                            # the reference's clip loop (run_video_retrieval.py:396-401)
+                b = dict(visual_inputs=vis[:, c], text_input_ids=ids, text_input_mask=mask, n_examples_list=[rep] * videos)
+                per_clip.append(O.clipbert_forward(sdr, b, cfg, "retrieval")["logits"])
+            loss = O.lse_train_loss(O.aggregate_clip_logits(per_clip, "lse"), labels).mean()
+        loss.backward()
+        return {name: (sdr[name].grad if sdr[name].grad is not None else torch.zeros(p.shape)).double() for name, p in bank._trainable}
+
+    def figures(grads, ref):
+        dot = n1 = n2 = 0.0
+        per = {}
+        for name, r in ref.items():
+            g = grads[name]
+            dot += float((g * r).sum()); n1 += float((g * g).sum()); n2 += float((r * r).sum())
+            if float(r.norm()) > 1e-8:
+                per[name] = float((g - r).norm() / r.norm())
+        return 1.0 - dot / (n1 ** 0.5 * n2 ** 0.5), float(np.median(list(per.values())))
+
+    ref = oracle_grads("fp32")
+    mine = {name: bank._view(g_eager, bank.offset[id(p)], p).detach().cpu().double().reshape(p.shape) for name, p in bank._trainable}
+    omc, med = figures(mine, ref)
+    yard = [figures(oracle_grads(m), ref) for m in PB.MODES]
+    y_omc, y_med = max(y[0] for y in yard), max(y[1] for y in yard)
+    rec = dict(one_minus_cosine=omc, median_tensor_rel_l2=med, tensors=len(ref), yardstick_one_minus_cosine=y_omc, yardstick_median=y_med,
+               yardstick_modes=dict(zip(PB.MODES, yard)))
     print("[bench step vs oracle autograd]", rec)
-    assert 1.0 - cos <= 2.0 * Y["one_minus_cosine"], rec
-    assert med <= 2.0 * Y["median_tensor_rel_l2"], rec
+    assert omc <= PB.FACTOR * y_omc, rec
+    assert med <= PB.FACTOR * y_med, rec

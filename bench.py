@@ -361,29 +361,22 @@ def main():
                         shard=os.environ.get("CB_BENCH_SHARD") == "1")      # opt-in: reduce-scatter -> owner-only AdamW -> all-gather
         sync.broadcast_parameters(0)
         opt = FusedAdamW(bank, lr=5e-5, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0)
-    state = {"global_step": 0}
-    one = torch.ones((), dtype=torch.float32, device=dev)          # d(loss)/d(loss): persistent, so that backward() launches no fill
+    # ---- the pieces of a step: tools/bench_step.make_step builds them (tests/test_bench_step.py checks exactly these closures: eager
+    # == captured replay, gradients against the oracle's autograd) ------------------------------------------------------------------
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_step
+    if train:
+        _fns = bench_step.make_step(model, batch, tcfg, opt, sync, labels, counts, nclip, T, args.pool, fold=fold)
+        state, one = _fns.state, _fns.one
+        forward_loss, host_prepare, device_step_single = _fns.forward_loss, _fns.host_prepare, _fns.device_step
+    else:
+        state = {"global_step": 0}
+        one = torch.ones((), dtype=torch.float32, device=dev)
 
-    # ---- the pieces of a step ------------------------------------------------------------------------------------------
-    def forward_loss():
-        stack = tasks.forward_clips_stack(model, batch, nclip, T, fold=fold, cfg=tcfg)       # (n_clips, pairs, C) logits
-        return tasks.training_loss(model, stack, labels, counts, args.pool)                  # clip pooling (a20) + loss
-
-    def host_prepare():
-        """per-step host work of a real training loop: LR schedule onto the 8 groups, hyper-parameter upload"""
-        state["global_step"] += 1
-        tasks.set_learning_rates(opt, tcfg, state["global_step"])
-        opt.prepare_step(grad_scale=sync.grad_scale)
-
-    def device_step_single():
-        """everything a 1-GPU step enqueues (capturable)"""
-        opt.zero_grad(lazy=True)
-        model.rt.pending_encoder_nodes = model.rt.pending_cnn_nodes = 0
-        loss = forward_loss()
-        loss.backward(one)
-        ops.counter_add(model.rt.seed_dev)
-        opt.launch()
-        return loss
+        def forward_loss():
+            stack = tasks.forward_clips_stack(model, batch, nclip, T, fold=fold, cfg=tcfg)       # (n_clips, pairs, C) logits
+            return tasks.training_loss(model, stack, labels, counts, args.pool)                  # clip pooling (a20) + loss
+        host_prepare = device_step_single = None
 
     # Software-pipelined optimizer (1 GPU, opt-in: CB_BENCH_PIPELINE=1 -- measured SLOWER than the plain plan, 11.70-11.81 vs 11.52-11.56 ms
     # on the same box, round 3: the streaming update beside the ResNet forward costs that forward more than it hides): the AdamW update of the TRANSFORMER groups (111 M of the

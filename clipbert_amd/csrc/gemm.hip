@@ -285,11 +285,13 @@ int gemm_prepare(const cb_gemm_desc* d, Prepared& out) {
     p.dropout_p = d->dropout_p; p.seed = d->dropout_seed; p.seed_ptr = d->dropout_seed_ptr;
     const int bk = d->dtype == CB_BF16 ? Tr<bf16>::BK : Tr<float>::BK;
     p.ktiles = (d->K + bk - 1) / bk;
-    {   // write-through epilogue stores (round-5 experiment, tools/r05a_call.sh): CB_GEMM_WT=1
-        static const bool wt = getenv("CB_GEMM_WT") != nullptr && atoi(getenv("CB_GEMM_WT")) != 0;
-        p.wt = wt && d->dtype == CB_BF16 && !d->c_f32 && (int64_t)d->M * (d->ldc > d->ldc2 ? d->ldc : d->ldc2) * 2 * (p.batch) < 0xffffffffll;
+    {   // write-through (sc1) bf16 epilogue stores (round 5, profiles/r05b_bench_ab_wt.txt: -0.10 ... -0.14 ms per step, four alternating runs):
+        // the output leaves for the memory side while the other workgroups still compute, instead of sitting dirty in the XCD's L2 until
+        // the end-of-kernel release writes it back in one burst.  CB_GEMM_WT=0 restores plain stores; =3 adds nt on the second output.
+        static const int wt = getenv("CB_GEMM_WT") != nullptr ? atoi(getenv("CB_GEMM_WT")) : 1;
+        const bool ok = d->dtype == CB_BF16 && !d->c_f32 && (int64_t)d->M * (d->ldc > d->ldc2 ? d->ldc : d->ldc2) * 2 * (p.batch) < 0xffffffffll && !d->c_rowmap;
+        p.wt = ok ? wt : 0;
     }
-
     const bool a_krow = d->a_mode == CB_KROW;
     const bool b_krow = d->b_mode == CB_KROW || d->b_mode == CB_KROW_TAPS || d->b_mode == CB_KROW_GATHER;
     CB_REQUIRE(d->a_mode == CB_ROWK || d->a_mode == CB_ROWK_GATHER || d->a_mode == CB_KROW, "cb_gemm: bad a_mode %d", d->a_mode);

@@ -812,12 +812,13 @@ __device__ __forceinline__ void store8(bf16* q, const float (&v)[8]) {
 // Write-through form of store8 (bf16): `global_store_dwordx4 ... sc1` through a buffer descriptor over C.  A plain store leaves its line
 // dirty in the XCD's L2 until the end-of-kernel release writes everything back in one burst (MI355X_MICROARCH.md "boundary": + B / 6 TB/s
 // behind B dirty bytes); a write-through store sends the bytes to the memory side while the other workgroups still compute.
+template <int AUX = 16 /* sc1 */>
 __device__ __forceinline__ void store8_wt(void* base, int64_t elem_off, const float (&v)[8]) {
     union { bf16x8 x; u32x4 r; } u;
 #pragma unroll
     for (int r = 0; r < 8; ++r) u.x[r] = (bf16)v[r];
     const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, (short)0, (int)0xffffffffu, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b128(u.r, rs, (uint32_t)(elem_off * 2), 0, 16 /* sc1 */);
+    __builtin_amdgcn_raw_buffer_store_b128(u.r, rs, (uint32_t)(elem_off * 2), 0, AUX);
 }
 
 // Epilogue of 8 consecutive columns n..n+7 of row m (row-contiguous: every global access is a full 16-byte lane
@@ -875,14 +876,20 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
 #pragma unroll
                 for (int r = 0; r < 8; ++r) u[r] = v[r];
             }
-            store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, u);
+            if constexpr (sizeof(T) == 2) {
+                if (p.wt) store8_wt(p.C2, orow * p.ldc2 + n, u);
+                else store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, u);
+            } else store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, u);
         }
         if (p.post_scale) {
             load8(p.post_scale + n, t);
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] *= t[r];
         }
-        store8(c, v);
+        if constexpr (sizeof(T) == 2) {
+            if (p.wt) store8_wt(p.C, orow * p.ldc + n, v);
+            else store8(c, v);
+        } else store8(c, v);
         if (p.zfill) {
             zero_patch8(reinterpret_cast<T*>(p.C), p.ldc, orow, n, p.zfill);
             if (p.C2) zero_patch8(reinterpret_cast<T*>(p.C2), p.ldc2, orow, n, p.zfill);
@@ -899,7 +906,8 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
     }
     if (p.C2) {
         if constexpr (sizeof(T) == 2) {
-            if (p.wt) store8_wt(p.C2, orow * p.ldc2 + n, v);
+            if (p.wt & 2) store8_wt<18 /* sc1 + nt: the pre-activation is next read in the backward */>(p.C2, orow * p.ldc2 + n, v);
+            else if (p.wt) store8_wt(p.C2, orow * p.ldc2 + n, v);
             else store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, v);
         } else store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, v);
     }

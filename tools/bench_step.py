@@ -58,19 +58,39 @@ def build(videos=16, n_clips=2, frames=2, size=224, txt_len=32, repeat=2, pool="
     batch = dict(visual_inputs=fr, text_input_ids=ids, text_input_mask=mask, labels=labels, n_examples_list=counts)
     sync = GradSync(bank, compress="bf16", comm="auto")
     opt = FusedAdamW(bank, lr=5e-5, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0)
+    fns = make_step(model, batch, tcfg, opt, sync, labels, counts, n_clips, frames, pool)
+
+    def capture(fn=None):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = (fn or fns.device_step)()
+        return g, out
+
+    return SimpleNamespace(model=model, cfg=cfg, state_dict=sd, batch=batch, tcfg=tcfg, labels=labels, counts=counts, opt=opt, sync=sync, bank=bank,
+                           forward_loss=fns.forward_loss, host_prepare=fns.host_prepare, device_step=fns.device_step, capture=capture, state=fns.state,
+                           clips_per_step=videos * n_clips, dev=dev)
+
+
+def make_step(model, batch, tcfg, opt, sync, labels, counts, n_clips, frames, pool, fold=True):
+    """The closures of one training step on prepared objects -- bench.py's default path calls THIS (its `forward_loss`, `host_prepare`
+    and `device_step_single` are these functions), so tests/test_bench_step.py tests what is timed."""
+    from clipbert_amd import ops
+    from clipbert_amd import tasks
     state = {"global_step": 0}
-    one = torch.ones((), dtype=torch.float32, device=dev)
+    one = torch.ones((), dtype=torch.float32, device=labels.device)          # d(loss)/d(loss): persistent, so that backward() launches no fill
 
     def forward_loss():
-        stack = tasks.forward_clips_stack(model, batch, n_clips, frames, fold=True, cfg=tcfg)
-        return tasks.training_loss(model, stack, labels, counts, pool)
+        stack = tasks.forward_clips_stack(model, batch, n_clips, frames, fold=fold, cfg=tcfg)       # (n_clips, pairs, C) logits
+        return tasks.training_loss(model, stack, labels, counts, pool)                              # clip pooling (a20) + loss
 
     def host_prepare():
+        """per-step host work of a real training loop: LR schedule onto the 8 groups, hyper-parameter upload"""
         state["global_step"] += 1
         tasks.set_learning_rates(opt, tcfg, state["global_step"])
         opt.prepare_step(grad_scale=sync.grad_scale)
 
     def device_step():
+        """everything a 1-GPU step enqueues (capturable)"""
         opt.zero_grad(lazy=True)
         model.rt.pending_encoder_nodes = model.rt.pending_cnn_nodes = 0
         loss = forward_loss()
@@ -79,12 +99,4 @@ def build(videos=16, n_clips=2, frames=2, size=224, txt_len=32, repeat=2, pool="
         opt.launch()
         return loss
 
-    def capture(fn=None):
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            out = (fn or device_step)()
-        return g, out
-
-    return SimpleNamespace(model=model, cfg=cfg, state_dict=sd, batch=batch, tcfg=tcfg, labels=labels, counts=counts, opt=opt, sync=sync, bank=bank,
-                           forward_loss=forward_loss, host_prepare=host_prepare, device_step=device_step, capture=capture, state=state,
-                           clips_per_step=videos * n_clips, dev=dev)
+    return SimpleNamespace(forward_loss=forward_loss, host_prepare=host_prepare, device_step=device_step, state=state, one=one)

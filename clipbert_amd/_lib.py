@@ -33,8 +33,15 @@ class GemmDesc(C.Structure):
     ]
 
 
+class Res2Desc(C.Structure):
+    _fields_ = [("x", vp), ("out", vp), ("w1", vp), ("w2", vp), ("w3", vp), ("wsc", vp),
+                ("scale1", vp), ("shift1", vp), ("scale2", vp), ("shift2", vp), ("scale3", vp), ("shift3", vp),
+                ("scale_sc", vp), ("shift_sc", vp), ("N", i32), ("H", i32), ("W", i32), ("cin", i32)]
+
+
 _SIGNATURES = {
     "cb_gemm": [C.POINTER(GemmDesc), vp],
+    "cb_res2_block": [C.POINTER(Res2Desc), vp],
     "cb_gemm_plan": [vp, i32, vp],
     "cb_gemm_group": [vp, i32, vp],
     "cb_gemm_workspace_bytes": [vp, vp],

@@ -358,6 +358,26 @@ def _block_trainable(rt: Runtime, blk: BottleneckBlock) -> bool:
     return any(rt.bank.is_trainable(c.weight) for c in (blk.conv1, blk.conv2, blk.conv3) + ((blk.shortcut,) if blk.shortcut is not None else ()))
 
 
+def _res2_block_fused(rt: Runtime, x, blk: BottleneckBlock):
+    """one res2 block through cb_res2_block (conv1 -> conv2 -> conv3 + shortcut in ONE launch; forward only)"""
+    w = lambda conv: rt.bank.compute(conv.weight)
+    sc = blk.shortcut
+    return ops.res2_block(x, w(blk.conv1), w(blk.conv2), w(blk.conv3), blk.conv1.scale_shift(), blk.conv2.scale_shift(), blk.conv3.scale_shift(),
+                          wsc=w(sc) if sc is not None else None, sssc=sc.scale_shift() if sc is not None else None)
+
+
+def _res2_fusable(rt: Runtime, x, blk: BottleneckBlock, save: bool) -> bool:
+    """the fused forward kernel covers the frozen 64-mid-channel, stride-1 blocks in bf16 (FREEZE_AT = 2: nothing of res2 is saved for a
+    backward); CB_NO_RES2_FUSE=1 restores the three / four cb_gemm launches"""
+    if rt.dtype != torch.bfloat16 or os.environ.get("CB_NO_RES2_FUSE") is not None:
+        return False
+    if save and _block_trainable(rt, blk):
+        return False
+    c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
+    return (c1.cout == 64 and c2.cin == 64 and c2.cout == 64 and c3.cout == 256 and c1.stride == 1 and c1.k == 1 and c2.k == 3 and c2.stride == 1
+            and c3.k == 1 and c1.cin in (64, 256) and (blk.shortcut is not None) == (c1.cin == 64) and x.shape[-1] == c1.cin and x.is_contiguous())
+
+
 def cnn_forward(bb: "GridFeatBackbone", x5: torch.Tensor, save: bool):
     """(B,T,3,H,W) fp32 RGB mean-subtracted (or uint8 RGB) -> grid (B,T,H',W',hidden) + saved activations."""
     rt = bb.rt
@@ -384,6 +404,9 @@ def cnn_forward(bb: "GridFeatBackbone", x5: torch.Tensor, save: bool):
     saved = []
     for name, _nb, _mid, _cout, _s in RESNET50_STAGES:
         for blk in getattr(net, name):
+            if _res2_fusable(rt, x, blk, save):
+                x = _res2_block_fused(rt, x, blk)
+                continue
             if blk.shortcut is not None and blk.conv1.stride > 1 and rt.group_fwd_pairs:
                 # stage entry with a stride: projection shortcut and conv1 read the same strided pixels -- one grouped launch
                 # (the stride-1 entry of res2 stays two launches: its shortcut is a streaming-kernel shape, cb_gemm tile 8)

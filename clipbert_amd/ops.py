@@ -206,6 +206,24 @@ def maxpool_fwd(x: torch.Tensor, k: int, stride: int, pad: int, relu: bool = Fal
     return y
 
 
+def res2_block(x, w1, w2, w3, ss1, ss2, ss3, wsc=None, sssc=None) -> torch.Tensor:
+    """cb_res2_block: one res2 bottleneck block (64 mid channels, stride 1, FrozenBN, forward only) in one launch.  x (N, H, W, cin) bf16
+    NHWC; w*: the convolutions' KRSC weight images; ss*: their (scale, shift) fp32 vectors; wsc / sssc: the projection shortcut of the
+    stage-entry block (cin = 64), None for an identity shortcut (cin = 256)."""
+    n, h, w, cin = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    out = torch.empty(n, h, w, 256, dtype=x.dtype, device=x.device)
+    d = _lib.Res2Desc()
+    d.x, d.out = _ptr(x), _ptr(out)
+    d.w1, d.w2, d.w3, d.wsc = _ptr(w1), _ptr(w2), _ptr(w3), _ptr(wsc)
+    d.scale1, d.shift1, d.scale2, d.shift2, d.scale3, d.shift3 = (_ptr(t) for t in (*ss1, *ss2, *ss3))
+    d.scale_sc, d.shift_sc = (_ptr(sssc[0]), _ptr(sssc[1])) if sssc is not None else (None, None)
+    d.N, d.H, d.W, d.cin = n, h, w, cin
+    d._refs = (x, out, w1, w2, w3, wsc, ss1, ss2, ss3, sssc)
+    _chk(_lib.get().cb_res2_block(C.byref(d), _stream(x)), "cb_res2_block")
+    return out
+
+
 def maxpool2_bwd(x, y, dy, relu: bool = False) -> torch.Tensor:
     n, h, w, c = x.shape
     oh, ow = y.shape[1], y.shape[2]

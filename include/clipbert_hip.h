@@ -178,6 +178,22 @@ int cb_maxpool_fwd(int32_t dtype, const void* x, void* y, int32_t N, int32_t H, 
 int cb_maxpool2_bwd(int32_t dtype, const void* x, const void* y, const void* dy, void* dx, int32_t N,
                     int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t relu, void* stream);
 
+/* One bottleneck block of the res2 stage in ONE launch, forward only (round 5): detectron2's BottleneckBlock with 64 mid channels,
+ * stride 1, FrozenBN (modeling/backbone/resnet.py as built by src/modeling/grid_feat.py:60-70; FREEZE_AT = 2 keeps the stage frozen):
+ *     y1 = relu(bn1(conv1x1(x)));  y2 = relu(bn2(conv3x3(y1), pad 1));  out = relu(bn3(conv1x1(y2)) + shortcut)
+ * bf16, NHWC.  x: (N, H, W, cin), cin = 64 (stage entry: shortcut = bn_sc(conv1x1(x)) through wsc) or 256 (identity shortcut, wsc
+ * NULL); out: (N, H, W, 256).  Weights in their KRSC memory images: w1 [64][cin], w2 [64][3][3][64], w3 [256][64], wsc [256][64];
+ * scale / shift: the folded fp32 FrozenBN vectors of each convolution.  Replaces three (four) cb_gemm launches whose 64-channel
+ * intermediates made them HBM-bound; same arithmetic (bf16 y1 / y2, fp32 accumulation).  All pointers 16-byte aligned. */
+typedef struct cb_res2_desc {
+    const void* x; void* out;
+    const void* w1; const void* w2; const void* w3; const void* wsc;
+    const float* scale1; const float* shift1; const float* scale2; const float* shift2; const float* scale3; const float* shift3;
+    const float* scale_sc; const float* shift_sc;
+    int32_t N, H, W, cin;
+} cb_res2_desc;
+int cb_res2_block(const cb_res2_desc* desc, void* stream);
+
 /* g = dy * (y > 0) * scale[c]  (ReLU + FrozenBN backward); optional second output dz = dy * (y > 0)
  * and third g2 = dz * scale2[c] (projection shortcut).  rows x C, contiguous. */
 int cb_relu_scale_bwd(int32_t dtype, const void* dy, const void* y, const float* scale, void* g,

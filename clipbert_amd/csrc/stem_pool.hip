@@ -1,0 +1,156 @@
+// Fused ResNet-50 stem of the grid backbone, forward only: 7x7 stride-2 convolution (3 -> 64) + FrozenBN + ReLU + 3x3 stride-2 max-pool
+// (detectron2 BasicStem; src/modeling/grid_feat.py:89-105) on the packed NHWC4 image cb_stem_pack writes, bf16.
+//
+// Why one kernel.  As cb_gemm + cb_maxpool_fwd the 112 x 112 x 64 convolution output (103 MB for 64 frames) is written, read back by the
+// pooling kernel and thrown away: 120 + 36 us (r05f), the convolution issue-bound on its 7-row gather addressing and the pool at a 19 %
+// L2 hit rate (profiles/r04k).  Here a workgroup owns an 8 x 8 tile of POOLED pixels: the 17 x 17 convolution outputs it needs are
+// computed from a 39 x 40-pixel input tile in LDS (12 KB), stay in LDS as bf16 (41 KB) and are pooled from there -- 27 MB in (x 1.5 of
+// halo), 26 MB out.
+//
+// Structure (256 threads = 4 waves, persistent over the tiles, like cb_res2_block): the filter lives in registers -- every wave owns 16 of
+// the 64 output channels as 7 MFMA B fragments, one per filter ROW (K = 7 rows x (8 taps x 4 channels), tap 7 and channel 3 zero: the image
+// of _stem_weight / cb_gemm's stem form, so the fp32 summation order is the one of the unfused path); an A fragment is 16 convolution
+// pixels x one filter row = 16 bytes per lane straight from the input tile (pixel (2 oy + r, 2 ox + 2 q), 2 pixels x 4 channels).
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int PT = 8;                        // pooled tile
+constexpr int CT = 2 * PT + 1;               // 17 x 17 convolution outputs feed it (3x3 windows, stride 2, pad 1)
+constexpr int NCONV = CT * CT;               // 289
+constexpr int NFRAG = (NCONV + 15) / 16;     // 19 row fragments (the last one partial)
+constexpr int IR = 2 * CT + 5;               // 39 input rows (7-row filter, stride 2)
+constexpr int ICH = 20;                      // 16-byte chunks (2 pixels x 4 channels) per input row: 40 pixels, 39 used
+constexpr int IP = ICH * 16;                 // 320 B
+constexpr int PC = 64 * 2 + 16;              // LDS pitch of a 64-channel row
+
+struct StemP {
+    const bf16* img; bf16* out; const bf16* w; const float* scale; const float* shift;
+    int N, Hp, Wp, OH, OW, PH, PW, tiles_h, tiles_w, ntiles;
+};
+
+template <int DUMMY>
+__global__ void __launch_bounds__(256, 2) stem_pool_kernel(StemP p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[IR * IP + NFRAG * 16 * PC];
+    unsigned char* const Is = smem;
+    unsigned char* const Cs = smem + IR * IP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    bf16x8 wf[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r) wf[r] = *reinterpret_cast<const bf16x8*>(p.w + (size_t)(16 * wave + lr) * 224 + r * 32 + 8 * lq);
+    const int cA = 16 * wave + 4 * lq;
+    const f32x4 sc = load4(p.scale + cA), sh = load4(p.shift + cA);
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int tw = tile % p.tiles_w, rest = tile / p.tiles_w;
+        const int th = rest % p.tiles_h, n = rest / p.tiles_h;
+        const int ph0 = th * PT, pw0 = tw * PT;
+        const int cy0 = 2 * ph0 - 1, cx0 = 2 * pw0 - 1;          // convolution pixel of tile position (0, 0)
+        const int iy0 = 2 * cy0, ix0 = 2 * cx0;                  // its first packed-image row / pixel (the packed image carries the padding)
+        // ---- 1. input tile -> LDS (rows / pixels outside the packed image: zeros; they only feed convolution pixels outside the map)
+        {
+            constexpr int TOTAL = IR * ICH, ITERS = (TOTAL + 255) / 256;
+            u32x4 v[ITERS];
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int idx = tid + it * 256;
+                const int ir = idx / ICH, cc = idx % ICH;
+                const int gy = iy0 + ir, gx = ix0 + 2 * cc;
+                const bool ok = idx < TOTAL && (unsigned)gy < (unsigned)p.Hp && gx >= 0 && gx + 1 < p.Wp;
+                u32x4 z = {0u, 0u, 0u, 0u};
+                v[it] = z;
+                if (ok) v[it] = *reinterpret_cast<const u32x4*>(p.img + (((size_t)n * p.Hp + gy) * p.Wp + gx) * 4);
+            }
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int idx = tid + it * 256;
+                if (idx < TOTAL) *reinterpret_cast<u32x4*>(Is + (idx / ICH) * IP + (idx % ICH) * 16) = v[it];
+            }
+        }
+        __syncthreads();
+        // ---- 2. the 17 x 17 convolution outputs of this wave's 16 channels: FrozenBN + ReLU, zero outside the map, bf16 -> LDS
+#pragma unroll 1
+        for (int i0 = 0; i0 < NFRAG + 1; i0 += 2) {
+            f32x4 acc[2];
+            const unsigned char* base[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int pix = (i0 + u) * 16 + lr;
+                pix = pix < NCONV ? pix : NCONV - 1;                  // (fragment rows past the tile: discarded below)
+                base[u] = Is + (2 * (pix / CT)) * IP + (2 * (pix % CT) + 2 * lq) * 8;
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                acc[u] = z;
+            }
+#pragma unroll
+            for (int r = 0; r < 7; ++r)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[r], *reinterpret_cast<const bf16x8*>(base[u] + r * IP), acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pix = (i0 + u) * 16 + lr;
+                if (i0 + u < NFRAG && pix < NCONV) {
+                    const int gy = cy0 + pix / CT, gx = cx0 + pix % CT;
+                    const bool in = (unsigned)gy < (unsigned)p.OH && (unsigned)gx < (unsigned)p.OW;
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = acc[u][e] * sc[e] + sh[e];
+                        o[e] = (bf16)((in && y > 0.f) ? y : 0.f);     // (>= 0 everywhere: a zero stands in for the pool's -inf padding)
+                    }
+                    *reinterpret_cast<bf16x4*>(Cs + pix * PC + cA * 2) = o;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 3. 3 x 3 / stride 2 max-pool out of LDS: thread <-> (pooled pixel, 8 channels), 16-byte stores, 128-byte runs per pixel
+#pragma unroll
+        for (int it = 0; it < PT * PT * 8 / 256; ++it) {
+            const int idx = tid + it * 256;
+            const int pix = idx >> 3, ch = idx & 7;
+            const int py = pix >> 3, px = pix & 7;
+            float m[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + ((2 * py + t / 3) * CT + 2 * px + t % 3) * PC + ch * 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; m[e] = f > m[e] ? f : m[e]; }
+            }
+            const int gy = ph0 + py, gx = pw0 + px;
+            if (gy < p.PH && gx < p.PW) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)m[e];
+                *reinterpret_cast<bf16x8*>(p.out + (((size_t)n * p.PH + gy) * p.PW + gx) * 64 + ch * 8) = o;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int cb_stem_pool(const void* packed, const void* weight, const float* scale, const float* shift, void* out, int32_t N,
+                            int32_t Hp, int32_t Wp, int32_t OH, int32_t OW, int32_t PH, int32_t PW, void* stream) {
+    CB_REQUIRE(packed && weight && scale && shift && out, "cb_stem_pool: null operand");
+    CB_REQUIRE(N > 0 && OH > 0 && OW > 0 && PH == (OH + 2 - 3) / 2 + 1 && PW == (OW + 2 - 3) / 2 + 1, "cb_stem_pool: pooled size %d x %d does not follow from %d x %d", PH, PW, OH, OW);
+    CB_REQUIRE(Hp >= 2 * (OH - 1) + 7 && Wp >= 2 * (OW - 1) + 8 && Wp % 2 == 0, "cb_stem_pool: packed image %d x %d too small for a %d x %d convolution (cb_stem_pack: pad 3, even width)", Hp, Wp, OH, OW);
+    for (const void* q : {packed, weight, (const void*)scale, (const void*)shift, (const void*)out})
+        CB_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15) == 0, "cb_stem_pool: operands must be 16-byte aligned");
+    StemP p;
+    p.img = (const bf16*)packed; p.out = (bf16*)out; p.w = (const bf16*)weight; p.scale = scale; p.shift = shift;
+    p.N = N; p.Hp = Hp; p.Wp = Wp; p.OH = OH; p.OW = OW; p.PH = PH; p.PW = PW;
+    p.tiles_h = (PH + PT - 1) / PT; p.tiles_w = (PW + PT - 1) / PT;
+    const int64_t nt = (int64_t)N * p.tiles_h * p.tiles_w;
+    CB_REQUIRE(nt < (1ll << 31), "cb_stem_pool: too many tiles");
+    p.ntiles = (int)nt;
+    const char* cap = getenv("CB_STEM_MAXWG");                // (tests: a few workgroups walk many tiles)
+    const int max_wg = cap && atoi(cap) > 0 ? atoi(cap) : 512;
+    hipLaunchKernelGGL((stem_pool_kernel<0>), dim3((unsigned)(nt < max_wg ? nt : max_wg)), dim3(256), 0, cb_stream(stream), p);
+    return cb_launch_status("cb_stem_pool");
+}

@@ -395,12 +395,16 @@ def cnn_forward(bb: "GridFeatBackbone", x5: torch.Tensor, save: bool):
     stem = net.stem.conv1
     oh, ow = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
     m = n * oh * ow
-    tab = rt.table(n, oh, ow, 2, 0, hp * wp * 4, wp * 4, 4, x5.device)
-    y = torch.empty(n, oh, ow, 64, dtype=rt.dtype, device=x5.device)
     scale, shift = stem.scale_shift()
-    ops.gemm(packed, _stem_weight(rt, stem), m, 64, 224, out=y.view(m, 64), a_mode=ROWK_GATHER, a_tab=tab, lda=0, ldb=224,
-             R=7, S=1, Cin=32, H=hp, W=wp, sH=wp * 4, sW=4, scale=scale, shift=shift, act=ACT_RELU)
-    x = ops.maxpool_fwd(y, 3, 2, 1)
+    if rt.dtype == torch.bfloat16 and wp % 2 == 0 and os.environ.get("CB_NO_STEM_FUSE") is None:
+        # convolution + FrozenBN + ReLU + max-pool in one launch (the 112 x 112 x 64 map never leaves the CU); CB_NO_STEM_FUSE=1: two launches
+        x = ops.stem_pool(packed, _stem_weight(rt, stem), scale, shift, oh, ow)
+    else:
+        tab = rt.table(n, oh, ow, 2, 0, hp * wp * 4, wp * 4, 4, x5.device)
+        y = torch.empty(n, oh, ow, 64, dtype=rt.dtype, device=x5.device)
+        ops.gemm(packed, _stem_weight(rt, stem), m, 64, 224, out=y.view(m, 64), a_mode=ROWK_GATHER, a_tab=tab, lda=0, ldb=224,
+                 R=7, S=1, Cin=32, H=hp, W=wp, sH=wp * 4, sW=4, scale=scale, shift=shift, act=ACT_RELU)
+        x = ops.maxpool_fwd(y, 3, 2, 1)
     saved = []
     for name, _nb, _mid, _cout, _s in RESNET50_STAGES:
         for blk in getattr(net, name):

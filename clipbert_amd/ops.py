@@ -206,6 +206,18 @@ def maxpool_fwd(x: torch.Tensor, k: int, stride: int, pad: int, relu: bool = Fal
     return y
 
 
+def stem_pool(packed, weight, scale, shift, oh: int, ow: int) -> torch.Tensor:
+    """cb_stem_pool: stem convolution + FrozenBN + ReLU + 3x3/2 max-pool of the packed (N, Hp, Wp, 4) bf16 image in one launch ->
+    (N, PH, PW, 64)."""
+    n, hp, wp, _ = packed.shape
+    assert packed.dtype == torch.bfloat16 and packed.is_contiguous() and weight.dtype == torch.bfloat16
+    ph, pw = (oh - 1) // 2 + 1, (ow - 1) // 2 + 1
+    out = torch.empty(n, ph, pw, 64, dtype=packed.dtype, device=packed.device)
+    _chk(_lib.get().cb_stem_pool(_ptr(packed), _ptr(weight), _ptr(scale), _ptr(shift), _ptr(out), n, hp, wp, oh, ow, ph, pw, _stream(packed)),
+         "cb_stem_pool")
+    return out
+
+
 def res2_block(x, w1, w2, w3, ss1, ss2, ss3, wsc=None, sssc=None) -> torch.Tensor:
     """cb_res2_block: one res2 bottleneck block (64 mid channels, stride 1, FrozenBN, forward only) in one launch.  x (N, H, W, cin) bf16
     NHWC; w*: the convolutions' KRSC weight images; ss*: their (scale, shift) fp32 vectors; wsc / sssc: the projection shortcut of the

@@ -178,6 +178,13 @@ int cb_maxpool_fwd(int32_t dtype, const void* x, void* y, int32_t N, int32_t H, 
 int cb_maxpool2_bwd(int32_t dtype, const void* x, const void* y, const void* dy, void* dx, int32_t N,
                     int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t relu, void* stream);
 
+/* The stem in ONE launch, forward only (round 5): 7x7 stride-2 convolution (3 -> 64) + FrozenBN + ReLU + 3x3 stride-2 max-pool (pad 1)
+ * of detectron2's BasicStem, bf16.  packed: the (N, Hp, Wp, 4) image of cb_stem_pack (pad 3, Wp even); weight: [64][7][8 taps x 4 ch] bf16
+ * (tap 7 and channel 3 zero); scale / shift: the folded FrozenBN; out: (N, PH, PW, 64) with OH x OW the convolution's map and
+ * PH = (OH - 1) / 2 + 1.  Replaces cb_gemm (stem form) + cb_maxpool_fwd: the convolution output never leaves the CU. */
+int cb_stem_pool(const void* packed, const void* weight, const float* scale, const float* shift, void* out, int32_t N, int32_t Hp,
+                 int32_t Wp, int32_t OH, int32_t OW, int32_t PH, int32_t PW, void* stream);
+
 /* One bottleneck block of the res2 stage in ONE launch, forward only (round 5): detectron2's BottleneckBlock with 64 mid channels,
  * stride 1, FrozenBN (modeling/backbone/resnet.py as built by src/modeling/grid_feat.py:60-70; FREEZE_AT = 2 keeps the stage frozen):
  *     y1 = relu(bn1(conv1x1(x)));  y2 = relu(bn2(conv3x3(y1), pad 1));  out = relu(bn3(conv1x1(y2)) + shortcut)

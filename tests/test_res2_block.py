@@ -95,3 +95,38 @@ def test_fused_block_equals_the_unfused_product_path(hw, first):
     err = (got.float() - ref.float()).abs()
     assert float(err.max()) <= 2 ** -7 * max(1.0, float(ref.float().abs().max())), float(err.max())
     assert float((err > 0).float().mean()) < 0.05
+
+
+@pytest.mark.parametrize("n,h,w,maxwg", [(2, 32, 32, 0), (1, 48, 40, 3), (1, 30, 18, 0)])
+def test_stem_pool_equals_conv_then_pool(hw, monkeypatch, n, h, w, maxwg):
+    """cb_stem_pool against the two launches it replaces (cb_gemm in its stem form + cb_maxpool_fwd) on the same packed image, and
+    against conv2d + max_pool2d in fp32 PyTorch with the convolution output rounded to bf16 where the unfused path stores it"""
+    if maxwg:
+        monkeypatch.setenv("CB_STEM_MAXWG", str(maxwg))
+    from clipbert_amd import modeling as M
+    g = _gen(21)
+    frames = torch.randint(0, 256, (n, 3, h, w), generator=g, dtype=torch.uint8)
+    wt = torch.randn(64, 3, 7, 7, generator=g) * (2.0 / 147) ** 0.5
+    scale, shift = 0.5 + torch.rand(64, generator=g), torch.randn(64, generator=g) * 0.2
+    mean, std = (123.675, 116.28, 103.53), (1.0, 1.0, 1.0)
+    packed = ops.stem_pack(frames.to(DEV[0]), torch.bfloat16, 3, mean, std, extra_w=2)
+    wp_ = torch.zeros(64, 7, 8, 4)
+    wp_[:, :, :7, :3] = wt.permute(0, 2, 3, 1)
+    wk = wp_.view(64, 224).to(torch.bfloat16).to(DEV[0])
+    oh, ow = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+    got = ops.stem_pool(packed, wk, scale.to(DEV[0]), shift.to(DEV[0]), oh, ow).float().cpu()
+    # (a) the unfused launches
+    hp, wpk = packed.shape[1], packed.shape[2]
+    tab = ops.build_pixel_table(n, oh, ow, 2, 0, hp * wpk * 4, wpk * 4, 4, DEV[0])
+    y = torch.empty(n, oh, ow, 64, dtype=torch.bfloat16, device=DEV[0])
+    ops.gemm(packed, wk, n * oh * ow, 64, 224, out=y.view(-1, 64), a_mode=M.ROWK_GATHER, a_tab=tab, lda=0, ldb=224, R=7, S=1, Cin=32, H=hp, W=wpk,
+             sH=wpk * 4, sW=4, scale=scale.to(DEV[0]), shift=shift.to(DEV[0]), act=M.ACT_RELU)
+    ref_a = ops.maxpool_fwd(y, 3, 2, 1).float().cpu()
+    assert got.shape == ref_a.shape
+    assert torch.equal(got, ref_a), float((got - ref_a).abs().max())                  # same K order, same rounding points: bit-equal
+    # (b) plain PyTorch: BGR, mean-subtracted, bf16 operands, fp32 math
+    x = _bf(frames.float()[:, [2, 1, 0]] - torch.tensor(mean)[[2, 1, 0]].view(1, 3, 1, 1))
+    conv = F.conv2d(x, _bf(wt), stride=2, padding=3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    ref_b = F.max_pool2d(_bf(F.relu(conv)), 3, 2, 1).permute(0, 2, 3, 1)
+    err = (got - ref_b).abs()
+    assert float(err.max()) <= 2 ** -6 * max(1.0, float(ref_b.abs().max())), float(err.max())

@@ -104,7 +104,11 @@ __global__ void __launch_bounds__(256, OCC) gemm_stream_kernel(GP p) {
         } else {
             CB_WAIT_VMCNT(0);
         }
+        // (the barrier intrinsic is not a memory operation to LLVM: the empty asm statements keep the compiler from moving the fragment
+        // ds_reads below above it, or the previous tile's LDS accesses below it -- ADVICE r4)
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();                               // ... for every wave's share
+        asm volatile("" ::: "memory");
 
         f32x4 acc[FM][FN];
 #pragma unroll
@@ -189,8 +193,14 @@ __global__ void __launch_bounds__(256, OCC) gemm_stream_kernel(GP p) {
 // epilogue-operand prefetch runs that one at 5.5 TB/s).
 constexpr int STREAM_VARIANTS = 2;
 inline int stream_workgroups_per_cu(int) { return 2; }
-inline unsigned stream_cus() {
-    static const unsigned n = getenv("CB_GEMM_STREAM_CUS") && atoi(getenv("CB_GEMM_STREAM_CUS")) > 0 ? (unsigned)atoi(getenv("CB_GEMM_STREAM_CUS")) : 256u;
+inline unsigned stream_cus() {                                  // CUs of the current device (MI355X: 256); CB_GEMM_STREAM_CUS overrides
+    static const unsigned n = [] {
+        if (getenv("CB_GEMM_STREAM_CUS") && atoi(getenv("CB_GEMM_STREAM_CUS")) > 0) return (unsigned)atoi(getenv("CB_GEMM_STREAM_CUS"));
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            return (unsigned)cus;
+        return 256u;
+    }();
     return n;
 }
 

@@ -30,13 +30,17 @@ struct StemP {
     int N, Hp, Wp, OH, OW, PH, PW, tiles_h, tiles_w, ntiles;
 };
 
-template <int DUMMY>
-__global__ void __launch_bounds__(256, 2) stem_pool_kernel(StemP p) {
+// NT threads: 256 (4 waves: each owns 16 channels and all 19 row fragments) or 512 (8 waves: the two wave groups split the row fragments
+// -- twice the waves per SIMD to hide the LDS / MFMA latency chains of a tile; same LDS footprint).
+template <int NT>
+__global__ void __launch_bounds__(NT, 2) stem_pool_kernel(StemP p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[IR * IP + NFRAG * 16 * PC];
     unsigned char* const Is = smem;
     unsigned char* const Cs = smem + IR * IP;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_id & 3, half = wave_id >> 2;         // channel slice; row-fragment half (NT = 512)
+    constexpr int HALF_FRAGS = NT == 512 ? 10 : NFRAG + 1;     // fragments per wave group (even: two per trip)
     const int lr = lane & 15, lq = lane >> 4;
     bf16x8 wf[7];
 #pragma unroll
@@ -44,36 +48,44 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(StemP p) {
     const int cA = 16 * wave + 4 * lq;
     const f32x4 sc = load4(p.scale + cA), sh = load4(p.shift + cA);
 
+    // input tile of `tile` -> registers (rows / pixels outside the packed image: zeros; they only feed convolution pixels outside the map)
+    constexpr int TOTAL = IR * ICH, ITERS = (TOTAL + NT - 1) / NT;
+    auto fetch = [&](int tile, u32x4 (&v)[ITERS]) __attribute__((always_inline)) {
+        const int tw = tile % p.tiles_w, rest = tile / p.tiles_w;
+        const int th = rest % p.tiles_h, n = rest / p.tiles_h;
+        const int iy0 = 2 * (2 * th * PT - 1), ix0 = 2 * (2 * tw * PT - 1);
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int idx = tid + it * NT;
+            const int gy = iy0 + idx / ICH, gx = ix0 + 2 * (idx % ICH);
+            const bool ok = tile < p.ntiles && idx < TOTAL && (unsigned)gy < (unsigned)p.Hp && gx >= 0 && gx + 1 < p.Wp;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            v[it] = z;
+            if (ok) v[it] = *reinterpret_cast<const u32x4*>(p.img + (((size_t)n * p.Hp + gy) * p.Wp + gx) * 4);
+        }
+    };
+    auto stash = [&](const u32x4 (&v)[ITERS]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int idx = tid + it * NT;
+            if (idx < TOTAL) *reinterpret_cast<u32x4*>(Is + (idx / ICH) * IP + (idx % ICH) * 16) = v[it];
+        }
+    };
+    u32x4 nxt[ITERS];
+    fetch(blockIdx.x, nxt);
+    stash(nxt);
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int tw = tile % p.tiles_w, rest = tile / p.tiles_w;
         const int th = rest % p.tiles_h, n = rest / p.tiles_h;
         const int ph0 = th * PT, pw0 = tw * PT;
         const int cy0 = 2 * ph0 - 1, cx0 = 2 * pw0 - 1;          // convolution pixel of tile position (0, 0)
-        const int iy0 = 2 * cy0, ix0 = 2 * cx0;                  // its first packed-image row / pixel (the packed image carries the padding)
-        // ---- 1. input tile -> LDS (rows / pixels outside the packed image: zeros; they only feed convolution pixels outside the map)
-        {
-            constexpr int TOTAL = IR * ICH, ITERS = (TOTAL + 255) / 256;
-            u32x4 v[ITERS];
-#pragma unroll
-            for (int it = 0; it < ITERS; ++it) {
-                const int idx = tid + it * 256;
-                const int ir = idx / ICH, cc = idx % ICH;
-                const int gy = iy0 + ir, gx = ix0 + 2 * cc;
-                const bool ok = idx < TOTAL && (unsigned)gy < (unsigned)p.Hp && gx >= 0 && gx + 1 < p.Wp;
-                u32x4 z = {0u, 0u, 0u, 0u};
-                v[it] = z;
-                if (ok) v[it] = *reinterpret_cast<const u32x4*>(p.img + (((size_t)n * p.Hp + gy) * p.Wp + gx) * 4);
-            }
-#pragma unroll
-            for (int it = 0; it < ITERS; ++it) {
-                const int idx = tid + it * 256;
-                if (idx < TOTAL) *reinterpret_cast<u32x4*>(Is + (idx / ICH) * IP + (idx % ICH) * 16) = v[it];
-            }
-        }
+        // ---- 1. the input tile is in LDS (stashed behind the previous tile's convolution); the NEXT tile's loads go out now and land
+        //         under this tile's convolution
+        fetch(tile + gridDim.x, nxt);
         __syncthreads();
         // ---- 2. the 17 x 17 convolution outputs of this wave's 16 channels: FrozenBN + ReLU, zero outside the map, bf16 -> LDS
 #pragma unroll 1
-        for (int i0 = 0; i0 < NFRAG + 1; i0 += 2) {
+        for (int i0 = half * HALF_FRAGS; i0 < (half + 1) * HALF_FRAGS && i0 < NFRAG; i0 += 2) {
             f32x4 acc[2];
             const unsigned char* base[2];
 #pragma unroll
@@ -106,10 +118,11 @@ __global__ void __launch_bounds__(256, 2) stem_pool_kernel(StemP p) {
             }
         }
         __syncthreads();
+        stash(nxt);                                              // (the convolution is done with the input tile: the next one moves in)
         // ---- 3. 3 x 3 / stride 2 max-pool out of LDS: thread <-> (pooled pixel, 8 channels), 16-byte stores, 128-byte runs per pixel
 #pragma unroll
-        for (int it = 0; it < PT * PT * 8 / 256; ++it) {
-            const int idx = tid + it * 256;
+        for (int it = 0; it < PT * PT * 8 / NT; ++it) {
+            const int idx = tid + it * NT;
             const int pix = idx >> 3, ch = idx & 7;
             const int py = pix >> 3, px = pix & 7;
             float m[8];
@@ -151,6 +164,8 @@ extern "C" int cb_stem_pool(const void* packed, const void* weight, const float*
     p.ntiles = (int)nt;
     const char* cap = getenv("CB_STEM_MAXWG");                // (tests: a few workgroups walk many tiles)
     const int max_wg = cap && atoi(cap) > 0 ? atoi(cap) : 512;
-    hipLaunchKernelGGL((stem_pool_kernel<0>), dim3((unsigned)(nt < max_wg ? nt : max_wg)), dim3(256), 0, cb_stream(stream), p);
+    static const bool four_waves = getenv("CB_STEM_4WAVE") != nullptr;          // diagnostic: the 256-thread form
+    if (four_waves) hipLaunchKernelGGL((stem_pool_kernel<256>), dim3((unsigned)(nt < max_wg ? nt : max_wg)), dim3(256), 0, cb_stream(stream), p);
+    else hipLaunchKernelGGL((stem_pool_kernel<512>), dim3((unsigned)(nt < max_wg ? nt : max_wg)), dim3(512), 0, cb_stream(stream), p);
     return cb_launch_status("cb_stem_pool");
 }

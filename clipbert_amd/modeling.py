@@ -1156,7 +1156,11 @@ class ClipBertForVideoTextRetrieval(_ClipBertHead):
         elif self.config.loss_type == "rank":
             # sigmoid margin ranking, modeling.py:567-575: rows of (1 positive + negatives) scores per video
             assert sample_size > 0
-            loss = head_loss_none(ops.LOSS_RANK, logits.reshape(sample_size, -1), group=logits.numel() // sample_size, margin=self.margin)
+            group = logits.numel() // sample_size
+            if group < 2:                      # no negatives: the reference's scores[:, 1:] is (B, 0) and so is its loss (modeling.py:572-575)
+                loss = logits.new_zeros((sample_size, 0), dtype=torch.float32)
+            else:
+                loss = head_loss_none(ops.LOSS_RANK, logits.reshape(sample_size, -1), group=group, margin=self.margin)
         else:
             raise ValueError("Invalid option for config.loss_type")
         return logits, loss

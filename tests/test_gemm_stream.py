@@ -70,7 +70,6 @@ def test_stream_is_chosen_for_the_hbm_bound_shapes_and_refused_elsewhere(hw):
     o = hw(torch.empty(max(M, 64), 256).bfloat16())
     if hw.name == "gpu":
         assert _plan(ops.gemm_desc(a, w, M, 256, 64, out=o))[0] == 8
-        os.environ["CB_GEMM_STREAM_MIN_ROWS"] = "1"             # (read once per process: only documents the switch)
     small = ops.gemm_desc(a[:64], w, 64, 256, 64, out=o[:64])
     assert _plan(small)[0] != 8                                 # few rows: one workgroup per tile
     bad = ops.gemm_desc(a[:64], hw(rnd(256, 512, seed=3).bfloat16()), 64, 256, 512, out=o[:64], tile=8)          # K = 512: not covered

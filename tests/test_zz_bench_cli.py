@@ -34,7 +34,8 @@ def test_supervisor_retries_with_the_next_plan_and_honours_the_done_marker(monke
     sys.path.insert(0, ROOT)
     import bench
     monkeypatch.setenv("TMPDIR", str(tmp_path))
-    monkeypatch.setattr(bench, "ATTEMPT_TIMEOUT_S", 3.0)
+    import bench_launch                                   # (the supervisor lives in tools/bench_launch.py since round 5; bench re-exports it)
+    monkeypatch.setattr(bench_launch, "ATTEMPT_TIMEOUT_S", 3.0)
     log = tmp_path / "log.txt"
 
     def job(script_for_attempt):
@@ -63,7 +64,7 @@ def test_supervisor_retries_with_the_next_plan_and_honours_the_done_marker(monke
     log.write_text("")
     marker = bench._marker("jobD2", 0, "r2.done")
     hang_after_done = note + f"open({marker!r}, 'w').write('x'); import time; time.sleep(600)"
-    monkeypatch.setattr(bench, "ATTEMPT_TIMEOUT_S", 300.0)
+    monkeypatch.setattr(bench_launch, "ATTEMPT_TIMEOUT_S", 300.0)
     t_start = __import__("time").perf_counter()
     assert bench._run_attempts(job([hang_after_done, note + "pass"]), 2, 2, "jobD2") == 0
     assert __import__("time").perf_counter() - t_start < 60 and log.read_text().split() == ["0:captured"]
@@ -72,7 +73,7 @@ def test_supervisor_retries_with_the_next_plan_and_honours_the_done_marker(monke
     open(bench._marker("jobE", 0, "failed"), "w").write("x")
     import time
     t0 = time.perf_counter()
-    monkeypatch.setattr(bench, "ATTEMPT_TIMEOUT_S", 60.0)
+    monkeypatch.setattr(bench_launch, "ATTEMPT_TIMEOUT_S", 60.0)
     assert bench._run_attempts(job([hang, note + "pass"]), 2, 1, "jobE") == 0
     assert time.perf_counter() - t0 < 20 and log.read_text().split() == ["0:captured", "1:split"]
 

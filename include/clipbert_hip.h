@@ -363,7 +363,8 @@ int cb_elu_bn1d_bwd(int32_t dtype, const void* dy, const void* x, const float* g
 
 const char* cb_last_error(void);
 /* ABI version: 1 = round 1-2; 2 = CB_HP_SKIP / CB_HP_COUNT 10 (cb_adamw*), cb_gemm_group, cb_gemm_workspace_bytes;
- * 3 = cb_gemm_desc.tile = 8 (the streaming structure; every earlier descriptor means what it meant), cb_head_loss, cb_retrieval_scores */
+ * 3 = cb_gemm_desc.tile = 8 (the streaming structure; every earlier descriptor means what it meant), cb_head_loss, cb_retrieval_scores;
+ * 4 = cb_res2_block, cb_stem_pool (round 5: the frozen front of the backbone as fused launches; nothing else changed) */
 int cb_version(void);
 
 /* ---- gradient exchange (one process per GPU, RCCL over xGMI) ----------------------------------------------------

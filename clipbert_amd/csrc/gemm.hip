@@ -41,6 +41,7 @@ extern template int launch_gemm<bf16, 128, 128, 1, 2>(const GP&, bool, hipStream
 extern template int launch_gemm_group<float, 64, 64, 2, 1>(const GroupArgs&, int, hipStream_t);
 extern template int launch_gemm_group<bf16, 64, 64, 3, 1>(const GroupArgs&, int, hipStream_t);
 extern template int launch_gemm_group<bf16, 128, 128, 1, 2>(const GroupArgs&, int, hipStream_t);
+extern template int launch_gemm_streamk<128, 128, 1, 2>(const StreamKArgs&, int, unsigned, hipStream_t);
 // 8-wave LDS-DMA structure (gemm8_impl.h), instantiated in gemm8_inst_*.hip
 #define CB_G8_DECL(BM, BN, WGM, WGN, NST)                                                             \
     extern template int launch_gemm8_fwd<BM, BN, WGM, WGN, NST>(const GP&, int, float*, hipStream_t);   \
@@ -567,6 +568,59 @@ int launch_group_chunk(std::vector<GroupItem*>& g, int dtype, int cls, hipStream
     static const bool no_remap = getenv("CB_GEMM_NO_XCD_REMAP") != nullptr;
     static const bool no_wide = getenv("CB_GEMM_NO_WIDE_EPILOGUE") != nullptr;
     static const bool trace = getenv("CB_GEMM_TRACE") != nullptr;
+    // ---- stream-K (round 5, OPT-IN: CB_GEMM_STREAMK=1): the weight gradients of a stage whose K split is free (fp32 gradient accumulated
+    // in place through atomics) as ONE persistent launch of two workgroups per CU, every workgroup the same number of K tiles
+    // (gemm_streamk_kernel).  Correct (tests/test_gemm_group.py, emulator and MI355X) and MEASURED SLOWER than the split-K grouped launches
+    // it was meant to replace: +0.24 ms per step with a tile-major unit line (no L2 sharing of a K range between concurrent workgroups),
+    // +0.15 ... +0.25 ms with K chunks of 1 - 2 workgroup shares, +0.5 / +1.0 ms with shorter chunks (profiles/r05n_streamk_ab.txt).  Every
+    // cut a workgroup's share makes inside a (chunk, tile) piece is one more 64 KB burst of memory-side fp32 atomics (27-30 us of a
+    // workgroup's life, profiles/r05a_stamps_before.md), and the shares of a heterogeneous group never line up with the pieces: balance
+    // gained, atomics doubled.  Kept as a switch; the split-K grouped launch stays the default.
+    {
+        static const bool want_sk = getenv("CB_GEMM_STREAMK") != nullptr && atoi(getenv("CB_GEMM_STREAMK")) != 0;
+        bool ok = want_sk && dtype == CB_BF16 && (cls == GC_WGRAD || cls == GC_WGRAD_GATHER) && g[0]->d->tile == 0;
+        for (auto* it : g) ok = ok && split_is_free(it->d) && it->pr.p.c_vec && it->d->N > 64 && it->d->M > 64 && it->pr.p.batch == 1;
+        if (ok) {
+            StreamKArgs sa{};
+            sa.n = (int)g.size();
+            long long acc = 0;
+            int xcd = 0;
+            for (size_t i = 0; i < g.size(); ++i) {
+                const cb_gemm_desc* d = g[i]->d;
+                GP p = g[i]->pr.p;
+                p.c_vec8 = 0;
+                if (d->xcd_order != 0) xcd = d->xcd_order;
+                acc += (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * p.ktiles;
+                sa.unit_end[i] = (int)acc;
+                sa.g[i] = p;
+                if (trace) fprintf(stderr, "cb_gemm_group[%zu/%zu]: M=%d N=%d K=%d modes=%d/%d cls=%d stream-K units %lld\n", i, g.size(), d->M, d->N, d->K, d->a_mode,
+                                   d->b_mode, cls, acc);
+            }
+            CB_REQUIRE(acc < (1ll << 31), "cb_gemm_group: too many K-tile units");
+            sa.xcd_remap = !no_remap && xcd != 2;
+            static const unsigned cus_ = [] {
+                int dev = 0, n = 0;
+                return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? (unsigned)n : 256u;
+            }();
+            const char* cap = getenv("CB_GEMM_STREAMK_WG");             // (tests: few workgroups, many segments each)
+            unsigned wgs = cap && atoi(cap) > 0 ? (unsigned)atoi(cap) : 2u * cus_;
+            if ((long long)wgs * 4 > acc) wgs = (unsigned)((acc + 3) / 4);       // (at least ~4 K tiles per workgroup)
+            if (wgs < 1) wgs = 1;
+            // K chunks of about one workgroup's share: a workgroup's range is then (mostly) one chunk of a few neighbouring tiles
+            const long long share = (acc + wgs - 1) / wgs;
+            const char* kcs = getenv("CB_GEMM_STREAMK_CHUNK");          // diagnostic: chunk length in units of the share (default 1.0)
+            const double chunk_scale = kcs ? atof(kcs) : 1.0;
+            for (size_t i = 0; i < g.size(); ++i) {
+                const int kt = sa.g[i].ktiles;
+                long long kc = (long long)(share * chunk_scale + 0.5);
+                if (kc < 4) kc = 4;
+                int nchunks = (int)((kt + kc - 1) / kc);
+                if (nchunks < 1) nchunks = 1;
+                sa.kchunk[i] = (kt + nchunks - 1) / nchunks;             // equal chunks (the last one at most nchunks - 1 tiles shorter)
+            }
+            return launch_gemm_streamk<128, 128, 1, 2>(sa, cls, wgs, st);
+        }
+    }
     int splits[GROUP_MAX];
     int tile = 2;
     if (dtype == CB_F32) {

@@ -1154,8 +1154,10 @@ __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 
 // OCC = blocks per CU the register allocation must leave room for (__launch_bounds__'s second argument counts waves per SIMD;
 // a 256-thread block puts one wave on each SIMD)
 // One output tile of one problem: everything a workgroup of gemm_kernel / gemm_group_kernel does once it knows its (problem, tile).
-template <typename T, int BM, int BN, typename LA, typename LB, int PF, bool RS, int OCC>
-__device__ __forceinline__ void gemm_tile(GP& p, TileId bid) {
+// KRANGE: the K tiles [kt0_in, kt0_in + nt_in) of the output tile instead of the bid.bz-th of p.split_k equal parts (stream-K: a
+// workgroup's share of a tile is whatever its unit range cuts out of it)
+template <typename T, int BM, int BN, typename LA, typename LB, int PF, bool RS, int OCC, bool KRANGE = false>
+__device__ __forceinline__ void gemm_tile(GP& p, TileId bid, int kt0_in = 0, int nt_in = 0) {
     using X = Tr<T>;
     constexpr int BK = X::BK;
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
@@ -1173,8 +1175,8 @@ __device__ __forceinline__ void gemm_tile(GP& p, TileId bid) {
     apply_batch(p, bid);
     const int m0 = bid.by * BM, n0 = bid.bx * BN;
     const int kt_per = (p.ktiles + p.split_k - 1) / p.split_k;
-    const int kt0 = bid.bz * kt_per;
-    const int nt = ((kt0 + kt_per < p.ktiles) ? kt0 + kt_per : p.ktiles) - kt0;
+    const int kt0 = KRANGE ? kt0_in : bid.bz * kt_per;
+    const int nt = KRANGE ? nt_in : ((kt0 + kt_per < p.ktiles) ? kt0 + kt_per : p.ktiles) - kt0;
     if (nt <= 0) return;
 
     LA la;
@@ -1395,6 +1397,67 @@ __global__ void __launch_bounds__(256, OCC) gemm_group_kernel(GroupArgs ga) {
     const int pi = group_locate<BM, BN>(ga, bid);
     GP p = ga.g[pi];
     gemm_tile<T, BM, BN, LA, LB, PF, RS, OCC>(p, bid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stream-K form of the grouped WEIGHT-GRADIENT launch (round 5).  The split-K launches above give every output tile `split` equal K
+// parts: 6 x 16 tiles x 8 parts = 768 workgroups for two rounds of 512 resident ones (the second round starts 60-115 us into a 105-170 us
+// launch, profiles/r05a_stamps_before.md), and every part ends with a 64 KB burst of fp32 atomics (27-30 us per launch).  Here the launch is
+// PERSISTENT: the work of all problems is one line of units (one K tile of one output tile, tile-major), workgroup g of G owns the units
+// [g U / G, (g + 1) U / G) and walks them -- a tile's K range is cut only where a workgroup's share ends.  Every workgroup does the same
+// number of K tiles (no second round, no tail), and the number of atomics epilogues drops from tiles x split to ~tiles + G.  The partial
+// products combine through the same fp32 atomics as the split-K path (zero-initialised gradient buffer, order-independent up to fp32
+// rounding -- exactly the semantics the convolution weight gradients already had).
+// ---------------------------------------------------------------------------------------------
+struct StreamKArgs {
+    int n, xcd_remap;
+    int unit_end[GROUP_MAX];          // problem i owns units [unit_end[i-1], unit_end[i]): its tiles x its K tiles
+    int kchunk[GROUP_MAX];            // K tiles per chunk of problem i (see the unit order below)
+    GP g[GROUP_MAX];
+};
+static_assert(sizeof(StreamKArgs) + 256 <= 4096, "kernel arguments (+ the hidden ones) are limited to 4 KiB");
+
+// Unit order inside a problem: (K chunk, tile, K tile inside the chunk).  Workgroups with neighbouring unit ranges therefore work on
+// NEIGHBOURING TILES OVER THE SAME K RANGE at the same time and share the operand rows of that range in L2 -- what the split-K launch
+// order gave for free; a plain tile-major line (every workgroup a different K range of a different tile) streamed every operand byte
+// from HBM once per tile and measured 0.24 ms SLOWER per step than split-K (profiles/r05m_streamk_ab.txt).  The chunk length is about
+// one workgroup's share, so most segments are whole (chunk, tile) pieces.
+template <typename T, int BM, int BN, typename LA, typename LB, int PF, int OCC>
+__global__ void __launch_bounds__(256, OCC) gemm_streamk_kernel(StreamKArgs ga) {
+    const unsigned G = gridDim.x;
+    unsigned wg = blockIdx.x;
+    if (ga.xcd_remap) {                                     // consecutive unit ranges on one XCD (its L2 sees a K range's operands once)
+        const unsigned xcd = wg & 7u, i = wg >> 3;
+        const unsigned q = G >> 3, r = G & 7u;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    const long long U = ga.unit_end[ga.n - 1];
+    long long u = U * wg / G;
+    const long long u1 = U * (wg + 1) / G;
+    int pi = 0;
+    while (u < u1) {
+        while (pi + 1 < ga.n && u >= ga.unit_end[pi]) ++pi;
+        GP p = ga.g[pi];
+        const long long local = u - (pi > 0 ? ga.unit_end[pi - 1] : 0);
+        const unsigned gx = (unsigned)((p.N + BN - 1) / BN), gy = (unsigned)((p.M + BM - 1) / BM);
+        const long long tiles = (long long)gx * gy;
+        const int kc = ga.kchunk[pi];
+        const long long per_chunk = tiles * kc;
+        const int chunk = (int)(local / per_chunk);
+        const long long within = local - (long long)chunk * per_chunk;
+        const int klen = (chunk + 1) * kc <= p.ktiles ? kc : p.ktiles - chunk * kc;       // (the last chunk may be shorter)
+        const int tile = (int)(within / klen), kk = (int)(within - (long long)tile * klen);
+        long long len = klen - kk;
+        if (len > u1 - u) len = u1 - u;
+        TileId bid;
+        bid.bx = (int)((unsigned)tile % gx);
+        bid.by = (int)((unsigned)tile / gx);
+        bid.bz = 0;
+        p.split_k = 2;                                      // (any value > 1: partial products leave through the atomics epilogue)
+        gemm_tile<T, BM, BN, LA, LB, PF, false, OCC, true>(p, bid, chunk * kc + kk, (int)len);
+        __syncthreads();                                    // the next segment's first K tile overwrites the LDS the epilogue staged through
+        u += len;
+    }
 }
 
 // =============================================================================================
@@ -1727,6 +1790,15 @@ enum { GC_WGRAD = 0,        // A KROW, B KROW            (weight gradient of a L
        GC_FWD = 2,          // A ROWK, B ROWK            (Linear / 1x1 stride-1 convolution forward)
        GC_FWD_GATHER = 3,   // A ROWK_GATHER, B ROWK     (convolution forward)
        GC_COUNT = 4 };
+
+// stream-K launcher: bf16 weight-gradient classes only (A KROW, B KROW | KROW_GATHER, transpose-read loaders)
+template <int BM, int BN, int PF, int OCC>
+int launch_gemm_streamk(const StreamKArgs& ga, int cls, unsigned workgroups, hipStream_t st) {
+    using KA = KrowTr<BM, KM_PLAIN>; using KB0 = KrowTr<BN, KM_PLAIN>; using KB2 = KrowTr<BN, KM_GATHER>;
+    if (cls == GC_WGRAD) hipLaunchKernelGGL((gemm_streamk_kernel<bf16, BM, BN, KA, KB0, PF, OCC>), dim3(workgroups), dim3(NTHREADS), 0, st, ga);
+    else hipLaunchKernelGGL((gemm_streamk_kernel<bf16, BM, BN, KA, KB2, PF, OCC>), dim3(workgroups), dim3(NTHREADS), 0, st, ga);
+    return cb_launch_status("cb_gemm_group (stream-K)");
+}
 
 template <typename T, int BM, int BN, int PF, int OCC>
 int launch_gemm_group(const GroupArgs& ga, int cls, hipStream_t st) {

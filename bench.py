@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak (2:1 sparsity excluded)
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04z_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05z_pmc_traffic.json")
 
 BASE_CONFIG = dict(
     max_temporal_position_embeddings=100, backbone_channel_in_size=2048, max_grid_row_position_embeddings=100,
@@ -660,7 +660,7 @@ def measure_roofline(step_fn, pmc_ok=True, ms_per_step=None):
     except Exception:
         traffic = None
     hbm = dom["bound"] == "hbm"
-    out = {"bound": dom["bound"], "kernel": f"cb_gemm<bf16> {dom_name}", "launches": dom["launches"], "avg_launch_us": dom["avg_launch_us"],
+    out = {"bound": dom["bound"], "kernel": f"cb_gemm<bf16> {dom_name}" if not dom_name.startswith("fused") else dom_name, "launches": dom["launches"], "avg_launch_us": dom["avg_launch_us"],
            "achieved": dom["gbs"] if hbm else dom["tflops"], "peak": gemm_log.HBM_PEAK_GBS if hbm else BF16_MFMA_PEAK_TFLOPS,
            "unit": "GB/s" if hbm else "TFLOP/s", "frac": dom["frac"],
            "traffic": traffic, "traffic_unit": f"HBM bytes per launch (PMC, {os.path.relpath(PMC_TRAFFIC_FILE, ROOT)})",

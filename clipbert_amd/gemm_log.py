@@ -9,6 +9,9 @@ Families (reference functions: SURVEY.md a3 / a10-a14; shapes: Appendix B / C):
   resnet 1x1 conv, K > 256          res4 / res5 1x1 convolutions                                                 -> bf16 MFMA roof
   conv 3x3 / 7x7 (fwd + dgrad)      implicit-GEMM convolutions (pixel gather), grid_feat.py:43-48 + the stem     -> bf16 MFMA roof
   weight gradients                  every wgrad form (batched encoder layers, ResNet stages through cb_gemm_group) -> bf16 MFMA roof
+  fused frozen front                round 5: cb_stem_pool (7x7 convolution + FrozenBN + ReLU + max-pool) and cb_res2_block (a res2 bottleneck
+                                    block per launch): their 64-channel intermediates never leave the CU, what remains is input + output  -> HBM roof
+                                    (algorithmic flops = the convolutions' 2*M*N*K, algorithmic bytes = the block's input once + its output once)
 """
 from typing import Callable, Dict, List
 
@@ -25,7 +28,9 @@ FAMILY_BOUND = {
     "resnet 1x1 conv, K > 256 (fwd + dgrad)": "mfma",
     "conv 3x3 / 7x7 (fwd + dgrad)": "mfma",
     "weight gradients (linear + conv)": "mfma",
+    "fused frozen front: stem + res2 blocks (fwd)": "hbm",
 }
+FUSED = "fused frozen front: stem + res2 blocks (fwd)"
 
 
 def _problem(d) -> dict:
@@ -69,6 +74,24 @@ class GemmLog:
 
     def __enter__(self):
         self._gemm, self._group = ops.gemm, ops.gemm_group
+        self._stem, self._res2 = ops.stem_pool, ops.res2_block
+
+        def stem_pool(packed, weight, scale, shift, oh, ow):
+            n, hp, wp, _ = packed.shape
+            m = n * oh * ow
+            pooled = n * ((oh - 1) // 2 + 1) * ((ow - 1) // 2 + 1)
+            prob = {"family": FUSED, "flop": 2.0 * m * 64 * 147, "bytes": float(packed.numel() * 2 + pooled * 64 * 2), "M": m, "N": 64, "K": 147, "batch": 1,
+                    "taps": 49, "form": "fwd"}
+            self.launches.append({"problems": [prob], "replay": (lambda: self._stem(packed, weight, scale, shift, oh, ow))})
+            return self._stem(packed, weight, scale, shift, oh, ow)
+
+        def res2_block(x, w1, w2, w3, ss1, ss2, ss3, wsc=None, sssc=None):
+            n, h, w, cin = x.shape
+            m = n * h * w
+            kk = cin * 64 + 9 * 64 * 64 + 64 * 256 + (cin * 256 if wsc is not None else 0)
+            prob = {"family": FUSED, "flop": 2.0 * m * kk, "bytes": float(m * (cin + 256) * 2), "M": m, "N": 256, "K": kk // 256, "batch": 1, "taps": 9, "form": "fwd"}
+            self.launches.append({"problems": [prob], "replay": (lambda: self._res2(x, w1, w2, w3, ss1, ss2, ss3, wsc=wsc, sssc=sssc))})
+            return self._res2(x, w1, w2, w3, ss1, ss2, ss3, wsc=wsc, sssc=sssc)
 
         def gemm(a, b, M, N, K, **kw):
             d = ops.gemm_desc(a, b, M, N, K, **kw)
@@ -82,10 +105,12 @@ class GemmLog:
             return self._group(descs, like)
 
         ops.gemm, ops.gemm_group = gemm, gemm_group
+        ops.stem_pool, ops.res2_block = stem_pool, res2_block
         return self
 
     def __exit__(self, *exc):
         ops.gemm, ops.gemm_group = self._gemm, self._group
+        ops.stem_pool, ops.res2_block = self._stem, self._res2
         return False
 
     def by_family(self) -> Dict[str, List[dict]]:

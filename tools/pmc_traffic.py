@@ -35,7 +35,7 @@ def gemm_dispatches(d):
         if "splitk_reduce_kernel" in name:
             if g:
                 g[-1][1] += val
-        elif "gemm_kernel" in name or "gemm8_kernel" in name or "gemm_dma_kernel" in name or "gemm_group_kernel" in name or "gemm8p_kernel" in name or "gemm_stream_kernel" in name:
+        elif "gemm_kernel" in name or "gemm8_kernel" in name or "gemm_dma_kernel" in name or "gemm_group_kernel" in name or "gemm8p_kernel" in name or "gemm_stream_kernel" in name or "gemm_streamk_kernel" in name or "res2_block_kernel" in name or "stem_pool_kernel" in name:       # (round 5: the fused front-end launches are logged calls too)
             g.append([name, val])
     return g
 

@@ -68,7 +68,8 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", defines
 if __name__ == "__main__":
     if "--variant" in sys.argv:                    # python -m clipbert_amd.build --variant NAME --csrc DIR
         i = sys.argv.index("--variant")
-        print(build(verbose=True, variant=sys.argv[i + 1], csrc=sys.argv[sys.argv.index("--csrc") + 1] if "--csrc" in sys.argv else ""))
+        defs = tuple(sys.argv[j + 1] for j, a in enumerate(sys.argv) if a == "--define")        # ... [--define MACRO]...
+        print(build(verbose=True, variant=sys.argv[i + 1], defines=defs, csrc=sys.argv[sys.argv.index("--csrc") + 1] if "--csrc" in sys.argv else ""))
     elif "--stamps" in sys.argv:
         print(build(force="--force" in sys.argv, verbose=True, variant="stamps", defines=("CB_STAMPS",)))
     else:

@@ -42,24 +42,32 @@ __device__ __forceinline__ void store4(bf16* p, f32x4 v) {
 }
 
 // ---- activations -----------------------------------------------------------------------------
-// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32 round-off level): one exp + one rcp + 6 FMAs
-// instead of libm's branchy erff -- the exact-erf GELU sits in the epilogue of the largest GEMM of every layer.
-__device__ __forceinline__ float fast_erf(float x) {
-    const float ax = fabsf(x);
-    const float t = 1.0f / (1.0f + 0.3275911f * ax);
+// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32 round-off level): erfc(z) = q(t) exp(-z^2), t = 1 / (1 + p z), z >= 0.
+// One v_exp_f32 + one v_rcp_f32 (1 ulp; an IEEE division is ten instructions) + 6 FMAs instead of libm's branchy erff -- the exact-erf
+// GELU sits in the epilogue of the largest GEMM of every layer, where the stamps showed ~30 VALU instructions per element = 7 us of a 30 us
+// launch (profiles/r05r).  The GELU derivative shares ONE exponential between the cdf and the pdf: exp(-(x/sqrt 2)^2) = exp(-x^2/2).
+__device__ __forceinline__ float as_erfc_poly(float az) {       // erfc(az) / exp(-az^2), az >= 0
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * az);
     float p = 1.061405429f;
     p = p * t - 1.453152027f;
     p = p * t + 1.421413741f;
     p = p * t - 0.284496736f;
     p = p * t + 0.254829592f;
-    const float r = 1.0f - p * t * __expf(-ax * ax);
+    return p * t;
+}
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float r = 1.0f - as_erfc_poly(ax) * __expf(-ax * ax);
     return x < 0.f ? -r : r;
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float hq = 0.5f * as_erfc_poly(fabsf(x) * 0.70710678118654752f) * __expf(-0.5f * x * x);      // erfc(|x| / sqrt 2) / 2
+    return x * (x < 0.f ? hq : 1.0f - hq);
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f));
-    float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    const float e = __expf(-0.5f * x * x);
+    const float hq = 0.5f * as_erfc_poly(fabsf(x) * 0.70710678118654752f) * e;
+    return (x < 0.f ? hq : 1.0f - hq) + x * (0.3989422804014327f * e);
 }
 __device__ __forceinline__ float apply_act(int act, float v) {
     switch (act) {

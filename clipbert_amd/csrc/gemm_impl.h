@@ -833,6 +833,13 @@ __device__ __forceinline__ void zero_patch8(T* base, int64_t ld, int64_t orow, i
 }
 
 // EPF: the residual / (mask | GELU pre-activation) chunk was fetched before the K loop (epi_prefetch) -- rpre / apre hold it.
+// Diagnostic builds only (tools/r05r_call.sh): CB_EPI_NOSTORE keeps every instruction of the epilogue but its global stores (a condition
+// no launch meets guards them); CB_EPI_NOMATH stores the raw accumulators.  Neither is defined in the product library.
+#ifdef CB_EPI_NOSTORE
+#define CB_EPI_ST(...) do { if (p.alpha == 12345.f) { __VA_ARGS__; } } while (0)
+#else
+#define CB_EPI_ST(...) do { __VA_ARGS__; } while (0)
+#endif
 template <typename T, int EPF = 0>
 __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const float (&sc)[8], const float (&sh)[8],
                                           int m, int64_t orow, int n, bf16x8 rpre = bf16x8{}, bf16x8 apre = bf16x8{}) {
@@ -848,6 +855,15 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
             for (int r = 0; r < 8; ++r) t[r] = (float)apre[r];
         } else load8(reinterpret_cast<const T*>(base) + orow * ld + n, t);
     };
+#ifdef CB_EPI_NOMATH
+    if constexpr (sizeof(T) == 2) {
+        if (!p.c_f32 && p.wt) {
+            store8_wt(p.C, orow * p.ldc + n, v);
+            if (p.C2) store8_wt(p.C2, orow * p.ldc2 + n, v);
+            return;
+        }
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] *= p.alpha;
     if (p.relu_bwd) {          // t = (acc [+ C] [+ residual]) where mask > 0;  C2 = t * post_scale2,  C = t * post_scale
@@ -877,9 +893,9 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
                 for (int r = 0; r < 8; ++r) u[r] = v[r];
             }
             if constexpr (sizeof(T) == 2) {
-                if (p.wt) store8_wt(p.C2, orow * p.ldc2 + n, u);
-                else store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, u);
-            } else store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, u);
+                if (p.wt) CB_EPI_ST(store8_wt(p.C2, orow * p.ldc2 + n, u));
+                else CB_EPI_ST(store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, u));
+            } else CB_EPI_ST(store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, u));
         }
         if (p.post_scale) {
             load8(p.post_scale + n, t);
@@ -887,9 +903,9 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
             for (int r = 0; r < 8; ++r) v[r] *= t[r];
         }
         if constexpr (sizeof(T) == 2) {
-            if (p.wt) store8_wt(p.C, orow * p.ldc + n, v);
-            else store8(c, v);
-        } else store8(c, v);
+            if (p.wt) CB_EPI_ST(store8_wt(p.C, orow * p.ldc + n, v));
+            else CB_EPI_ST(store8(c, v));
+        } else CB_EPI_ST(store8(c, v));
         if (p.zfill) {
             zero_patch8(reinterpret_cast<T*>(p.C), p.ldc, orow, n, p.zfill);
             if (p.C2) zero_patch8(reinterpret_cast<T*>(p.C2), p.ldc2, orow, n, p.zfill);
@@ -906,10 +922,10 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
     }
     if (p.C2) {
         if constexpr (sizeof(T) == 2) {
-            if (p.wt & 2) store8_wt<18 /* sc1 + nt: the pre-activation is next read in the backward */>(p.C2, orow * p.ldc2 + n, v);
-            else if (p.wt) store8_wt(p.C2, orow * p.ldc2 + n, v);
-            else store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, v);
-        } else store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, v);
+            if (p.wt & 2) CB_EPI_ST(store8_wt<18 /* sc1 + nt: the pre-activation is next read in the backward */>(p.C2, orow * p.ldc2 + n, v));
+            else if (p.wt) CB_EPI_ST(store8_wt(p.C2, orow * p.ldc2 + n, v));
+            else CB_EPI_ST(store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, v));
+        } else CB_EPI_ST(store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, v));
     }
     if (p.act != CB_ACT_NONE) {
 #pragma unroll
@@ -950,7 +966,7 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] += t[r];
         }
-        store8(c, v);
+        CB_EPI_ST(store8(c, v));
     } else {
         T* c = reinterpret_cast<T*>(p.C) + orow * p.ldc + n;
         if (p.accumulate) {
@@ -960,9 +976,9 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
             for (int r = 0; r < 8; ++r) v[r] += t[r];
         }
         if constexpr (sizeof(T) == 2) {
-            if (p.wt) store8_wt(p.C, orow * p.ldc + n, v);
-            else store8(c, v);
-        } else store8(c, v);
+            if (p.wt) CB_EPI_ST(store8_wt(p.C, orow * p.ldc + n, v));
+            else CB_EPI_ST(store8(c, v));
+        } else CB_EPI_ST(store8(c, v));
     }
     if (p.zfill) {
         if (p.c_f32) zero_patch8(reinterpret_cast<float*>(p.C), p.ldc, orow, n, p.zfill);
@@ -1363,7 +1379,11 @@ __global__ void __launch_bounds__(256, OCC) gemm_kernel(GP p) {
 // problem by a scan over the prefix sums and then runs exactly gemm_kernel's tile code.  A launch of many small problems fills
 // the chip where each of them alone is a fraction of a round of workgroups, and the problems' cold starts / store tails overlap.
 // ---------------------------------------------------------------------------------------------
+#ifdef CB_STAMPS
+constexpr int GROUP_MAX = 9;          // (diagnostic build: GP carries the stamp pointer; the argument block must stay under 4 KiB)
+#else
 constexpr int GROUP_MAX = 10;
+#endif
 struct GroupArgs {
     int n, xcd_remap;
     int tile_end[GROUP_MAX];          // problem i owns workgroups [tile_end[i-1], tile_end[i])

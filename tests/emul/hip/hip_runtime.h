@@ -291,6 +291,7 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetc
 
 // ---- math ----------------------------------------------------------------------------------
 #define __expf(x) expf(x)
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 #define __logf(x) logf(x)
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __fdividef(float a, float b) { return a / b; }

@@ -32,11 +32,12 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "stamps"))
     ap.add_argument("--replays", type=int, default=6)
     ap.add_argument("--videos", type=int, default=16)
+    ap.add_argument("--lib", default="stamps", help="library variant (a CB_STAMPS build): lib/libclipbert_hip_<lib>.so")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     from clipbert_amd import _lib
     from clipbert_amd.build import variant_path
-    path = variant_path("stamps")
+    path = variant_path(a.lib)
     lib = _lib.load(path)
     _lib._LIB = lib                                   # every ops.* call of this process goes to the diagnostic build
     lib.cb_debug_stamps_begin.argtypes = [C.c_void_p, C.c_int64]

@@ -40,6 +40,20 @@ def gemm_dispatches(d):
     return g
 
 
+def xcd_floor(p):
+    """Bytes a product must move when 8 non-coherent L2s each serve 1/8 of the tiles: every XCD fetches the operand panels its tiles touch.
+    With the tiles of an XCD forming an (M / xm) x (N / xn) block (xm * xn = 8), A is fetched xn times and B xm times; outputs and epilogue
+    operands once.  The best split is the floor; a launch cannot do better without cross-XCD sharing, whatever its tile order.  (1x1 /
+    linear forms only: K = the reduction length, A = M x K, B = N x K in bf16.)"""
+    if p["taps"] != 1:
+        return None
+    a, b = 2.0 * p["M"] * p["K"] * p["batch"], 2.0 * p["N"] * p["K"] * p["batch"]
+    rest = max(0.0, p["bytes"] - a - b)
+    if p["form"] == "wgrad":                 # the reduction is the long axis: an XCD can own a K range instead (split-K), no operand re-read
+        return p["bytes"]
+    return rest + min(a * xn + b * xm for xm, xn in ((8, 1), (4, 2), (2, 4), (1, 8)))
+
+
 def main():
     calls = json.load(open(sys.argv[1]))
     fetch = per_dispatch(sys.argv[2], "FETCH_SIZE")
@@ -49,7 +63,7 @@ def main():
     assert len(gf) == nk == len(gw), (len(gf), len(gw), nk)
 
     def new():
-        return dict(launches=0, kernels=0, problems=0, fetch_kib=0.0, write_kib=0.0, algorithmic_bytes=0.0, flop=0.0)
+        return dict(launches=0, kernels=0, problems=0, fetch_kib=0.0, write_kib=0.0, algorithmic_bytes=0.0, flop=0.0, floor=0.0, floor_ok=True)
     fam, form = collections.defaultdict(new), collections.defaultdict(new)
     pos = 0
     for c in calls:
@@ -63,6 +77,11 @@ def main():
             a["launches"] += 1; a["kernels"] += c["kernels"]; a["problems"] += len(c["problems"])
             a["fetch_kib"] += f; a["write_kib"] += w
             a["algorithmic_bytes"] += sum(p["bytes"] for p in c["problems"]); a["flop"] += sum(p["flop"] for p in c["problems"])
+            fl = [xcd_floor(p) for p in c["problems"]]
+            if any(x is None for x in fl):
+                a["floor_ok"] = False
+            else:
+                a["floor"] += sum(fl)
 
     def table(t):
         out = {}
@@ -73,11 +92,15 @@ def main():
                       "algorithmic_bytes_per_launch": round(a["algorithmic_bytes"] / n), "hbm_over_algorithmic": round(hbm / a["algorithmic_bytes"], 2),
                       "hbm_mbytes_per_step": round(hbm / 1e6, 1), "algorithmic_mbytes_per_step": round(a["algorithmic_bytes"] / 1e6, 1),
                       "fetch_kib_raw_per_launch": round(a["fetch_kib"] / n, 1), "write_kib_per_launch": round(a["write_kib"] / n, 1),
-                      "flop_per_launch": round(a["flop"] / n)}
+                      "flop_per_launch": round(a["flop"] / n),
+                      "xcd_floor_over_algorithmic": round(a["floor"] / a["algorithmic_bytes"], 2) if a["floor_ok"] else None,
+                      "hbm_over_xcd_floor": round(hbm / a["floor"], 2) if a["floor_ok"] else None}
         return out
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python tools/gemm_breakdown.py "
                      "(one eager training step of the bench workload)",
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (KiB counters; gfx950 FETCH_SIZE counts 64 B per 128 B request)",
+           "xcd_floor": "bytes a product moves at best when 8 non-coherent L2s each serve 1/8 of its tiles (tools/pmc_traffic.py: xcd_floor); "
+                        "1x1 / linear families only",
            "families": table(fam), "by_form": table(form)}
     ad_f = [x[1] for x in fetch if "adamw" in x[0]]
     ad_w = [x[1] for x in write if "adamw" in x[0]]
@@ -94,7 +117,7 @@ def main():
     for k, v in out["families"].items():
         print(k, v)
     for k, v in out["by_form"].items():
-        print(k, {kk: v[kk] for kk in ("launches_in_trace", "hbm_over_algorithmic", "hbm_mbytes_per_step")})
+        print(k, {kk: v[kk] for kk in ("launches_in_trace", "hbm_over_algorithmic", "xcd_floor_over_algorithmic", "hbm_over_xcd_floor", "hbm_mbytes_per_step")})
     print(out.get("calibration_adamw"), out.get("fills"))
 
 

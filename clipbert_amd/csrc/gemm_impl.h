@@ -1122,7 +1122,11 @@ __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 
                     const int64_t orow = p.c_rowmap ? (int64_t)p.c_rowmap[m] : (int64_t)m;
                     float x = *reinterpret_cast<const float*>(smem + rl * SROW + cl * 4) * p.alpha;
                     if (p.scale) x *= p.scale[n];
+#ifdef CB_EPI_NOATOMIC                   /* diagnostic build (tools/r05w_call.sh): what the split-K atomics cost -- plain stores, WRONG sums */
+                    cbase[orow * p.ldc + n] = x;
+#else
                     atomicAdd(cbase + orow * p.ldc + n, x);
+#endif
                 }
             }
         }

@@ -526,6 +526,27 @@ bool split_is_free(const cb_gemm_desc* d) {
 
 struct GroupItem { const cb_gemm_desc* d; Prepared pr; int cls; int split; };
 
+// Arrival counters of the slab K split (gemm_tile): 16 K zeroed ints per device, owned by the library, allocated on first use OUTSIDE a
+// stream capture (a capture that comes first keeps the atomics path for that launch); every launch leaves them zero.
+constexpr int GROUP_COUNTERS = 16384;
+int* group_counters(hipStream_t st) {
+    static int* buf[32] = {};
+    static bool failed[32] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    if (buf[dev] || failed[dev]) return buf[dev];
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    int* ptr = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&ptr), GROUP_COUNTERS * sizeof(int)) != hipSuccess || hipMemset(ptr, 0, GROUP_COUNTERS * sizeof(int)) != hipSuccess) {
+        (void)hipGetLastError();
+        failed[dev] = true;
+        return nullptr;
+    }
+    buf[dev] = ptr;
+    return ptr;
+}
+
 // Launch configuration of one grouped launch (bf16): tile 2 (64x64) or 4 (128x128, two workgroups per CU) and a K split per problem.
 // Cost model (calibrated on the in-step durations of profiles/r03z_train_step.md; tools/group_probe.py re-measures it): a CU retires
 // the K tiles of its resident workgroups at a fixed aggregate rate once it holds enough of them -- 0.30 us per 64x64 K tile
@@ -578,7 +599,7 @@ int launch_group_chunk(std::vector<GroupItem*>& g, int dtype, int cls, hipStream
     // gained, atomics doubled.  Kept as a switch; the split-K grouped launch stays the default.
     {
         static const bool want_sk = getenv("CB_GEMM_STREAMK") != nullptr && atoi(getenv("CB_GEMM_STREAMK")) != 0;
-        bool ok = want_sk && dtype == CB_BF16 && (cls == GC_WGRAD || cls == GC_WGRAD_GATHER) && g[0]->d->tile == 0;
+        bool ok = want_sk && dtype == CB_BF16 && (cls == GC_WGRAD || cls == GC_WGRAD_GATHER) && g[0]->d->tile == 0 && g.size() <= (size_t)STREAMK_MAX;
         for (auto* it : g) ok = ok && split_is_free(it->d) && it->pr.p.c_vec && it->d->N > 64 && it->d->M > 64 && it->pr.p.batch == 1;
         if (ok) {
             StreamKArgs sa{};
@@ -651,6 +672,37 @@ int launch_group_chunk(std::vector<GroupItem*>& g, int dtype, int cls, hipStream
     const int B = (dtype == CB_BF16 && tile == 4) ? 128 : 64;
     GroupArgs ga{};
     ga.n = (int)g.size();
+    // ---- slab K split (bf16 weight gradients; gemm_tile): the split problems' partial tiles go to the caller's K-split scratch and the last
+    // part of a tile to arrive adds them in part order -- no fp32 atomics, a bit-reproducible sum.  Needs the scratch of the first split
+    // problem (the same buffer on every descriptor of a step: ops.splitk_workspace) to hold every part, and the library's counters.
+    // CB_GROUP_SLAB=0 keeps the atomics.
+    static const bool slab_off = getenv("CB_GROUP_SLAB") != nullptr && atoi(getenv("CB_GROUP_SLAB")) == 0;
+    float* slab_ws = nullptr;
+    int* slab_cnt = nullptr;
+    if (dtype == CB_BF16 && !slab_off && (cls == GC_WGRAD || cls == GC_WGRAD_GATHER)) {
+        int64_t units = 0, tiles_split = 0;
+        const cb_gemm_desc* first = nullptr;
+        bool ok = true;
+        for (size_t i = 0; i < g.size(); ++i) {
+            const cb_gemm_desc* d = g[i]->d;
+            const int kt = g[i]->pr.p.ktiles;
+            const int si = splits[i] > kt ? (kt > 0 ? kt : 1) : splits[i];
+            if (si <= 1) continue;
+            const int64_t tiles = (int64_t)((d->M + B - 1) / B) * ((d->N + B - 1) / B);
+            units += tiles * si;
+            tiles_split += tiles;
+            if (!first) first = d;
+            ok = ok && d->splitk_ws == first->splitk_ws && g[i]->pr.p.batch == 1 && !d->a_rowsum && !d->c_rowmap;
+        }
+        if (first && ok && first->splitk_ws && aligned16(first->splitk_ws) && units * B * B * 4 <= first->splitk_ws_bytes && tiles_split <= GROUP_COUNTERS) {
+            slab_cnt = group_counters(st);
+            if (slab_cnt) slab_ws = reinterpret_cast<float*>(first->splitk_ws);
+        }
+    }
+    ga.slab = slab_ws;
+    ga.cnt = slab_ws ? slab_cnt : nullptr;
+    int64_t slab_units = 0;
+    int cnt_tiles = 0;
     int xcd = 0;
     int64_t acc = 0;
     for (size_t i = 0; i < g.size(); ++i) {
@@ -662,15 +714,23 @@ int launch_group_chunk(std::vector<GroupItem*>& g, int dtype, int cls, hipStream
             CB_REQUIRE(!d->C2 && !d->residual && !d->mask && !d->gelu_grad_pre && d->act == CB_ACT_NONE && !d->relu_after && !d->shift && d->dropout_p <= 0.f,
                        "cb_gemm_group: split_k > 1 supports only scale/alpha in the epilogue");
         }
-        p.c_vec8 = g[i]->pr.cv8 && p.split_k == 1 && !no_wide;
+        p.c_vec8 = g[i]->pr.cv8 && (p.split_k == 1 || slab_ws) && !no_wide;
+        if (slab_ws && p.split_k > 1) {
+            const int tiles = ((d->M + B - 1) / B) * ((d->N + B - 1) / B);
+            CB_REQUIRE(slab_units < (1ll << 31), "cb_gemm_group: slab index overflow");
+            p.slab_base = (int)slab_units;
+            p.cnt_base = cnt_tiles;
+            slab_units += (int64_t)tiles * p.split_k;
+            cnt_tiles += tiles;
+        }
         if (d->xcd_order != 0) xcd = d->xcd_order;
         acc += (int64_t)((d->M + B - 1) / B) * ((d->N + B - 1) / B) * p.split_k;
         CB_REQUIRE(acc < (1ll << 30), "cb_gemm_group: too many workgroups");
         ga.tile_end[i] = (int)acc;
         CB_STAMP_ASSIGN(p, d, tile, p.split_k, 0, (int)i, (int)g.size());
         ga.g[i] = p;
-        if (trace) fprintf(stderr, "cb_gemm_group[%zu/%zu]: M=%d N=%d K=%d modes=%d/%d cls=%d tile=%d split=%d\n", i, g.size(), d->M, d->N, d->K, d->a_mode,
-                           d->b_mode, cls, tile, p.split_k);
+        if (trace) fprintf(stderr, "cb_gemm_group[%zu/%zu]: M=%d N=%d K=%d modes=%d/%d cls=%d tile=%d split=%d%s\n", i, g.size(), d->M, d->N, d->K, d->a_mode,
+                           d->b_mode, cls, tile, p.split_k, slab_ws && p.split_k > 1 ? " slab" : "");
     }
     ga.xcd_remap = !no_remap && xcd != 2;
     if (dtype == CB_F32) return launch_gemm_group<float, 64, 64, 2, 1>(ga, cls, st);

@@ -42,6 +42,7 @@ struct GP {
     int ktiles;
     int raster_w;               // > 0: the XCD-compact tile order walks column panels of this many N tiles (tile_id)
     int wt;                     // 1: the row-contiguous epilogue's bf16 C / C2 stores are write-through (sc1), see store8_wt
+    int slab_base, cnt_base;    // grouped launch with slab K split (gemm_tile): this problem's first slab unit / first tile counter
 #ifdef CB_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/stamps_*.py): this launch's record area, or null
 #endif
@@ -1177,7 +1178,7 @@ __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 
 // KRANGE: the K tiles [kt0_in, kt0_in + nt_in) of the output tile instead of the bid.bz-th of p.split_k equal parts (stream-K: a
 // workgroup's share of a tile is whatever its unit range cuts out of it)
 template <typename T, int BM, int BN, typename LA, typename LB, int PF, bool RS, int OCC, bool KRANGE = false>
-__device__ __forceinline__ void gemm_tile(GP& p, TileId bid, int kt0_in = 0, int nt_in = 0) {
+__device__ __forceinline__ void gemm_tile(GP& p, TileId bid, int kt0_in = 0, int nt_in = 0, float* slab = nullptr, int* cnt = nullptr) {
     using X = Tr<T>;
     constexpr int BK = X::BK;
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
@@ -1365,6 +1366,62 @@ __device__ __forceinline__ void gemm_tile(GP& p, TileId bid, int kt0_in = 0, int
         }
     }
     CB_STAMP(2);
+    // ---- slab K split (grouped weight gradients, round 5) ------------------------------------------------------------------------
+    // Instead of 64 KB of memory-side fp32 atomics per workgroup (profiles/r05w: 0.09 ms of the step), every K part of an output tile
+    // writes its partial tile to scratch in the accumulators' own layout (16 B per lane, one contiguous 4 KB run per wave instruction)
+    // and takes a ticket; the LAST part to arrive adds all parts IN PART ORDER and runs the ordinary epilogue once (C (+)= sum, row-
+    // contiguous 32-byte stores).  The sum no longer depends on the order of arrival: the weight gradient is bit-reproducible.
+    // Visibility across the XCDs' non-coherent L2s WITHOUT fences: the parts are stored write-through and loaded with device scope
+    // (sc1 on both: the accesses of an agent-scope atomic store / load), the ticket is taken after s_waitcnt vmcnt(0) + a barrier.  A
+    // __threadfence() pair here (buffer_wbl2 + buffer_inv: the whole L2 of the XCD invalidated once per workgroup) cost the co-resident
+    // workgroups their operand reuse: +0.45 ms per step (profiles/r05x_slab_ksplit_ab.txt, first variant).
+    if constexpr (!KRANGE) {
+        if (slab != nullptr && p.split_k > 1) {                                 // (block-uniform)
+            __shared__ int s_last;
+            constexpr int SC1 = 16;
+            const int tile_lin = bid.by * ((p.N + BN - 1) / BN) + bid.bx;
+            const int parts = (p.ktiles + kt_per - 1) / kt_per;                 // K parts that hold K tiles (the others returned above)
+            float* const base = slab + ((int64_t)p.slab_base + (int64_t)tile_lin * p.split_k) * (BM * BN);
+            {
+                const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base + (int64_t)bid.bz * (BM * BN), (short)0, BM * BN * 4, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < BM / 32; ++i)
+#pragma unroll
+                    for (int j = 0; j < BN / 32; ++j) {
+                        union { f32x4 f; u32x4 r; } u;
+                        u.f = acc[i][j];
+                        __builtin_amdgcn_raw_buffer_store_b128(u.r, rs, (uint32_t)(((i * (BN / 32) + j) * NTHREADS + tid) * 16), 0, SC1);
+                    }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70);                                 // vmcnt(0): this thread's parts have left for the memory side
+            __syncthreads();
+            if (tid == 0) s_last = atomicAdd(cnt + p.cnt_base + tile_lin, 1) == parts - 1;
+            __syncthreads();
+            if (!s_last) {
+                CB_STAMP(3);
+                CB_STAMP_FLUSH(p, stamp_lin, tid);
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < BM / 32; ++i)
+#pragma unroll
+                for (int j = 0; j < BN / 32; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
+#pragma unroll 2                                                                 // (two parts' loads in flight; the additions keep the part order)
+            for (int z = 0; z < parts; ++z) {
+                const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base + (int64_t)z * (BM * BN), (short)0, BM * BN * 4, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < BM / 32; ++i)
+#pragma unroll
+                    for (int j = 0; j < BN / 32; ++j) {
+                        union { u32x4 r; f32x4 f; } u;
+                        u.r = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(((i * (BN / 32) + j) * NTHREADS + tid) * 16), 0, SC1);
+                        acc[i][j] += u.f;
+                    }
+            }
+            if (tid == 0) atomicExch(cnt + p.cnt_base + tile_lin, 0);           // ready for the next launch (same stream: ordered)
+            p.split_k = 1;                                                      // the epilogue below is the plain one
+        }
+    }
     if constexpr (EPF != 0) tile_epilogue<T, BM, BN, SMEM_BYTES, EPF>(p, acc, smem, m0, n0, tid, epre, epf_on);
     else tile_epilogue<T, BM, BN, SMEM_BYTES>(p, acc, smem, m0, n0, tid);
     CB_STAMP(3);
@@ -1391,6 +1448,8 @@ constexpr int GROUP_MAX = 10;
 struct GroupArgs {
     int n, xcd_remap;
     int tile_end[GROUP_MAX];          // problem i owns workgroups [tile_end[i-1], tile_end[i])
+    float* slab;                      // slab K split (gemm_tile): scratch for the partial tiles, and the per-tile arrival counters (zero
+    int* cnt;                         // between launches); null: the split problems combine through fp32 atomics
     GP g[GROUP_MAX];
 };
 static_assert(sizeof(GroupArgs) + 256 <= 4096, "kernel arguments (+ the hidden ones) are limited to 4 KiB");
@@ -1420,7 +1479,7 @@ __global__ void __launch_bounds__(256, OCC) gemm_group_kernel(GroupArgs ga) {
     TileId bid;
     const int pi = group_locate<BM, BN>(ga, bid);
     GP p = ga.g[pi];
-    gemm_tile<T, BM, BN, LA, LB, PF, RS, OCC>(p, bid);
+    gemm_tile<T, BM, BN, LA, LB, PF, RS, OCC>(p, bid, 0, 0, ga.slab, ga.cnt);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1433,11 +1492,12 @@ __global__ void __launch_bounds__(256, OCC) gemm_group_kernel(GroupArgs ga) {
 // products combine through the same fp32 atomics as the split-K path (zero-initialised gradient buffer, order-independent up to fp32
 // rounding -- exactly the semantics the convolution weight gradients already had).
 // ---------------------------------------------------------------------------------------------
+constexpr int STREAMK_MAX = GROUP_MAX - 1;        // (two int arrays beside the problems: one problem fewer fits the 4 KiB argument block)
 struct StreamKArgs {
     int n, xcd_remap;
-    int unit_end[GROUP_MAX];          // problem i owns units [unit_end[i-1], unit_end[i]): its tiles x its K tiles
-    int kchunk[GROUP_MAX];            // K tiles per chunk of problem i (see the unit order below)
-    GP g[GROUP_MAX];
+    int unit_end[STREAMK_MAX];        // problem i owns units [unit_end[i-1], unit_end[i]): its tiles x its K tiles
+    int kchunk[STREAMK_MAX];          // K tiles per chunk of problem i (see the unit order below)
+    GP g[STREAMK_MAX];
 };
 static_assert(sizeof(StreamKArgs) + 256 <= 4096, "kernel arguments (+ the hidden ones) are limited to 4 KiB");
 

@@ -114,7 +114,8 @@ typedef struct {
     const float* post_scale; const float* post_scale2;
     void* splitk_ws;          /* optional scratch for the K split of tiles 5-7: split_k * batch * M * N fp32 partial products
                                  (one slab per split), summed in index order by a second kernel that applies the whole
-                                 epilogue -- deterministic, no atomics, every epilogue allowed.  Too small / null: no split. */
+                                 epilogue -- deterministic, no atomics, every epilogue allowed.  Too small / null: no split.
+                                 cb_gemm_group uses the same buffer for the split weight gradients of a group (see there). */
     int64_t splitk_ws_bytes;
 } cb_gemm_desc;
 
@@ -146,7 +147,13 @@ int cb_gemm_workspace_bytes(const cb_gemm_desc* d, int64_t* bytes);
  * (bf16: 64x64 or 128x128 with two workgroups per CU; a problem's K may be split only where cb_gemm's own rule allows atomics:
  * fp32 C, accumulate = 1, scale/alpha-only epilogue); 2 / 4 = that tile with descs[i].split_k as given (problems are grouped with
  * those that ask for the same tile).  CB_F32 problems run the 64x64 fp32 tile with the caller's split_k: bit-identical to n
- * cb_gemm calls wherever split_k == 1. */
+ * cb_gemm calls wherever split_k == 1.
+ * Split bf16 weight gradients of a group combine WITHOUT atomics when every split problem carries the same splitk_ws and it holds
+ * all partial tiles (sum over the split problems of tiles x split_k x tile bytes): each K part writes its partial tile there, the
+ * last part of a tile to arrive adds them in part order and applies the epilogue once -- an order-independent, bit-reproducible
+ * sum (csrc/gemm_impl.h gemm_tile; the arrival counters are the library's own: 64 KiB per device, allocated on the first such call
+ * outside a stream capture).  No / too small a scratch, or CB_GROUP_SLAB=0: fp32 atomics as before (zero-initialised or
+ * accumulated-into C, order of addition not fixed). */
 int cb_gemm_group(const cb_gemm_desc* descs, int32_t n, void* stream);
 
 /* Output-pixel table of a convolution: entry m=(n,oh,ow) -> offset of input pixel

@@ -33,6 +33,12 @@ enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return 0; }      // (an MI355X's CU count)
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+static inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return 0; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? 0 : 2; }
+typedef int hipStreamCaptureStatus;
+#define hipStreamCaptureStatusNone 0
+static inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* s) { *s = hipStreamCaptureStatusNone; return 0; }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 enum hipMemcpyKind { hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
     memmove(d, s, n); return 0;
@@ -288,6 +294,7 @@ static inline float atomicAdd(float* p, float v) {
 }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline int atomicExch(int* p, int v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 
 // ---- math ----------------------------------------------------------------------------------
 #define __expf(x) expf(x)

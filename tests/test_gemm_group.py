@@ -200,3 +200,53 @@ def test_group_stream_k_weight_gradients(hw, monkeypatch, wgs):
     ops.gemm_group(cdescs, outs[0][0])
     for o, ref in outs:
         torch.testing.assert_close(o.cpu(), ref, **tol(dt))
+
+
+@pytest.mark.parametrize("tile", [4, 2, 0])
+def test_group_slab_k_split_is_ordered_and_reproducible(hw, monkeypatch, tile):
+    """round 5: with the K-split scratch at hand the split problems of a grouped weight-gradient launch write their partial tiles to it and
+    the last K part of a tile to arrive adds them IN PART ORDER (gemm_tile: no fp32 atomics).  Two launches from the same state are
+    bit-equal, the result is the fp32 reference within tolerance and the atomics path's within rounding; cases: K parts that end up empty
+    (9 K tiles in 4 parts), a K tail, ragged M / N edges, a gathered 3x3 operand, outputs that start from ones (C += sum) and one that
+    stores (accumulate off), a problem that is not split inside a split group."""
+    dt = torch.bfloat16
+    split = {4: 4, 2: 3, 0: 0}[tile]
+    shapes = [(576, 136, 200), (1100, 264, 136), (330, 128, 128), (2000, 72, 72)]          # (reduction, out rows, out cols)
+    lin = _wgrad_problems(hw, dt, shapes)
+    conv = _conv_wgrad_problems(hw, dt, [(2, 12, 12, 32, 72, 3, 1, 1), (2, 14, 14, 72, 136, 3, 1, 1)])
+
+    def run(ws_on, sign=1.0, init=1.0):
+        if not ws_on:
+            monkeypatch.setattr(ops, "_SPLITK_OFF", True)
+        descs, outs = [], []
+        for i, (g, x, m, n, k) in enumerate(lin):
+            g = g if sign == 1.0 else hw((g.cpu().float() * sign).to(dt))
+            o = torch.full((n, k), init, device=hw.dev)
+            kw = dict(tile=tile, split_k=(1 if i == 2 else split)) if tile else {}
+            descs.append(ops.gemm_desc(g, x, n, k, m, out=o, a_mode=ops.KROW, b_mode=ops.KROW, accumulate=True, **kw))
+            outs.append(o)
+        for pr in conv:
+            cout, kk = pr[7], pr[8] * pr[8] * pr[6]
+            o = torch.zeros(cout, kk, device=hw.dev)
+            kw = dict(tile=tile, split_k=split) if tile else {}
+            if sign != 1.0:
+                pr = (hw((pr[0].cpu().float() * sign).to(dt)),) + tuple(pr[1:])
+            descs.append(_conv_desc(pr, o, accumulate=True, **kw))
+            outs.append(o)
+        ops.gemm_group(descs, outs[0])
+        if not ws_on:
+            monkeypatch.setattr(ops, "_SPLITK_OFF", False)
+        return [o.cpu() for o in outs]
+
+    a, b, atom = run(True), run(True), run(False)
+    refs = [g.float().cpu().t() @ x.float().cpu() + 1.0 for g, x, m, n, k in lin] + [_conv_ref(pr) for pr in conv]
+    for x, y, z, r in zip(a, b, atom, refs):
+        assert torch.equal(x, y)                                     # ordered sum: launch to launch bit-equal
+        torch.testing.assert_close(x, r, **tol(dt))
+        torch.testing.assert_close(x, z, rtol=1e-5, atol=1e-4)       # same partial products, another order of fp32 additions
+    # the scratch is REUSED by the next launch: other values at the same addresses must not be served from a stale cache line
+    # (inputs scaled by a power of two: every product, partial sum and rounding scales exactly -- whatever the matrix core's rounding is)
+    one = run(True, init=0.0)
+    for sc in (2.0, 4.0, 0.5, 2.0, 1.0, 0.25):
+        for x, y in zip(one, run(True, sign=sc, init=0.0)):
+            assert torch.equal(sc * x, y), sc

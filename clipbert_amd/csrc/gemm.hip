@@ -582,7 +582,8 @@ double group_cost(const std::vector<GroupItem*>& g, int tile, int s, int* splits
     if (tile == 4) unit = per_cu <= 1 ? 1.0 : 0.77;
     else unit = per_cu <= 1 ? 0.45 : (per_cu == 2 ? 0.35 : 0.30);
     // workgroups beyond what a CU holds at once (2 / 4) queue behind the first round: their K loops do not overlap
-    return 8.0 + (double)per_cu * kt_per_max * unit + atom / 2.0e6;
+    static const double atom_scale = getenv("CB_GROUP_ATOM_SCALE") ? atof(getenv("CB_GROUP_ATOM_SCALE")) : 1.0;      // (diagnostic)
+    return 8.0 + (double)per_cu * kt_per_max * unit + atom_scale * atom / 2.0e6;
 }
 
 int launch_group_chunk(std::vector<GroupItem*>& g, int dtype, int cls, hipStream_t st) {

@@ -577,7 +577,11 @@ double group_cost(const std::vector<GroupItem*>& g, int tile, int s, int* splits
         kt_per_max = per > kt_per_max ? per : kt_per_max;
         if (si > 1) atom += (double)d->M * d->N * 4.0 * si;
     }
-    const int64_t per_cu = (W + 255) / 256;
+    static const int cus = [] {                    // (the device's CU count; the unit costs below were fitted on an MI355X: 256)
+        int dev = 0, n = 0;
+        return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }();
+    const int64_t per_cu = (W + cus - 1) / cus;
     double unit;
     if (tile == 4) unit = per_cu <= 1 ? 1.0 : 0.77;
     else unit = per_cu <= 1 ? 0.45 : (per_cu == 2 ? 0.35 : 0.30);

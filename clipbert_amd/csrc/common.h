@@ -69,9 +69,19 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float hq = 0.5f * as_erfc_poly(fabsf(x) * 0.70710678118654752f) * e;
     return (x < 0.f ? hq : 1.0f - hq) + x * (0.3989422804014327f * e);
 }
+// GELU and its derivative at once (CB_ACT_GELU_SAVE_GRAD): the forward epilogue already holds exp(-x^2 / 2) and erfc(|x| / sqrt 2) / 2; the
+// derivative costs three more instructions there and saves the backward epilogue the whole evaluation (it multiplies by the stored value).
+__device__ __forceinline__ void gelu_erf_both(float x, float& y, float& dy) {
+    const float e = __expf(-0.5f * x * x);
+    const float hq = 0.5f * as_erfc_poly(fabsf(x) * 0.70710678118654752f) * e;
+    const float cdf = x < 0.f ? hq : 1.0f - hq;
+    y = x * cdf;
+    dy = cdf + x * (0.3989422804014327f * e);
+}
 __device__ __forceinline__ float apply_act(int act, float v) {
     switch (act) {
         case CB_ACT_RELU: return v > 0.f ? v : 0.f;
+        case CB_ACT_GELU_SAVE_GRAD:                    // (without a second output it is a plain GELU)
         case CB_ACT_GELU: return gelu_erf(v);
         case CB_ACT_TANH: return tanhf(v);
         default: return v;

@@ -717,10 +717,21 @@ __device__ __forceinline__ void epilogue_vec(const GP& p, f32x4 v, int m, int64_
     }
     if (p.scale) v = v * load4(p.scale + nb);
     if (p.shift) v = v + load4(p.shift + nb);
-    if (p.C2) store4(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + nb, v);
-    if (p.act != CB_ACT_NONE) {
+    if (p.act == CB_ACT_GELU_SAVE_GRAD && p.C2) {
+        f32x4 dv;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act(p.act, v[r]);
+        for (int r = 0; r < 4; ++r) {
+            float y, dy;
+            gelu_erf_both(v[r], y, dy);
+            v[r] = y; dv[r] = dy;
+        }
+        store4(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + nb, dv);
+    } else {
+        if (p.C2) store4(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + nb, v);
+        if (p.act != CB_ACT_NONE) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = apply_act(p.act, v[r]);
+        }
     }
     if (p.dropout_p > 0.f) {
         v = v * dropout_mult4(p.seed, (uint64_t)m * ((p.N + 3) >> 2) + (nb >> 2), p.dropout_p);
@@ -738,7 +749,7 @@ __device__ __forceinline__ void epilogue_vec(const GP& p, f32x4 v, int m, int64_
     if (p.dact_pre) {
         f32x4 pr = load4(reinterpret_cast<const T*>(p.dact_pre) + orow * p.ldd + nb);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(pr[r]);
+        for (int r = 0; r < 4; ++r) v[r] *= p.act == CB_ACT_SAVED_GRAD ? pr[r] : gelu_erf_grad(pr[r]);
     }
     if (p.c_f32) {
         float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + nb;
@@ -771,13 +782,22 @@ __device__ __forceinline__ void epilogue_elem(const GP& p, float x, int m, int64
     }
     if (p.scale) x *= p.scale[n];
     if (p.shift) x += p.shift[n];
-    if (p.C2) reinterpret_cast<T*>(p.C2)[orow * p.ldc2 + n] = from_f32<T>(x);
-    x = apply_act(p.act, x);
+    if (p.act == CB_ACT_GELU_SAVE_GRAD && p.C2) {
+        float dx;
+        gelu_erf_both(x, x, dx);
+        reinterpret_cast<T*>(p.C2)[orow * p.ldc2 + n] = from_f32<T>(dx);
+    } else {
+        if (p.C2) reinterpret_cast<T*>(p.C2)[orow * p.ldc2 + n] = from_f32<T>(x);
+        x = apply_act(p.act, x);
+    }
     if (p.dropout_p > 0.f) x *= dropout_mult1(p.seed, (uint64_t)m * ((p.N + 3) >> 2) + (n >> 2), n & 3, p.dropout_p);
     if (p.residual) x += to_f32(reinterpret_cast<const T*>(p.residual)[orow * p.ldr + n]);
     if (p.relu_after) x = x > 0.f ? x : 0.f;
     if (p.mask) x = to_f32(reinterpret_cast<const T*>(p.mask)[orow * p.ldm + n]) > 0.f ? x : 0.f;
-    if (p.dact_pre) x *= gelu_erf_grad(to_f32(reinterpret_cast<const T*>(p.dact_pre)[orow * p.ldd + n]));
+    if (p.dact_pre) {
+        const float t = to_f32(reinterpret_cast<const T*>(p.dact_pre)[orow * p.ldd + n]);
+        x *= p.act == CB_ACT_SAVED_GRAD ? t : gelu_erf_grad(t);
+    }
     if (p.c_f32) {
         float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + n;
         if (p.split_k > 1) atomicAdd(c, x);
@@ -921,14 +941,21 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += sh[r];
     }
-    if (p.C2) {
-        if constexpr (sizeof(T) == 2) {
-            if (p.wt & 2) CB_EPI_ST(store8_wt<18 /* sc1 + nt: the pre-activation is next read in the backward */>(p.C2, orow * p.ldc2 + n, v));
-            else if (p.wt) CB_EPI_ST(store8_wt(p.C2, orow * p.ldc2 + n, v));
-            else CB_EPI_ST(store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, v));
-        } else CB_EPI_ST(store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, v));
+    const bool save_grad = p.act == CB_ACT_GELU_SAVE_GRAD && p.C2 != nullptr;        // C = gelu(v), C2 = gelu'(v): one evaluation for both
+    float dv[8];
+    if (save_grad) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) gelu_erf_both(v[r], v[r], dv[r]);
     }
-    if (p.act != CB_ACT_NONE) {
+    if (p.C2) {
+        const float (&w)[8] = save_grad ? dv : v;
+        if constexpr (sizeof(T) == 2) {
+            if (p.wt & 2) CB_EPI_ST(store8_wt<18 /* sc1 + nt: the pre-activation is next read in the backward */>(p.C2, orow * p.ldc2 + n, w));
+            else if (p.wt) CB_EPI_ST(store8_wt(p.C2, orow * p.ldc2 + n, w));
+            else CB_EPI_ST(store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, w));
+        } else CB_EPI_ST(store8(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + n, w));
+    }
+    if (p.act != CB_ACT_NONE && !save_grad) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = apply_act(p.act, v[r]);
     }
@@ -956,8 +983,13 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
     } else if (p.dact_pre) {
         float t[8];
         load_aux(p.dact_pre, p.ldd, t);
+        if (p.act == CB_ACT_SAVED_GRAD) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_grad(t[r]);
+            for (int r = 0; r < 8; ++r) v[r] *= t[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_grad(t[r]);
+        }
     }
     if (p.c_f32) {
         float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + n;

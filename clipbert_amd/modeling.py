@@ -27,6 +27,8 @@ from torch import nn
 
 from . import ops
 from .ops import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_TANH, KROW, KROW_GATHER, KROW_TAPS, ROWK, ROWK_GATHER)
+
+_GELU_SAVE_GRAD = os.environ.get("CB_NO_GELU_SAVE_GRAD") is None      # FFN1 stores gelu'(pre) for the backward instead of the pre-activation
 from .params import ParamBank
 
 FROZEN_BN_EPS = 1e-5
@@ -746,7 +748,10 @@ def encoder_forward(model: ClipBertBaseModel, grid, ids, mask, src_row, pooled_d
                                             out=stk.a[li] if save else None)
         hact = stk.hact[li] if save else torch.empty(M, ff, dtype=dt, device=dev)
         hpre = torch.empty(M, ff, dtype=dt, device=dev) if save else None
-        ops.gemm(a, bank.compute(it.dense.weight), M, ff, d, out=hact, shift=it.dense.bias, act=ACT_GELU, out2=hpre)
+        # (training: the second output is gelu'(pre-activation), all the backward needs of it -- one evaluation of exp / erfc for both, and
+        # the FFN2 data-gradient epilogue multiplies by the stored value instead of evaluating the derivative: CB_ACT_GELU_SAVE_GRAD)
+        ops.gemm(a, bank.compute(it.dense.weight), M, ff, d, out=hact, shift=it.dense.bias,
+                 act=ops.ACT_GELU_SAVE_GRAD if (save and _GELU_SAVE_GRAD) else ACT_GELU, out2=hpre)
         o_pre = torch.empty(M, d, dtype=dt, device=dev)
         ops.gemm(hact, bank.compute(ou.dense.weight), M, d, ff, out=o_pre, shift=ou.dense.bias, residual=a, dropout_p=p_h,
                  dropout_seed=_seed(_SITE_OUT, li, fwd_i), seed_ptr=rt.seed_dev)
@@ -916,7 +921,8 @@ def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
         d_o_pre, d_o_drop = ln_bwd(2 * li + 1, dx, o_pre, ou.LayerNorm, mean2, rstd2, _seed(_SITE_OUT, li, pk.fwd_i), keep)
         g = d_o_drop if d_o_drop is not None else d_o_pre
         dhp = gs.hp[li]
-        ops.gemm(g, bank.compute(ou.dense.weight), M, ff, d, out=dhp, b_mode=KROW, gelu_grad_pre=hpre)   # dgrad + GELU'
+        ops.gemm(g, bank.compute(ou.dense.weight), M, ff, d, out=dhp, b_mode=KROW, gelu_grad_pre=hpre,      # dgrad x GELU'
+                 act=ops.ACT_SAVED_GRAD if _GELU_SAVE_GRAD else ACT_NONE)
         da = torch.empty(M, d, dtype=dt, device=dev)
         ops.gemm(dhp, bank.compute(it.dense.weight), M, d, ff, out=da, b_mode=KROW, residual=d_o_pre)
         keep = dict(dx2=gs.att[li]) if pk.p_h > 0 else dict(dx=gs.att[li])

@@ -9,7 +9,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_TANH, CB_BF16, CB_F32, KROW, KROW_GATHER,  # noqa: F401
+from ._lib import (ACT_GELU, ACT_GELU_SAVE_GRAD, ACT_NONE, ACT_RELU, ACT_SAVED_GRAD, ACT_TANH, CB_BF16, CB_F32, KROW, KROW_GATHER,  # noqa: F401
                    KROW_TAPS, ROWK, ROWK_GATHER, GemmDesc)
 
 # Set only by the CPU test-suite when it swaps in the host emulator build of the same sources.

@@ -31,7 +31,11 @@ extern "C" {
 #endif
 
 enum { CB_F32 = 0, CB_BF16 = 1 };
-enum { CB_ACT_NONE = 0, CB_ACT_RELU = 1, CB_ACT_GELU = 2, CB_ACT_TANH = 3 };
+enum { CB_ACT_NONE = 0, CB_ACT_RELU = 1, CB_ACT_GELU = 2, CB_ACT_TANH = 3,
+       CB_ACT_GELU_SAVE_GRAD = 4,   /* cb_gemm: GELU; the second output C2, if given, receives gelu'(pre-activation) INSTEAD of the
+                                       pre-activation: what the backward needs of it, computed where exp / erfc are at hand      */
+       CB_ACT_SAVED_GRAD = 5 };      /* cb_gemm: no activation; gelu_grad_pre holds gelu'(pre) as stored by a CB_ACT_GELU_SAVE_GRAD
+                                       launch: the result is multiplied by it as it is (no erf / exp in the backward epilogue)   */
 
 /* operand addressing modes of cb_gemm (reduction index = k) */
 enum {
@@ -98,7 +102,8 @@ typedef struct {
                                  and every row / tap start is 16-byte aligned the kernel uses range-checked
                                  buffer loads (fast path); otherwise element-wise guarded loads.           */
     const void* gelu_grad_pre; int64_t ld_gelu;  /* optional: result *= gelu'(pre[m,n]) (last step before the store):
-                                 the GELU backward of BertIntermediate fused into the dgrad of BertOutput.dense  */
+                                 the GELU backward of BertIntermediate fused into the dgrad of BertOutput.dense;
+                                 with act == CB_ACT_SAVED_GRAD the tensor already holds gelu'(pre): result *= it  */
     float* a_rowsum;          /* optional, weight-gradient form only (A and B CB_KROW): a_rowsum[m] += sum_k A(m,k),
                                  i.e. the bias gradient colsum(dY), computed on the matrix core next to dW (atomics) */
     int32_t batch;            /* > 1: `batch` independent problems of this shape in ONE launch (grid z); problem b uses

@@ -87,6 +87,24 @@ def test_fused_bias_grad_and_gelu_grad(hw, dt, tile):
     pr = pre.float().requires_grad_(True)
     F.gelu(pr).backward(g.float() @ w.float())
     torch.testing.assert_close(dx.float(), pr.grad, **tol(dt))
+    # round 5: the forward stores gelu'(pre) as its second output (CB_ACT_GELU_SAVE_GRAD), the data gradient multiplies by it as stored
+    # (CB_ACT_SAVED_GRAD) -- the pair gives what gelu_grad_pre on the pre-activation gives, up to the storage rounding of the derivative
+    wf, bf = hw(rnd(K, N, seed=9, scale=0.2).to(dt)), hw(rnd(K, seed=10))
+    xin = hw(rnd(M, N, seed=11).to(dt))
+    y, dsave = torch.empty(M, K, dtype=dt, device=hw.dev), torch.empty(M, K, dtype=dt, device=hw.dev)
+    y0, pre0 = torch.empty(M, K, dtype=dt, device=hw.dev), torch.empty(M, K, dtype=dt, device=hw.dev)
+    ops.gemm(xin, wf, M, K, N, out=y, shift=bf, act=ops.ACT_GELU_SAVE_GRAD, out2=dsave, tile=tile)
+    ops.gemm(xin, wf, M, K, N, out=y0, shift=bf, act=ops.ACT_GELU, out2=pre0, tile=tile)
+    assert torch.equal(y, y0) or (y.float() - y0.float()).abs().max() <= 1e-6 * max(1.0, float(y0.float().abs().max()))
+    z = (xin.float() @ wf.float().t() + bf).requires_grad_(True)
+    F.gelu(z).sum().backward()
+    torch.testing.assert_close(dsave.float(), z.grad, **tol(dt))
+    dx2 = torch.empty(M, K, dtype=dt, device=hw.dev)
+    ops.gemm(g, w, M, K, N, out=dx2, b_mode=ops.KROW, tile=tile, gelu_grad_pre=dsave, act=ops.ACT_SAVED_GRAD)
+    torch.testing.assert_close(dx2.float(), (g.float() @ w.float()) * dsave.float(), **tol(dt))
+    y1 = torch.empty(M, K, dtype=dt, device=hw.dev)
+    ops.gemm(xin, wf, M, K, N, out=y1, shift=bf, act=ops.ACT_GELU_SAVE_GRAD, tile=tile)        # no second output: a plain GELU
+    assert torch.equal(y1, y0)
 
 
 @pytest.mark.parametrize("dt", DT)

@@ -105,6 +105,18 @@ def test_dgrad_wgrad_rowsum_batched(hw, tile, sched):
     pr = pre.float().requires_grad_(True)
     F.gelu(pr).backward(g.float() @ w.float())
     torch.testing.assert_close(dx.float(), pr.grad, **TOL)
+    # round 5: forward with C2 = gelu'(pre) (CB_ACT_GELU_SAVE_GRAD), data gradient x the stored derivative (CB_ACT_SAVED_GRAD)
+    wf, bf = hw(rnd(K, N, seed=9, scale=0.1).to(BF)), hw(rnd(K, seed=10))
+    y, dsave, y0 = (torch.empty(M, K, dtype=BF, device=hw.dev) for _ in range(3))
+    ops.gemm(g, wf, M, K, N, out=y, shift=bf, act=ops.ACT_GELU_SAVE_GRAD, out2=dsave, tile=tile, schedule=sched)
+    ops.gemm(g, wf, M, K, N, out=y0, shift=bf, act=ops.ACT_GELU, tile=tile, schedule=sched)
+    assert torch.equal(y, y0) or (y.float() - y0.float()).abs().max() <= 1e-6 * max(1.0, float(y0.float().abs().max()))
+    z = (g.float() @ wf.float().t() + bf).requires_grad_(True)
+    F.gelu(z).sum().backward()
+    torch.testing.assert_close(dsave.float(), z.grad, **TOL)
+    dx2 = torch.empty(M, K, dtype=BF, device=hw.dev)
+    ops.gemm(g, w, M, K, N, out=dx2, b_mode=ops.KROW, tile=tile, schedule=sched, gelu_grad_pre=dsave, act=ops.ACT_SAVED_GRAD)
+    torch.testing.assert_close(dx2.float(), (g.float() @ w.float()) * dsave.float(), **TOL)
     # dW = g^T x (+ bias gradient as row sums on the matrix core), unsplit and split through slabs
     buf = ws(hw)
     tolw = dict(rtol=2e-2, atol=8e-2)

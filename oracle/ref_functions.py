@@ -49,6 +49,23 @@ def load(rel_path: str, names, extra_ns=None, strip_cuda: bool = False):
     return {n: ns[n] for n in names}
 
 
+def load_method(rel_path: str, cls_name: str, method: str, extra_ns=None):
+    """one METHOD of a reference class as a plain function ``f(self, ...)``, executed from its source: the class statement is found by
+    name, the method's ``def`` is lifted out of it (decorators dropped) and compiled alone -- neither the class body nor the module's
+    imports (detectron2, horovod, apex) run.  ``super()`` calls inside such a method would not work; none of the methods taken this way
+    has one."""
+    path = os.path.join(ref_shim.REFERENCE_ROOT, rel_path)
+    with open(path) as fh:
+        tree = ast.parse(fh.read(), filename=path)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls_name)
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == method)
+    fn.decorator_list = []
+    ns = {"np": np, "torch": torch, "nn": torch.nn, "os": os}
+    ns.update(extra_ns or {})
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+    return ns[method]
+
+
 def _import_file(rel_path: str, mod_name: str):
     """a reference module that is plain torch / stdlib at module level, imported from where it lies"""
     import importlib.util
@@ -92,6 +109,41 @@ def grid_encoder(backbone_channel_in_size: int, hidden_size: int):
     ns = {"nn": torch.nn, "torch": torch, "conv3x3": conv3x3(),
           "config": SimpleNamespace(backbone_channel_in_size=backbone_channel_in_size, hidden_size=hidden_size)}
     return eval(compile(ast.Expression(body=stmt.value), path, "eval"), ns)
+
+
+def grid_feat_forward():
+    """GridFeatBackbone.forward (src/modeling/grid_feat.py:89-105) as ``f(self, x)``: the (B, T) -> (B T) reshape, the RGB -> BGR flip,
+    backbone -> get_conv5_features -> grid_encoder, the (B, T, C, H, W) view and the channels-last permute.  ``self`` is supplied by the
+    caller (a namespace with ``input_format``, ``feature.backbone``, ``feature.roi_heads`` and ``grid_encoder``): detectron2 builds the
+    real ones and is absent from the image."""
+    return load_method(GRID_FEAT, "GridFeatBackbone", "forward")
+
+
+def roi_heads_name() -> str:
+    """MODEL.ROI_HEADS.NAME of the detectron2 config the reference's JSON configs point at (src/configs/detectron2_configs/R-50-grid.yaml
+    through its _BASE_): which class's get_conv5_features GridFeatBackbone.forward calls"""
+    import yaml
+    base = os.path.join(ref_shim.REFERENCE_ROOT, "src", "configs", "detectron2_configs")
+    with open(os.path.join(base, "R-50-grid.yaml")) as fh:
+        top = yaml.safe_load(fh)
+    with open(os.path.join(base, top["_BASE_"])) as fh:
+        parent = yaml.safe_load(fh)
+    roi = dict(parent["MODEL"]["ROI_HEADS"])
+    roi.update(top.get("MODEL", {}).get("ROI_HEADS", {}))
+    assert roi["IN_FEATURES"] == ["res5"] and parent["MODEL"]["RESNETS"]["OUT_FEATURES"] == ["res5"]
+    return roi["NAME"]
+
+
+def get_conv5_features():
+    """get_conv5_features of the ROI-heads class the config names (src/modeling/grid_feats/roi_heads.py:232-236 for
+    AttributeStandardROIHeads: the identity select of the single in_feature) as ``f(self, features)``"""
+    return load_method(os.path.join("src", "modeling", "grid_feats", "roi_heads.py"), roi_heads_name(), "get_conv5_features")
+
+
+def clipbert_forward():
+    """ClipBert.forward (src/modeling/e2e_model.py:29-39) as ``f(self, batch)`` with the reference's own repeat_tensor_rows in scope;
+    ``self`` (cnn, transformer, retrieval) is the caller's"""
+    return load_method(os.path.join("src", "modeling", "e2e_model.py"), "ClipBert", "forward", extra_ns={"repeat_tensor_rows": repeat_tensor_rows()})
 
 
 def repeat_tensor_rows():

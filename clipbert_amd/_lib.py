@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libclipbert_hip.so")
 
 CB_F32, CB_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
+SPLITK_WS_COUNTER_BYTES = 65536                     # CB_SPLITK_WS_COUNTER_BYTES: zeroed tail of cb_gemm_desc.splitk_ws (arrival counters)
 ACT_GELU_SAVE_GRAD, ACT_SAVED_GRAD = 4, 5          # cb_gemm only: GELU with C2 = gelu'(pre); backward multiplies by that stored derivative
 ROWK, ROWK_GATHER, KROW, KROW_TAPS, KROW_GATHER = 0, 1, 2, 3, 4
 (HP_LR, HP_BETA1, HP_BETA2, HP_EPS, HP_WD, HP_BC1, HP_BC2, HP_MAX_NORM, HP_GRAD_SCALE, HP_SKIP, HP_COUNT) = range(11)

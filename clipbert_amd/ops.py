@@ -152,8 +152,17 @@ def splitk_workspace(device) -> torch.Tensor:
     if ws is None:
         if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
             return None
-        ws = torch.empty(SPLITK_WS_BYTES // 4, dtype=torch.float32, device=device)
+        ws = new_splitk_workspace(device)
         _SPLITK_WS[key] = ws
+    return ws
+
+
+def new_splitk_workspace(device, nbytes: int = SPLITK_WS_BYTES) -> torch.Tensor:
+    """A K-split scratch as include/clipbert_hip.h lays it out: partial products, then CB_SPLITK_WS_COUNTER_BYTES of arrival counters
+    that start at zero (every launch leaves them zero).  One per stream whose launches may overlap another stream's."""
+    assert nbytes % 16 == 0 and nbytes > _lib.SPLITK_WS_COUNTER_BYTES
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+    ws[-(_lib.SPLITK_WS_COUNTER_BYTES // 4):].zero_()
     return ws
 
 

@@ -31,6 +31,7 @@ extern "C" {
 #endif
 
 enum { CB_F32 = 0, CB_BF16 = 1 };
+enum { CB_SPLITK_WS_COUNTER_BYTES = 65536 };   /* tail of cb_gemm_desc.splitk_ws reserved for arrival counters (see there) */
 enum { CB_ACT_NONE = 0, CB_ACT_RELU = 1, CB_ACT_GELU = 2, CB_ACT_TANH = 3,
        CB_ACT_GELU_SAVE_GRAD = 4,   /* cb_gemm: GELU; the second output C2, if given, receives gelu'(pre-activation) INSTEAD of the
                                        pre-activation: what the backward needs of it, computed where exp / erfc are at hand      */
@@ -120,7 +121,13 @@ typedef struct {
     void* splitk_ws;          /* optional scratch for the K split of tiles 5-7: split_k * batch * M * N fp32 partial products
                                  (one slab per split), summed in index order by a second kernel that applies the whole
                                  epilogue -- deterministic, no atomics, every epilogue allowed.  Too small / null: no split.
-                                 cb_gemm_group uses the same buffer for the split weight gradients of a group (see there). */
+                                 cb_gemm_group uses the same buffer for the split weight gradients of a group (see there).
+                                 LAYOUT: the LAST CB_SPLITK_WS_COUNTER_BYTES bytes of the buffer are the arrival counters of the
+                                 in-launch K-split reduce; the caller zeroes them ONCE when it allocates the buffer (cb_zero), every
+                                 launch leaves them zero, and no launch puts partial products there (the payload is
+                                 splitk_ws_bytes - CB_SPLITK_WS_COUNTER_BYTES).  The buffer -- partial products AND counters -- belongs
+                                 to the launches of ONE stream (or of streams ordered by events): launches that may run concurrently
+                                 must carry different buffers.  The library itself allocates nothing and keeps no such state. */
     int64_t splitk_ws_bytes;
 } cb_gemm_desc;
 
@@ -139,7 +146,8 @@ int cb_gemm_plan(const cb_gemm_desc* d, int32_t use_table, int32_t* out4);
 /* Bytes of K-split scratch (cb_gemm_desc.splitk_ws) cb_gemm would use for `d` at most -- what it picks when the workspace is not the
  * constraint; 0 when the problem runs unsplit or through atomics.  A caller sizes ONE buffer by the maximum over the problems it will
  * launch on a stream (clipbert_amd keeps 128 MiB per device: the largest value over the three bench workloads is 115 MiB); a smaller or
- * absent buffer is never an error -- cb_gemm then chooses among the configurations that fit. */
+ * absent buffer is never an error -- cb_gemm then chooses among the configurations that fit.  A non-zero answer includes the
+ * CB_SPLITK_WS_COUNTER_BYTES tail. */
 int cb_gemm_workspace_bytes(const cb_gemm_desc* d, int64_t* bytes);
 /* `n` INDEPENDENT problems in as few launches as possible: the same results as n cb_gemm calls (no problem's output may overlap
  * another problem's output or operands), but problems that run the same kernel class -- weight gradients of Linear / 1x1
@@ -156,9 +164,10 @@ int cb_gemm_workspace_bytes(const cb_gemm_desc* d, int64_t* bytes);
  * Split bf16 weight gradients of a group combine WITHOUT atomics when every split problem carries the same splitk_ws and it holds
  * all partial tiles (sum over the split problems of tiles x split_k x tile bytes): each K part writes its partial tile there, the
  * last part of a tile to arrive adds them in part order and applies the epilogue once -- an order-independent, bit-reproducible
- * sum (csrc/gemm_impl.h gemm_tile; the arrival counters are the library's own: 64 KiB per device, allocated on the first such call
- * outside a stream capture).  No / too small a scratch, or CB_GROUP_SLAB=0: fp32 atomics as before (zero-initialised or
- * accumulated-into C, order of addition not fixed). */
+ * sum (csrc/gemm_impl.h gemm_tile; the arrival counters are the zeroed tail of that same scratch, see cb_gemm_desc.splitk_ws: nothing
+ * is allocated here, and two grouped launches in flight on two streams are independent exactly when their scratch buffers are).
+ * No / too small a scratch, or CB_GROUP_SLAB=0: fp32 atomics as before (zero-initialised or accumulated-into C, order of addition
+ * not fixed). */
 int cb_gemm_group(const cb_gemm_desc* descs, int32_t n, void* stream);
 
 /* Output-pixel table of a convolution: entry m=(n,oh,ow) -> offset of input pixel
@@ -376,7 +385,9 @@ int cb_elu_bn1d_bwd(int32_t dtype, const void* dy, const void* x, const float* g
 const char* cb_last_error(void);
 /* ABI version: 1 = round 1-2; 2 = CB_HP_SKIP / CB_HP_COUNT 10 (cb_adamw*), cb_gemm_group, cb_gemm_workspace_bytes;
  * 3 = cb_gemm_desc.tile = 8 (the streaming structure; every earlier descriptor means what it meant), cb_head_loss, cb_retrieval_scores;
- * 4 = cb_res2_block, cb_stem_pool (round 5: the frozen front of the backbone as fused launches; nothing else changed) */
+ * 4 = cb_res2_block, cb_stem_pool (round 5: the frozen front of the backbone as fused launches; nothing else changed);
+ * 5 = the K-split arrival counters live in the tail of cb_gemm_desc.splitk_ws (CB_SPLITK_WS_COUNTER_BYTES, zeroed once by the caller)
+ *     instead of a library-owned allocation: a caller of version 4 that passes a scratch must zero its last 64 KiB once */
 int cb_version(void);
 
 /* ---- gradient exchange (one process per GPU, RCCL over xGMI) ----------------------------------------------------

@@ -147,7 +147,7 @@ def main():
     model.load_state_dict(S.full_state_dict(cfg, args.head, 42), strict=True)
     model.to(dev)
     model.train(train)
-    model.prepare(dtype=torch.bfloat16, device=dev, overlap_wgrad=os.environ.get("CB_OVERLAP_WGRAD", "0") != "0")
+    model.prepare(dtype=torch.bfloat16, device=dev, overlap_wgrad=int(os.environ.get("CB_OVERLAP_WGRAD", "0")))     # Runtime.overlap bits (diagnostic A/B)
     log("model prepared")
     bank = model.rt.bank
 

@@ -165,16 +165,19 @@ class _GridConv(nn.Module):
 
 
 class _SideStream:
-    """torch.cuda.stream(side) + no K-split workspace for the launches inside (it belongs to the main stream's launches)"""
-    def __init__(self, stream):
+    """torch.cuda.stream(side) + the K-split scratch of the launches inside: the side stream's own (``ws``: partial products and
+    arrival tickets belong to ONE stream, include/clipbert_hip.h) or none (the default scratch belongs to the main stream's launches)"""
+    def __init__(self, stream, ws=None):
         self.ctx = torch.cuda.stream(stream)
+        self.ws = ws
 
     def __enter__(self):
-        self.prev, ops._SPLITK_OFF = ops._SPLITK_OFF, True
+        self.prev = (ops._SPLITK_OFF, ops._SPLITK_SIDE)
+        ops._SPLITK_OFF, ops._SPLITK_SIDE = self.ws is None, self.ws
         return self.ctx.__enter__()
 
     def __exit__(self, *exc):
-        ops._SPLITK_OFF = self.prev
+        ops._SPLITK_OFF, ops._SPLITK_SIDE = self.prev
         return self.ctx.__exit__(*exc)
 
 
@@ -201,6 +204,11 @@ class Runtime:
         self.forward_count = 0                           # host counter folded into every dropout seed: each forward (each
                                                          # clip of a clip loop) draws its own masks; kept in the saved pack
         self.side_stream = None                          # second HIP stream: weight-gradient GEMMs run beside the dgrad chain
+        self.side_ws = None                              # its own K-split scratch (ops.new_splitk_workspace)
+        self.overlap = 0                                 # what runs there (prepare(overlap_wgrad=...)): bit 0 the encoder's batched weight
+                                                         # gradients beside the ResNet backward, bit 1 a ResNet stage's grouped weight
+                                                         # gradients beside the next stage's data gradients, bit 2 every convolution's
+                                                         # weight gradient on its own (the round-1 form)
         self.group_wgrads = os.environ.get("CB_NO_GROUP_WGRAD") is None     # ResNet weight gradients per stage through cb_gemm_group
         self.group_fwd_pairs = os.environ.get("CB_GROUP_FWD_PAIRS", "0") == "1"   # shortcut + conv1 of the strided stage entries in one launch: measured SLOWER (profiles/r04f: +0.1 ms; the grouped gather kernel runs the pair in 106 us against 47 + 24 apart) -- kept as a switch
         self._side_refs = []
@@ -216,7 +224,7 @@ class Runtime:
         ev.record()
         self.side_stream.wait_event(ev)
         self._side_refs.extend(tensors)
-        return _SideStream(self.side_stream)
+        return _SideStream(self.side_stream, self.side_ws)
 
     def join(self):
         if self.side_stream is not None:
@@ -335,7 +343,9 @@ def _conv_wgrad(rt: Runtime, g, x, conv, pending=None):
     m = n * oh * ow
     kk = k * k * cin
     split, tile = _pick_split(cout, kk, m)
-    run = ops.gemm if pending is None else (lambda *a, **kw: pending.append(ops.gemm_desc(*a, **kw)))
+    # (descriptors that will be LAUNCHED on the side stream carry its scratch, whichever stream describes them)
+    side_ws = rt.side_ws if (pending is not None and rt.overlap & 2) else None
+    run = ops.gemm if pending is None else (lambda *a, **kw: pending.append(ops.gemm_desc(*a, splitk_ws=side_ws, **kw)))
     if k == 1 and s == 1:
         run(g.view(m, cout), x.view(m, cin), cout, cin, m, out=gw.view(cout, kk), a_mode=KROW, lda=cout,
             b_mode=KROW, ldb=cin, accumulate=True, split_k=split, tile=tile)
@@ -454,7 +464,7 @@ def cnn_backward_steps(bb: "GridFeatBackbone", saved_pack, dgrid: torch.Tensor):
     saved, res5, gy, grid = saved_pack
     gconv = bb.grid_encoder[0]
     dg = ops.maxpool2_bwd(gy, grid, dgrid.reshape(grid.shape).contiguous(), relu=True)
-    with rt.side(dg, res5):
+    with (rt.side(dg, res5) if rt.overlap & 6 else contextlib.nullcontext()):
         _conv_wgrad(rt, dg, res5, gconv)
     if not saved:
         rt.join()
@@ -464,11 +474,16 @@ def cnn_backward_steps(bb: "GridFeatBackbone", saved_pack, dgrid: torch.Tensor):
     # weight gradients of a stage's convolutions: described as the data-gradient chain passes them, launched together when the chain
     # leaves the stage (cb_gemm_group; not with the side-stream variant, which overlaps them one by one)
     stage_of = {id(b): name for name, *_ in RESNET50_STAGES for b in getattr(bb.feature.backbone, name)}
-    pend = [] if (rt.group_wgrads and rt.side_stream is None) else None
+    pend = [] if (rt.group_wgrads and not rt.overlap & 4) else None
+    conv_side = rt.side if pend is None else (lambda *t: contextlib.nullcontext())     # (pending: only described here, launched by flush)
 
     def flush():
         if pend:
-            ops.gemm_group(pend, dg)
+            if rt.overlap & 2:                          # the stage's grouped launches beside the next stage's data gradients
+                with rt.side(*pend):                    # (the descriptors keep their operands alive until join())
+                    ops.gemm_group(pend, dg)
+            else:
+                ops.gemm_group(pend, dg)
             pend.clear()
 
     def fuse_spec(i):
@@ -486,15 +501,15 @@ def cnn_backward_steps(bb: "GridFeatBackbone", saved_pack, dgrid: torch.Tensor):
         s2, _ = blk.conv2.scale_shift()
         s1, _ = blk.conv1.scale_shift()
         dz, gsc = (sec, None) if blk.shortcut is None else (None, sec)
-        with rt.side(g3, y2, sec):
+        with conv_side(g3, y2, sec):
             _conv_wgrad(rt, g3, y2, blk.conv3, pend)
             if blk.shortcut is not None:
                 _conv_wgrad(rt, gsc, x, blk.shortcut, pend)
         g2 = _conv_dgrad(rt, g3, blk.conv3, y2.shape, scale=s2, mask=y2)       # -> d(conv2 out) * mask * scale2
-        with rt.side(g2, y1):
+        with conv_side(g2, y1):
             _conv_wgrad(rt, g2, y1, blk.conv2, pend)
         g1 = _conv_dgrad(rt, g2, blk.conv2, y1.shape, scale=s1, mask=y1)
-        with rt.side(g1, x):
+        with conv_side(g1, x):
             _conv_wgrad(rt, g1, x, blk.conv1, pend)
         if idx == 0 or stage_of.get(id(saved[idx - 1][0])) != stage_of.get(id(blk)):
             flush()                                     # the chain leaves this stage: its weight gradients in a few grouped launches
@@ -937,9 +952,15 @@ def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
         ops.gemm(dqkv, wqkv, M, d, 3 * d, out=dx, b_mode=KROW, residual=d_a_pre)
     if ln_part is not None:
         ops.ln_partials_reduce(ln_part, bank.grad, ln_off[0], ln_off[1])
-    _encoder_wgrads(model, pk, gs, M)
+    if rt.overlap & 1 and rt.side_stream is not None and rt.after_encoder_backward is None:
+        # the four batched weight-gradient launches on the second branch: they run beside the embedding backwards and the ResNet
+        # backward and are joined where that ends (cnn_backward_steps) or, without a ResNet backward, in _EncoderFn.backward
+        with rt.side(gs.out, gs.hp, gs.att, gs.qkv, stk.x, stk.ctx, stk.a, stk.hact):
+            _encoder_wgrads(model, pk, gs, M)
+    else:
+        _encoder_wgrads(model, pk, gs, M)
+        rt.join()
     # ---- embeddings -----------------------------------------------------------------------------------
-    rt.join()
     if pk.p_h > 0:
         dx = ops.dropout(dx, pk.p_h, _seed(_SITE_EMB, 0, pk.fwd_i), rt.seed_dev)
     emb, vemb = model.embeddings, model.visual_embeddings
@@ -977,6 +998,8 @@ class _EncoderFn(torch.autograd.Function):
         dgrid = encoder_backward(ctx.model, ctx.pack, d_seq, d_pooled)
         ctx.pack = None
         rt = ctx.model.rt
+        if rt.pending_cnn_nodes == 0:
+            rt.join()                                   # (no ResNet backward follows: the side branch ends here)
         rt.pending_encoder_nodes = max(0, rt.pending_encoder_nodes - 1)
         hook = rt.after_encoder_backward
         # a clip LOOP (train_n_clips forwards before one backward) runs several encoder backwards per step: the
@@ -1410,7 +1433,11 @@ class ClipBert(nn.Module):
         if dtype == torch.bfloat16 and (device.type == "cuda" or ops._ALLOW_HOST_POINTERS):
             ops.splitk_workspace(device)            # scratch of cb_gemm's K-split: allocated here, before any hipGraph capture
         if device.type == "cuda" and overlap_wgrad:
+            # overlap_wgrad: True = every convolution's weight gradient on a second stream (round 1); an int = Runtime.overlap bits
+            rt.overlap = 4 if overlap_wgrad is True else int(overlap_wgrad)
             rt.side_stream = torch.cuda.Stream(device=device)
+            if rt.overlap & 3 and dtype == torch.bfloat16:
+                rt.side_ws = ops.new_splitk_workspace(device)
         for m in self.modules():
             if hasattr(m, "rt"):
                 m.rt = rt

@@ -109,7 +109,7 @@ def gemm_desc(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: 
         d.batch = batch
         d.batch_stride_a, d.batch_stride_b, d.batch_stride_c, d.batch_stride_rowsum = batch_strides
     if splitk_ws is None and d.dtype == CB_BF16 and not _SPLITK_OFF:
-        splitk_ws = splitk_workspace(a.device)
+        splitk_ws = _SPLITK_SIDE if _SPLITK_SIDE is not None else splitk_workspace(a.device)
     if splitk_ws is not None:
         d.splitk_ws, d.splitk_ws_bytes = _ptr(splitk_ws), splitk_ws.numel() * splitk_ws.element_size()
     d._refs = (a, b, out, a_tab, b_tab, c_rowmap, scale, shift, residual, mask, out2, seed_ptr, gelu_grad_pre, a_rowsum, post_scale,
@@ -139,6 +139,7 @@ def gemm_group(descs, like: torch.Tensor):
 _LAUNCH_OVERRIDE = {}                  # (a_mode, b_mode, M, N, K, batch, taps, split_k) -> (tile, xcd_order, split_k, schedule); tuning only
 _SPLITK_WS = {}
 _SPLITK_OFF = False                    # set while launches go to a SIDE stream (Runtime.side): the buffer belongs to the main stream's launches
+_SPLITK_SIDE = None                    # set while launches go to a side stream that OWNS a scratch of its own (Runtime.side with side_ws)
 SPLITK_WS_BYTES = 128 << 20
 
 

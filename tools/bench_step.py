@@ -45,7 +45,7 @@ def build(videos=16, n_clips=2, frames=2, size=224, txt_len=32, repeat=2, pool="
     model.load_state_dict(sd, strict=True)
     model.to(dev)
     model.train(True)
-    model.prepare(dtype=torch.bfloat16, device=dev)
+    model.prepare(dtype=torch.bfloat16, device=dev, overlap_wgrad=int(os.environ.get("CB_OVERLAP_WGRAD", "0")))
     bank = model.rt.bank
     fr = S.synthetic_frames(videos, n_clips * frames, size, seed).to(dev)
     ids, mask = S.synthetic_text(videos * repeat, txt_len, seed)

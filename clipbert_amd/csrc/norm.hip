@@ -192,6 +192,126 @@ __global__ void __launch_bounds__(NW * 64) layernorm_bwd_kernel(const T* dy, con
     }
 }
 
+// Round 6: the same backward with EVERY row of a wave in flight at once.  The kernel above gives a wave one row at a time (next row
+// prefetched): at the encoder's 2624 rows that is one row per wave on 164 sixteen-wave blocks -- 12.2 us in the step against 5.8 us for the
+// forward (profiles/r05z_train_step.md): a launch of one dependent chain {loads -> two 64-lane reductions -> stores -> a 16-way LDS
+// reduction of 2 * D sums behind six barriers} with ten waves per CU to hide it.  Here a block is NW waves x RPW rows: a wave requests the
+// dy / x rows of all its RPW rows up front (RPW x the bytes in flight per wave), forms the 2 * RPW row sums and reduces them TOGETHER
+// (independent shuffles interleave), stores, and keeps the column sums of its rows in registers -- the cross-wave reduction is NW-way
+// (4 instead of 16) behind ONE barrier pair per 1024 columns.  Same arithmetic per element and the same order of the column additions
+// inside a wave's rows; the partial-sum layout part[block][gamma | beta][D] and cb_ln_partials_reduce are unchanged.
+template <typename T, int MAXCH, int NW, int RPW>
+__global__ void __launch_bounds__(NW * 64) layernorm_bwd_rows_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
+                                                                    const float* rstd, T* dx, float* dgamma, float* dbeta,
+                                                                    int64_t rows, int D, T* dx2, float drop_p, uint64_t seed,
+                                                                    const uint64_t* seed_ptr, int seg_len, int seg_stride, int seg_off,
+                                                                    float* part) {
+    constexpr int GC = MAXCH < 4 ? MAXCH : 4;                     // chunks (of 256 columns) reduced across the waves per barrier pair
+    __shared__ float red[2][NW][GC * 256];
+    if (dx2 && seed_ptr) seed += *seed_ptr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 ag[MAXCH], ab[MAXCH], gm[MAXCH];
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        ag[c] = z; ab[c] = z;
+        const int e = (lane + 64 * c) * 4;
+        gm[c] = e < D ? load4(gamma + e) : z;
+    }
+    auto phys = [&](int64_t lrow) { return seg_len > 0 ? (lrow / seg_len) * seg_stride + seg_off + lrow % seg_len : lrow; };
+    constexpr int RPB = NW * RPW;
+    for (int64_t base = (int64_t)blockIdx.x * RPB; base < rows; base += (int64_t)gridDim.x * RPB) {
+        f32x4 g[RPW][MAXCH], xv[RPW][MAXCH];
+        float mu[RPW], rs[RPW];
+        int64_t row[RPW];
+        bool ok[RPW];
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {                           // wave w owns rows base + w, + NW, ...: a short last block stays spread
+            const int64_t lrow = base + wave + NW * j;
+            ok[j] = lrow < rows;
+            row[j] = ok[j] ? phys(lrow) : 0;
+            if (ok[j]) {
+                load_row(dy + row[j] * D, D, lane, g[j]);
+                load_row(x + row[j] * D, D, lane, xv[j]);
+                mu[j] = mean[row[j]]; rs[j] = rstd[row[j]];
+            } else {
+#pragma unroll
+                for (int c = 0; c < MAXCH; ++c) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; g[j][c] = z; xv[j][c] = z; }
+                mu[j] = 0.f; rs[j] = 0.f;
+            }
+        }
+        float s1[RPW], s2[RPW];
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            s1[j] = 0.f; s2[j] = 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXCH; ++c) {
+                const int e = (lane + 64 * c) * 4;
+                if (e < D) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float xh = (xv[j][c][i] - mu[j]) * rs[j];
+                        const float dgv = g[j][c][i] * gm[c][i];
+                        ag[c][i] += g[j][c][i] * xh;
+                        ab[c][i] += g[j][c][i];
+                        s1[j] += dgv; s2[j] += dgv * xh;
+                        xv[j][c][i] = xh; g[j][c][i] = dgv;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {                        // the 2 * RPW reductions side by side
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) { s1[j] += __shfl_xor(s1[j], o); s2[j] += __shfl_xor(s2[j], o); }
+        }
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            if (!ok[j]) continue;
+            const float c1 = s1[j] / (float)D, c2 = s2[j] / (float)D;
+#pragma unroll
+            for (int c = 0; c < MAXCH; ++c) {
+                const int e = (lane + 64 * c) * 4;
+                if (e < D) {
+                    f32x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = rs[j] * (g[j][c][i] - c1 - xv[j][c][i] * c2);
+                    store4(dx + row[j] * D + e, o);
+                    if (dx2) {
+                        o = o * dropout_mult4(seed, ((uint64_t)row[j] * D + e) >> 2, drop_p);
+                        store4(dx2 + row[j] * D + e, o);
+                    }
+                }
+            }
+        }
+    }
+    // cross-wave reduction of the column sums: GC chunks per barrier pair, waves added in wave order (fixed: deterministic)
+#pragma unroll
+    for (int c0 = 0; c0 < MAXCH; c0 += GC) {
+        if (c0 * 256 >= D) break;
+        if (c0 > 0) __syncthreads();
+#pragma unroll
+        for (int c = 0; c < GC; ++c) {
+            if (c0 + c < MAXCH) {
+                *reinterpret_cast<f32x4*>(&red[0][wave][c * 256 + lane * 4]) = ag[c0 + c];
+                *reinterpret_cast<f32x4*>(&red[1][wave][c * 256 + lane * 4]) = ab[c0 + c];
+            }
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 2 * GC * 256; idx += NW * 64) {
+            const int kind = idx / (GC * 256), e = idx - kind * (GC * 256);
+            const int col = c0 * 256 + e;
+            if (col < D) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sacc += red[kind][w][e];
+                if (part) part[((int64_t)blockIdx.x * 2 + kind) * D + col] = sacc;
+                else atomicAdd((kind ? dbeta : dgamma) + col, sacc);
+            }
+        }
+    }
+}
+
 // grad[off[kind][job] + col] += sum_b part[job][b][kind][col].  Block = (256-column chunk, kind, job), 16 waves: wave w sums the partial
 // rows b = w, w + 16, ... (lane = 4 consecutive columns, 1 KiB per wave per row, every load of a wave's rows in flight together), the 16
 // wave sums are then added in wave order through LDS -- a fixed order: deterministic.
@@ -405,6 +525,24 @@ void run_ln_bwd(hipStream_t st, const void* dy, const void* x, const float* gamm
     // grid cap: every block ends with 2*D atomics, but a block per CU (one row per wave at the encoder's 2624 rows) measured faster
     // next to other kernels than 128 blocks with two rows per wave (tools/small_kernel_probe.py: 13.3 vs 16.5 us)
     static const unsigned cap = getenv("CB_LN_BWD_BLOCKS") ? (unsigned)atoi(getenv("CB_LN_BWD_BLOCKS")) : 256u;
+    // CB_LN_BWD_GEOM=NW*10+RPW (44 / 82 / 42 / 81): the rows-in-flight kernel above with that block shape (round-6 A/B; 0: the kernel below)
+    const int geom = getenv("CB_LN_BWD_GEOM") ? atoi(getenv("CB_LN_BWD_GEOM")) : 0;      // (read per call: the probe switches it)
+    if constexpr (NCH <= 4) {
+        if (geom != 0) {
+            const int nw = geom / 10, rpw = geom % 10;
+            unsigned blocks = nblk(rows, nw * rpw);
+            if (blocks > cap) blocks = cap;
+            if (part) blocks = (unsigned)part_blocks;
+#define CB_LN_ROWS(NW_, RPW_)                                                                                                              \
+            hipLaunchKernelGGL((layernorm_bwd_rows_kernel<T, NCH, NW_, RPW_>), dim3(blocks), dim3(NW_ * 64), 0, st, (const T*)dy, (const T*)x, gamma, \
+                               mean, rstd, (T*)dx, dgamma, dbeta, rows, D, (T*)dx2, p, seed, seed_ptr, seg_len, seg_stride, seg_off, part)
+            if (nw == 4 && rpw == 4) { CB_LN_ROWS(4, 4); return; }
+            if (nw == 8 && rpw == 2) { CB_LN_ROWS(8, 2); return; }
+            if (nw == 4 && rpw == 2) { CB_LN_ROWS(4, 2); return; }
+            if (nw == 8 && rpw == 1) { CB_LN_ROWS(8, 1); return; }
+#undef CB_LN_ROWS
+        }
+    }
     if constexpr (NCH <= 4) {
         if (rows >= 1024) {                  // many rows: 16 waves per block (see the kernel comment)
             unsigned blocks = nblk(rows, 16);

@@ -1,0 +1,45 @@
+"""LayerNorm backward (cb_layernorm_bwd_part, dropped copy on) at the encoder's row counts: the one-row-per-wave kernel against the
+rows-in-flight kernel (CB_LN_BWD_GEOM = NW * 10 + RPW) over the number of blocks.  24 calls on 24 different buffer sets inside one
+hipGraph (cold-ish operands: 24 x 16 MB), 5 x 20 replays; the step's own figure comes from the kernel trace."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from clipbert_amd import ops
+
+dev = torch.device("cuda", 0)
+D = 768
+g = (1 + 0.1 * torch.randn(D, device=dev))
+res = {}
+for rows in (2624, 2720 * 2, 1312):
+    sets = []
+    for i in range(24):
+        x = torch.randn(rows, D, device=dev).bfloat16(); dy = torch.randn(rows, D, device=dev).bfloat16()
+        mean = x.float().mean(-1); rstd = (x.float().var(-1, unbiased=False) + 1e-12).rsqrt()
+        sets.append((x, dy, mean, rstd, torch.empty_like(x), torch.empty_like(x)))
+    ref = None
+    for geom in (0, 44, 82, 42, 81):
+        os.environ["CB_LN_BWD_GEOM"] = str(geom)
+        for nb in (ops.ln_part_blocks(rows), 256, 128, 328, 512):
+            part = torch.empty(24, nb, 2, D, device=dev)
+
+            def run():
+                for i, (x, dy, mean, rstd, dx, dx2) in enumerate(sets):
+                    ops.layernorm_bwd_part(dy, x, g, mean, rstd, part[i], dropout_p=0.1, dropout_seed=7, dx=dx, dx2=dx2)
+            run(); torch.cuda.synchronize()
+            got = (sets[3][4].clone(), sets[3][5].clone(), part[3].sum(0))
+            if ref is None:
+                ref = got
+            ok = torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.allclose(got[2], ref[2], rtol=1e-4, atol=1e-3)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                run()
+            best = 1e9
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    gr.replay()
+                e1.record(); torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / (20 * 24) * 1e3)
+            print(f"rows {rows} geom {geom:2d} blocks {nb:4d}: {best:6.2f} us/launch  {'ok' if ok else 'MISMATCH'}", flush=True)

@@ -78,6 +78,41 @@ __device__ __forceinline__ void gelu_erf_both(float x, float& y, float& dy) {
     y = x * cdf;
     dy = cdf + x * (0.3989422804014327f * e);
 }
+// Two elements at once in PACKED fp32 (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: one lane-instruction per pair), round 6 -- the
+// bf16 performance mode's GELU epilogue (FFN1 spent 8 of its 12-13.6 us of epilogue on ~35 scalar fp32 VALU slots per
+// element).  Same A&S 7.1.26 rational as above (the 0.5 of Phi folded into its coefficients), exp as ONE v_exp_f32 on a pre-scaled
+// argument (2^(-x^2 log2(e) / 2): __expf costs a multiply more), the branch Phi = x < 0 ? q : 1 - q as 0.5 + copysign(0.5 - q, x).  The fmas
+// are written as fmas (no dependence on what -ffp-contract decides per call site): every bf16 kernel evaluates these exact operations.
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ void gelu_erf_both2(f32x2 x, f32x2& y, f32x2& dy) {
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2 xx = x * x;
+    const f32x2 ea = xx * (-0.72134752044448170368f);                                   // -x^2 / 2 * log2(e)
+    const f32x2 e = {__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1])};     // exp(-x^2 / 2)
+    const f32x2 den = pk_fma(ax, f32x2{0.23164188826636f, 0.23164188826636f}, f32x2{1.0f, 1.0f});   // 1 + 0.3275911 |x| / sqrt 2
+    const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    f32x2 q = pk_fma(f32x2{0.5307027145f, 0.5307027145f}, t, f32x2{-0.7265760135f, -0.7265760135f});
+    q = pk_fma(q, t, f32x2{0.7107068705f, 0.7107068705f});
+    q = pk_fma(q, t, f32x2{-0.142248368f, -0.142248368f});
+    q = pk_fma(q, t, f32x2{0.127414796f, 0.127414796f});
+    q = q * t * e;                                                                      // erfc(|x| / sqrt 2) / 2
+    const f32x2 hm = f32x2{0.5f, 0.5f} - q;
+    const f32x2 cdf = f32x2{0.5f, 0.5f} + f32x2{__builtin_copysignf(hm[0], x[0]), __builtin_copysignf(hm[1], x[1])};
+    y = x * cdf;
+    dy = pk_fma(x, e * 0.3989422804014327f, cdf);
+}
+// scalar faces of the packed evaluation: EVERY bf16-mode GELU of the library goes through gelu_erf_both2, so that kernels with different
+// epilogue structures (4-wave / 8-wave, generic / specialised, with or without the stored derivative) produce the same bits
+__device__ __forceinline__ float gelu_erf_pk(float x) {
+    f32x2 y, dy;
+    gelu_erf_both2(f32x2{x, x}, y, dy);
+    return y[0];
+}
+__device__ __forceinline__ void gelu_erf_both_pk(float x, float& y, float& dy) {
+    f32x2 yy, dd;
+    gelu_erf_both2(f32x2{x, x}, yy, dd);
+    y = yy[0]; dy = dd[0];
+}
 __device__ __forceinline__ float apply_act(int act, float v) {
     switch (act) {
         case CB_ACT_RELU: return v > 0.f ? v : 0.f;

@@ -304,6 +304,22 @@ int gemm_prepare(const cb_gemm_desc* d, Prepared& out) {
         const bool ok = d->dtype == CB_BF16 && !d->c_f32 && (int64_t)d->M * (d->ldc > d->ldc2 ? d->ldc : d->ldc2) * 2 * (p.batch) < 0xffffffffll && !d->c_rowmap;
         p.wt = ok ? wt : 0;
     }
+    {   // specialised epilogue of the 8-wave kernels (FE_* in gemm_impl.h); CB_GEMM_FAST_EPI=0: the generic one for everything
+        static const bool fe_off = getenv("CB_GEMM_FAST_EPI") != nullptr && atoi(getenv("CB_GEMM_FAST_EPI")) == 0;
+        p.fast_epi = FE_NONE;
+        const bool plain = !fe_off && p.wt == 1 && p.batch == 1 && !d->accumulate && p.alpha == 1.f && !d->scale && !d->zero_fill_pitch && !d->relu_bwd && !d->mask &&
+                           !d->relu_after && d->dropout_p <= 0.f && !d->residual && !d->a_rowsum && d->N % 8 == 0 && d->ldc % 8 == 0 && aligned16(d->C) &&
+                           (!d->shift || aligned16(d->shift));
+        if (plain) {
+            if (!d->gelu_grad_pre && !d->C2 && d->act == CB_ACT_NONE) p.fast_epi = FE_BIAS;
+            else if (!d->gelu_grad_pre && d->C2 && d->act == CB_ACT_GELU_SAVE_GRAD && d->shift && d->ldc2 % 8 == 0 && aligned16(d->C2) &&
+                     (int64_t)d->M * d->ldc2 * 2 < 0xffffffffll)
+                p.fast_epi = FE_GELU2;
+            else if (d->gelu_grad_pre && d->act == CB_ACT_SAVED_GRAD && !d->C2 && !d->shift && d->ld_gelu % 8 == 0 && aligned16(d->gelu_grad_pre) &&
+                     (int64_t)d->M * d->ld_gelu * 2 < 0x7fffffffll)
+                p.fast_epi = FE_MULAUX;
+        }
+    }
     const bool a_krow = d->a_mode == CB_KROW;
     const bool b_krow = d->b_mode == CB_KROW || d->b_mode == CB_KROW_TAPS || d->b_mode == CB_KROW_GATHER;
     CB_REQUIRE(d->a_mode == CB_ROWK || d->a_mode == CB_ROWK_GATHER || d->a_mode == CB_KROW, "cb_gemm: bad a_mode %d", d->a_mode);

@@ -43,10 +43,21 @@ struct GP {
     int raster_w;               // > 0: the XCD-compact tile order walks column panels of this many N tiles (tile_id)
     int wt;                     // 1: the row-contiguous epilogue's bf16 C / C2 stores are write-through (sc1), see store8_wt
     int slab_base, cnt_base;    // grouped launch with slab K split (gemm_tile): this problem's first slab unit / first tile counter
+    int fast_epi;               // FE_*: the 8-wave kernels' specialised epilogue for this call (gemm8_impl.h tile_epilogue8w_fast), 0: generic
 #ifdef CB_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/stamps_*.py): this launch's record area, or null
 #endif
 };
+
+// Specialised epilogues of the 8-wave kernels (round 6): the generic epilogue8 resolves every option of cb_gemm_desc by wave-uniform runtime
+// branches around 64-bit address arithmetic; the encoder's three hottest launches get straight-line bodies instead (chosen on the host,
+// gemm_prepare): bf16 C (and C2) through write-through buffer stores at 32-bit offsets, alpha 1, no scale / row map / residual / mask /
+// dropout / accumulate.
+enum { FE_NONE = 0,
+       FE_BIAS = 1,        // C = acc (+ shift)                                             -- fused QKV projection, plain products
+       FE_GELU2 = 2,       // C = gelu(acc + shift), C2 = gelu'(acc + shift), packed fp32   -- BertIntermediate forward (training)
+       FE_MULAUX = 3 };    // C = acc * aux (aux = the stored gelu', CB_ACT_SAVED_GRAD); every chunk's aux load is issued BEFORE the
+                           // staging passes: one memory round trip instead of one per chunk  -- data gradient of BertOutput.dense
 
 // ---------------------------------------------------------------------------------------------
 // In-kernel time stamps (diagnostic build -DCB_STAMPS only, never the product library): thread 0 of a workgroup reads the
@@ -701,6 +712,16 @@ __device__ __forceinline__ void apply_batch(GP& p, TileId& t) {
 // ---------------------------------------------------------------------------------------------
 // Epilogue of one 4-wide accumulator fragment (row m, columns nb..nb+3).
 // ---------------------------------------------------------------------------------------------
+// activation of one element: the bf16 mode's GELU is the packed evaluation everywhere (common.h gelu_erf_both2), the fp32 parity mode's
+// the 1.5e-7 scalar one
+template <typename T>
+__device__ __forceinline__ float act_of(int act, float v) {
+    if constexpr (sizeof(T) == 2) {
+        if (act == CB_ACT_GELU || act == CB_ACT_GELU_SAVE_GRAD) return gelu_erf_pk(v);
+    }
+    return apply_act(act, v);
+}
+
 template <typename T>
 __device__ __forceinline__ void epilogue_vec(const GP& p, f32x4 v, int m, int64_t orow, int nb) {
     v = v * p.alpha;
@@ -722,7 +743,8 @@ __device__ __forceinline__ void epilogue_vec(const GP& p, f32x4 v, int m, int64_
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float y, dy;
-            gelu_erf_both(v[r], y, dy);
+            if constexpr (sizeof(T) == 2) gelu_erf_both_pk(v[r], y, dy);
+            else gelu_erf_both(v[r], y, dy);
             v[r] = y; dv[r] = dy;
         }
         store4(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + nb, dv);
@@ -730,7 +752,7 @@ __device__ __forceinline__ void epilogue_vec(const GP& p, f32x4 v, int m, int64_
         if (p.C2) store4(reinterpret_cast<T*>(p.C2) + orow * p.ldc2 + nb, v);
         if (p.act != CB_ACT_NONE) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = apply_act(p.act, v[r]);
+            for (int r = 0; r < 4; ++r) v[r] = act_of<T>(p.act, v[r]);
         }
     }
     if (p.dropout_p > 0.f) {
@@ -784,11 +806,12 @@ __device__ __forceinline__ void epilogue_elem(const GP& p, float x, int m, int64
     if (p.shift) x += p.shift[n];
     if (p.act == CB_ACT_GELU_SAVE_GRAD && p.C2) {
         float dx;
-        gelu_erf_both(x, x, dx);
+        if constexpr (sizeof(T) == 2) gelu_erf_both_pk(x, x, dx);
+        else gelu_erf_both(x, x, dx);
         reinterpret_cast<T*>(p.C2)[orow * p.ldc2 + n] = from_f32<T>(dx);
     } else {
         if (p.C2) reinterpret_cast<T*>(p.C2)[orow * p.ldc2 + n] = from_f32<T>(x);
-        x = apply_act(p.act, x);
+        x = act_of<T>(p.act, x);
     }
     if (p.dropout_p > 0.f) x *= dropout_mult1(p.seed, (uint64_t)m * ((p.N + 3) >> 2) + (n >> 2), n & 3, p.dropout_p);
     if (p.residual) x += to_f32(reinterpret_cast<const T*>(p.residual)[orow * p.ldr + n]);
@@ -945,7 +968,16 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
     float dv[8];
     if (save_grad) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) gelu_erf_both(v[r], v[r], dv[r]);
+        for (int r = 0; r < 8; r += 2) {
+            if constexpr (sizeof(T) == 2) {
+                f32x2 y, dy;
+                gelu_erf_both2(f32x2{v[r], v[r + 1]}, y, dy);
+                v[r] = y[0]; v[r + 1] = y[1]; dv[r] = dy[0]; dv[r + 1] = dy[1];
+            } else {
+                gelu_erf_both(v[r], v[r], dv[r]);
+                gelu_erf_both(v[r + 1], v[r + 1], dv[r + 1]);
+            }
+        }
     }
     if (p.C2) {
         const float (&w)[8] = save_grad ? dv : v;
@@ -957,7 +989,7 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
     }
     if (p.act != CB_ACT_NONE && !save_grad) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = apply_act(p.act, v[r]);
+        for (int r = 0; r < 8; ++r) v[r] = act_of<T>(p.act, v[r]);
     }
     if (p.dropout_p > 0.f) {
         const uint64_t grp = (uint64_t)m * ((p.N + 3) >> 2) + (n >> 2);

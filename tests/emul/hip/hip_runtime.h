@@ -299,6 +299,7 @@ static inline int atomicExch(int* p, int v) { return __atomic_exchange_n(p, v, _
 // ---- math ----------------------------------------------------------------------------------
 #define __expf(x) expf(x)
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 #define __logf(x) logf(x)
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __fdividef(float a, float b) { return a / b; }

@@ -304,20 +304,34 @@ int gemm_prepare(const cb_gemm_desc* d, Prepared& out) {
         const bool ok = d->dtype == CB_BF16 && !d->c_f32 && (int64_t)d->M * (d->ldc > d->ldc2 ? d->ldc : d->ldc2) * 2 * (p.batch) < 0xffffffffll && !d->c_rowmap;
         p.wt = ok ? wt : 0;
     }
-    {   // specialised epilogue of the 8-wave kernels (FE_* in gemm_impl.h); CB_GEMM_FAST_EPI=0: the generic one for everything
+    {   // specialised epilogue (FAST_EPI_COMBOS in gemm_impl.h): the call's option combination, if it is one of the listed ones and the
+        // row-contiguous bf16 write-through epilogue applies; CB_GEMM_FAST_EPI=0: the generic epilogue8 for everything
         static const bool fe_off = getenv("CB_GEMM_FAST_EPI") != nullptr && atoi(getenv("CB_GEMM_FAST_EPI")) == 0;
-        p.fast_epi = FE_NONE;
-        const bool plain = !fe_off && p.wt == 1 && p.batch == 1 && !d->accumulate && p.alpha == 1.f && !d->scale && !d->zero_fill_pitch && !d->relu_bwd && !d->mask &&
-                           !d->relu_after && d->dropout_p <= 0.f && !d->residual && !d->a_rowsum && d->N % 8 == 0 && d->ldc % 8 == 0 && aligned16(d->C) &&
-                           (!d->shift || aligned16(d->shift));
+        p.fast_epi = 0;
+        auto rows_ok = [&](const void* q, int64_t ld) { return q == nullptr || (ld % 8 == 0 && aligned16(q) && (int64_t)d->M * ld * 2 < 0x7fffffffll); };
+        const bool plain = !fe_off && p.wt == 1 && p.batch == 1 && !d->accumulate && p.alpha == 1.f && !d->zero_fill_pitch && !d->relu_bwd && !d->a_rowsum &&
+                           d->N % 8 == 0 && d->ldc % 8 == 0 && aligned16(d->C) && (!d->shift || aligned16(d->shift)) && (!d->scale || aligned16(d->scale)) &&
+                           rows_ok(d->residual, d->ldr) && rows_ok(d->mask, d->ldm) && rows_ok(d->gelu_grad_pre, d->ld_gelu) &&
+                           !(d->mask && d->gelu_grad_pre);
         if (plain) {
-            if (!d->gelu_grad_pre && !d->C2 && d->act == CB_ACT_NONE) p.fast_epi = FE_BIAS;
-            else if (!d->gelu_grad_pre && d->C2 && d->act == CB_ACT_GELU_SAVE_GRAD && d->shift && d->ldc2 % 8 == 0 && aligned16(d->C2) &&
-                     (int64_t)d->M * d->ldc2 * 2 < 0xffffffffll)
-                p.fast_epi = FE_GELU2;
-            else if (d->gelu_grad_pre && d->act == CB_ACT_SAVED_GRAD && !d->C2 && !d->shift && d->ld_gelu % 8 == 0 && aligned16(d->gelu_grad_pre) &&
-                     (int64_t)d->M * d->ld_gelu * 2 < 0x7fffffffll)
-                p.fast_epi = FE_MULAUX;
+            int flags = 0;
+            bool ok = true;
+            if (d->scale) flags |= EF_SCALE;
+            if (d->shift) flags |= EF_SHIFT;
+            if (d->act == CB_ACT_RELU) flags |= EF_RELU;
+            else if (d->act == CB_ACT_GELU_SAVE_GRAD && d->C2) flags |= EF_GELU2;
+            else if (d->act == CB_ACT_SAVED_GRAD && d->gelu_grad_pre) flags |= EF_MULAUX;
+            else if (d->act != CB_ACT_NONE) ok = false;
+            if (d->C2 && !(flags & EF_GELU2)) ok = false;                    // (a second output only as the stored derivative)
+            if (d->C2) ok = ok && d->ldc2 % 8 == 0 && aligned16(d->C2) && (int64_t)d->M * d->ldc2 * 2 < 0xffffffffll;
+            if (d->gelu_grad_pre && !(flags & EF_MULAUX)) ok = false;        // (GELU' evaluated from the pre-activation: generic path)
+            if (d->dropout_p > 0.f) flags |= EF_DROP;
+            if (d->residual) flags |= EF_RES;
+            if (d->relu_after) flags |= EF_RELU_AFTER;
+            if (d->mask) flags |= EF_MASK;
+            if (ok)
+                for (int i = 1; i < FAST_EPI_N; ++i)
+                    if (FAST_EPI_COMBOS[i] == flags) { p.fast_epi = i; break; }
         }
     }
     const bool a_krow = d->a_mode == CB_KROW;

@@ -202,127 +202,34 @@ template <int ROWS, int KMODE> struct KrowDma8 {
 // executes ONCE, i.e. entirely out of instruction-cache misses: ~1.1 us per chunk, 9 us for a bias-only 128x256 tile, 17 us for FFN1's
 // GELU + two outputs (longer than its 11 us K loop).  The pass loop and the chunk loop are therefore ROLLED: one copy of the body, warm
 // after its first trip.  Only the accumulator -> LDS staging needs compile-time register indices: a switch over the WM / PR row blocks.
-// The specialised form (GP::fast_epi, see the FE_* kinds in gemm_impl.h): same staging through LDS, same (row, 8-column chunk) ownership,
-// but a straight-line body per kind -- no runtime option branches, 32-bit buffer offsets, packed fp32 math.  FE_BIAS / FE_GELU2 keep the
-// rolled pass / chunk loops (the GELU body is ~2 KB: one warm copy); FE_MULAUX is unrolled: its body is a dozen instructions and its
-// point is that the aux loads of ALL chunks leave before the first staging barrier.
-template <int BM, int BN, int WGM, int WGN, int SMEM_BYTES, int PR = 64>
-__device__ __forceinline__ void tile_epilogue8w_fast(const GP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], unsigned char* smem, int m0,
-                                                     int n0, int tid) {
-    constexpr int WM = BM / WGM, WN = BN / WGN, FN = WN / 16;
-    constexpr int SROW = BN * 4 + 16;
-    constexpr int CPR = BN / 8, ITER = PR * CPR / NT8;
-    constexpr int NPASS = BM / PR, SUB = WM / PR;
-    static_assert(WM % PR == 0 && PR * SROW <= SMEM_BYTES && PR * CPR % NT8 == 0 && NT8 % CPR == 0, "epilogue staging");
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int cc = tid % CPR, n = n0 + cc * 8;
-    const bool nok = n < p.N;
-    const int rl0 = tid / CPR;                                  // this thread's row inside a pass, chunk `it` adds it * (NT8 / CPR)
-    unsigned char* const stage_base = smem + (lane & 15) * SROW + (wn * WN + 4 * (lane >> 4)) * 4;
-    const unsigned char* const read_base = smem + rl0 * SROW + cc * 32;
-    const rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, (short)0, (int)0xffffffffu, 0x00020000);
-    const uint32_t ldc2b = (uint32_t)p.ldc * 2u;
-    auto stage = [&](int h) __attribute__((always_inline)) {
-        if (wm == h / SUB) {
-            const int sub = h % SUB;
-#pragma unroll
-            for (int sb = 0; sb < SUB; ++sb) {
-                if (sb == sub) {
-#pragma unroll
-                    for (int i = 0; i < PR / 16; ++i)
-#pragma unroll
-                        for (int j = 0; j < FN; ++j)
-                            *reinterpret_cast<f32x4*>(stage_base + i * 16 * SROW + j * 64) = acc[sb * (PR / 16) + i][j];
-                }
-            }
-        }
-    };
-    auto pack8 = [](const f32x2 (&v)[4]) __attribute__((always_inline)) {
-        union { bf16x8 x; u32x4 r; } u;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { u.x[2 * r] = (bf16)v[r][0]; u.x[2 * r + 1] = (bf16)v[r][1]; }
-        return u.r;
-    };
-    if (p.fast_epi == FE_MULAUX) {
-        constexpr int NCH = NPASS * ITER;
-        constexpr bool ALL = NCH <= 8;                           // every chunk's aux in flight at once (32 VGPRs), else pass by pass
-        const rsrc_t ra = make_rsrc(p.dact_pre, (uint32_t)((int64_t)p.M * p.ldd * 2));
-        const uint32_t ldd2b = (uint32_t)p.ldd * 2u;
-        u32x4 aux[ALL ? NCH : ITER];
-        auto request = [&](int h) __attribute__((always_inline)) {
-#pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const int m = m0 + h * PR + rl0 + it * (NT8 / CPR);
-                aux[(ALL ? h * ITER : 0) + it] = bload16(ra, (m < p.M && nok) ? (uint32_t)m * ldd2b + (uint32_t)n * 2u : OOB);
-            }
-        };
-        if constexpr (ALL) {
-#pragma unroll
-            for (int h = 0; h < NPASS; ++h) request(h);
-        }
-#pragma unroll
-        for (int h = 0; h < NPASS; ++h) {
-            if constexpr (!ALL) request(h);
-            __syncthreads();
-            stage(h);
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const int m = m0 + h * PR + rl0 + it * (NT8 / CPR);
-                if (m < p.M && nok) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(read_base + it * (NT8 / CPR) * SROW);
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(read_base + it * (NT8 / CPR) * SROW + 16);
-                    union { u32x4 r; bf16x8 x; } g;
-                    g.r = aux[(ALL ? h * ITER : 0) + it];
-                    f32x2 v[4] = {{a[0], a[1]}, {a[2], a[3]}, {b[0], b[1]}, {b[2], b[3]}};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = v[r] * f32x2{(float)g.x[2 * r], (float)g.x[2 * r + 1]};
-                    __builtin_amdgcn_raw_buffer_store_b128(pack8(v), rc, (uint32_t)m * ldc2b + (uint32_t)n * 2u, 0, 16 /* sc1 */);
-                }
-            }
-        }
-        return;
-    }
-    f32x2 sh[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-    if (p.shift && nok) {
-        const f32x4 a = load4(p.shift + n), b = load4(p.shift + n + 4);
-        sh[0] = f32x2{a[0], a[1]}; sh[1] = f32x2{a[2], a[3]}; sh[2] = f32x2{b[0], b[1]}; sh[3] = f32x2{b[2], b[3]};
-    }
-    const bool gelu = p.fast_epi == FE_GELU2;
-    const rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc(gelu ? p.C2 : p.C, (short)0, (int)0xffffffffu, 0x00020000);
-    const uint32_t ldc22b = (uint32_t)p.ldc2 * 2u;
-#pragma unroll 1
-    for (int h = 0; h < NPASS; ++h) {
-        __syncthreads();
-        stage(h);
-        __syncthreads();
-#pragma unroll 1
-        for (int it = 0; it < ITER; ++it) {
-            const int m = m0 + h * PR + rl0 + it * (NT8 / CPR);
-            if (m < p.M && nok) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(read_base + it * (NT8 / CPR) * SROW);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(read_base + it * (NT8 / CPR) * SROW + 16);
-                f32x2 v[4] = {f32x2{a[0], a[1]} + sh[0], f32x2{a[2], a[3]} + sh[1], f32x2{b[0], b[1]} + sh[2], f32x2{b[2], b[3]} + sh[3]};
-                if (gelu) {
-                    f32x2 dv[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) gelu_erf_both2(v[r], v[r], dv[r]);
-                    __builtin_amdgcn_raw_buffer_store_b128(pack8(dv), rc2, (uint32_t)m * ldc22b + (uint32_t)n * 2u, 0, 16 /* sc1 */);
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(pack8(v), rc, (uint32_t)m * ldc2b + (uint32_t)n * 2u, 0, 16 /* sc1 */);
-            }
-        }
-    }
-}
-
 template <int BM, int BN, int WGM, int WGN, int SMEM_BYTES, int PR = 64, bool RAW = false>
 __device__ __forceinline__ void tile_epilogue8w(GP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], unsigned char* smem, int m0, int n0,
                                                 int tid, float* slab) {
     using T = bf16;
     if constexpr (!RAW) {
-        if (!slab && p.fast_epi != FE_NONE) {                   // (wave-uniform: a kernel argument)
-            tile_epilogue8w_fast<BM, BN, WGM, WGN, SMEM_BYTES, PR>(p, acc, smem, m0, n0, tid);
+        if (!slab && p.fast_epi != 0) {                         // specialised body for this call's option combination (gemm_impl.h fast_epilogue)
+            constexpr int WM_ = BM / WGM, WN_ = BN / WGN, FN_ = WN_ / 16, SROW_ = BN * 4 + 16, SUB_ = WM_ / PR;
+            static_assert(WM_ % PR == 0 && PR * SROW_ <= SMEM_BYTES, "epilogue staging");
+            const int lane_ = tid & 63, wave_ = tid >> 6;
+            const int wm_ = wave_ / WGN, wn_ = wave_ % WGN;
+            if (p.dropout_p > 0.f && p.seed_ptr) p.seed += *p.seed_ptr;
+            unsigned char* const sb_ = smem + (lane_ & 15) * SROW_ + (wn_ * WN_ + 4 * (lane_ >> 4)) * 4;
+            auto stage = [&](int h) __attribute__((always_inline)) {
+                if (wm_ == h / SUB_) {
+                    const int sub = h % SUB_;
+#pragma unroll
+                    for (int sb = 0; sb < SUB_; ++sb) {
+                        if (sb == sub) {
+#pragma unroll
+                            for (int i = 0; i < PR / 16; ++i)
+#pragma unroll
+                                for (int j = 0; j < FN_; ++j)
+                                    *reinterpret_cast<f32x4*>(sb_ + i * 16 * SROW_ + j * 64) = acc[sb * (PR / 16) + i][j];
+                        }
+                    }
+                }
+            };
+            fast_epilogue_dispatch<NT8, BN, PR, BM / PR>(p, smem, m0, n0, tid, stage);
             return;
         }
     }

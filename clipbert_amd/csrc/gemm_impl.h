@@ -43,21 +43,34 @@ struct GP {
     int raster_w;               // > 0: the XCD-compact tile order walks column panels of this many N tiles (tile_id)
     int wt;                     // 1: the row-contiguous epilogue's bf16 C / C2 stores are write-through (sc1), see store8_wt
     int slab_base, cnt_base;    // grouped launch with slab K split (gemm_tile): this problem's first slab unit / first tile counter
-    int fast_epi;               // FE_*: the 8-wave kernels' specialised epilogue for this call (gemm8_impl.h tile_epilogue8w_fast), 0: generic
+    int fast_epi;               // index into FAST_EPI_COMBOS: the specialised epilogue of this call (fast_epilogue), 0: the generic epilogue8
 #ifdef CB_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/stamps_*.py): this launch's record area, or null
 #endif
 };
 
-// Specialised epilogues of the 8-wave kernels (round 6): the generic epilogue8 resolves every option of cb_gemm_desc by wave-uniform runtime
-// branches around 64-bit address arithmetic; the encoder's three hottest launches get straight-line bodies instead (chosen on the host,
-// gemm_prepare): bf16 C (and C2) through write-through buffer stores at 32-bit offsets, alpha 1, no scale / row map / residual / mask /
-// dropout / accumulate.
-enum { FE_NONE = 0,
-       FE_BIAS = 1,        // C = acc (+ shift)                                             -- fused QKV projection, plain products
-       FE_GELU2 = 2,       // C = gelu(acc + shift), C2 = gelu'(acc + shift), packed fp32   -- BertIntermediate forward (training)
-       FE_MULAUX = 3 };    // C = acc * aux (aux = the stored gelu', CB_ACT_SAVED_GRAD); every chunk's aux load is issued BEFORE the
-                           // staging passes: one memory round trip instead of one per chunk  -- data gradient of BertOutput.dense
+// Specialised epilogues (round 6).  The generic epilogue8 resolves every option of cb_gemm_desc by wave-uniform runtime branches around
+// 64-bit address arithmetic and loads its M x N operands (residual / mask / stored derivative) one chunk after the other, each a
+// dependent memory round trip.  The launches that make up the training step use a dozen option COMBINATIONS; each gets a straight-line
+// body (fast_epilogue<FLAGS> below: `if constexpr` per option, packed fp32 math, 32-bit buffer offsets, write-through stores) whose
+// operand loads leave BEFORE the staging barriers.  The host (gemm_prepare) maps a call's options to the index of its combination
+// (GP::fast_epi, 0 = none: generic path); bf16 row-contiguous epilogues only, alpha 1, no row map / zero fill / accumulate / relu_bwd.
+enum { EF_SCALE = 1, EF_SHIFT = 2, EF_RELU = 4, EF_GELU2 = 8, EF_DROP = 16, EF_RES = 32, EF_RELU_AFTER = 64, EF_MASK = 128, EF_MULAUX = 256 };
+constexpr int FAST_EPI_COMBOS[] = {
+    -1,                                                  // 0: generic
+    0,                                                   // 1: C = acc                                  (data gradients without epilogue, grid conv)
+    EF_SHIFT,                                            // 2: + bias                                   (fused QKV projection)
+    EF_SHIFT | EF_GELU2,                                 // 3: C = gelu(.), C2 = gelu'(.)               (BertIntermediate forward, training)
+    EF_SHIFT | EF_DROP | EF_RES,                         // 4: bias, dropout, + residual                (BertSelfOutput / BertOutput dense, training)
+    EF_SHIFT | EF_RES,                                   // 5: the same in eval
+    EF_MULAUX,                                           // 6: x stored gelu'                           (data gradient of BertOutput.dense)
+    EF_RES,                                              // 7: + residual                               (data gradients that close a residual branch)
+    EF_SCALE | EF_SHIFT | EF_RELU,                       // 8: FrozenBN + ReLU                          (bottleneck conv1 / conv2)
+    EF_SCALE | EF_SHIFT,                                 // 9: FrozenBN                                 (projection shortcut)
+    EF_SCALE | EF_SHIFT | EF_RES | EF_RELU_AFTER,        // 10: FrozenBN + shortcut + ReLU              (bottleneck conv3)
+    EF_SCALE | EF_MASK,                                  // 11: x FrozenBN scale where the producer's ReLU was open (data gradients inside a block)
+};
+constexpr int FAST_EPI_N = sizeof(FAST_EPI_COMBOS) / sizeof(int);
 
 // ---------------------------------------------------------------------------------------------
 // In-kernel time stamps (diagnostic build -DCB_STAMPS only, never the product library): thread 0 of a workgroup reads the
@@ -1053,6 +1066,160 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
 }
 
 // ---------------------------------------------------------------------------------------------
+// fast_epilogue<FLAGS, NT, BN, PR, NPASS>: the specialised row-contiguous bf16 epilogue of a tile (see FAST_EPI_COMBOS).  Geometry as in
+// tile_epilogue / tile_epilogue8w: NT threads, NPASS passes of PR tile rows through the staging area [PR][BN * 4 + 16 B]; `stage(h)` writes
+// the calling thread's share of pass h's accumulators (the caller knows its wave grid).  A thread owns the 8-column chunk cc = tid % (BN / 8)
+// of the rows rl0 + it * (NT / CPR), it < ITER, of every pass.  The M x N operands of ALL chunks of a pass (of all passes when there are
+// at most 8 chunks) are requested before the pass's first barrier: they land while the tile is staged.  The pass loop stays rolled when
+// there are more than two passes, and for the GELU body (~2 KB): one warm copy in the instruction cache.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32x4 pack_bf16x8(const f32x2 (&v)[4]) {
+    union { bf16x8 x; u32x4 r; } u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { u.x[2 * r] = (bf16)v[r][0]; u.x[2 * r + 1] = (bf16)v[r][1]; }
+    return u.r;
+}
+__device__ __forceinline__ void unpack_bf16x8(u32x4 raw, f32x2 (&v)[4]) {
+    union { u32x4 r; bf16x8 x; } u;
+    u.r = raw;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = f32x2{(float)u.x[2 * r], (float)u.x[2 * r + 1]};
+}
+
+template <int FLAGS, int NT, int BN, int PR, int NPASS, typename StageFn>
+__device__ __forceinline__ void fast_epilogue(const GP& p, unsigned char* smem, int m0, int n0, int tid, StageFn stage) {
+    constexpr int SROW = BN * 4 + 16, CPR = BN / 8, ITER = PR * CPR / NT, RSTEP = NT / CPR, NCH = NPASS * ITER;
+    static_assert(PR * CPR % NT == 0 && NT % CPR == 0, "chunk map");
+    constexpr bool HAS_RES = (FLAGS & EF_RES) != 0, HAS_AUX = (FLAGS & (EF_MASK | EF_MULAUX)) != 0;
+    constexpr bool ALL = NCH <= 8;                               // every chunk's operands in flight at once, else pass by pass
+    constexpr bool ROLL = (FLAGS & EF_GELU2) != 0 || NPASS > 2;
+    const int cc = tid % CPR, n = n0 + cc * 8, rl0 = tid / CPR;
+    const bool nok = n < p.N;
+    const unsigned char* const read_base = smem + rl0 * SROW + cc * 32;
+    const rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, (short)0, (int)0xffffffffu, 0x00020000);
+    const rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc((FLAGS & EF_GELU2) ? p.C2 : p.C, (short)0, (int)0xffffffffu, 0x00020000);
+    const uint32_t ldcb = (uint32_t)p.ldc * 2u, ldc2b = (uint32_t)p.ldc2 * 2u, nb = (uint32_t)n * 2u;
+    // operands are read through range-checked descriptors: rows past M (and chunks past N) take the out-of-range offset and read zeros
+    const rsrc_t rr = make_rsrc(HAS_RES ? p.residual : p.C, HAS_RES ? (uint32_t)((int64_t)p.M * p.ldr * 2) : 0u);
+    const void* auxp = (FLAGS & EF_MASK) ? p.mask : p.dact_pre;
+    const int64_t lda = (FLAGS & EF_MASK) ? p.ldm : p.ldd;
+    const rsrc_t ra = make_rsrc(HAS_AUX ? auxp : p.C, HAS_AUX ? (uint32_t)((int64_t)p.M * lda * 2) : 0u);
+    const uint32_t ldrb = (uint32_t)p.ldr * 2u, ldab = (uint32_t)lda * 2u;
+    f32x2 sc[4], sh[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { sc[r] = f32x2{1.f, 1.f}; sh[r] = f32x2{0.f, 0.f}; }
+    if (nok) {
+        if constexpr ((FLAGS & EF_SCALE) != 0) {
+            const f32x4 a = load4(p.scale + n), b = load4(p.scale + n + 4);
+            sc[0] = f32x2{a[0], a[1]}; sc[1] = f32x2{a[2], a[3]}; sc[2] = f32x2{b[0], b[1]}; sc[3] = f32x2{b[2], b[3]};
+        }
+        if constexpr ((FLAGS & EF_SHIFT) != 0) {
+            const f32x4 a = load4(p.shift + n), b = load4(p.shift + n + 4);
+            sh[0] = f32x2{a[0], a[1]}; sh[1] = f32x2{a[2], a[3]}; sh[2] = f32x2{b[0], b[1]}; sh[3] = f32x2{b[2], b[3]};
+        }
+    }
+    u32x4 res[HAS_RES ? (ALL ? NCH : ITER) : 1], aux[HAS_AUX ? (ALL ? NCH : ITER) : 1];
+    auto request = [&](int h) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int m = m0 + h * PR + rl0 + it * RSTEP;
+            const bool ok = m < p.M && nok;
+            if constexpr (HAS_RES) res[(ALL ? h * ITER : 0) + it] = bload16(rr, ok ? (uint32_t)m * ldrb + nb : OOB);
+            if constexpr (HAS_AUX) aux[(ALL ? h * ITER : 0) + it] = bload16(ra, ok ? (uint32_t)m * ldab + nb : OOB);
+        }
+    };
+    auto chunk = [&](int h, int it, int slot) __attribute__((always_inline)) {
+        const int m = m0 + h * PR + rl0 + it * RSTEP;
+        if (!(m < p.M && nok)) return;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(read_base + it * RSTEP * SROW);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(read_base + it * RSTEP * SROW + 16);
+        f32x2 v[4] = {f32x2{a[0], a[1]}, f32x2{a[2], a[3]}, f32x2{b[0], b[1]}, f32x2{b[2], b[3]}};
+        {   // scale, then shift, as TWO roundings -- what the generic epilogue8 does behind its runtime branches; the streaming kernel and the
+            // K-split reduce run that one and must stay bit-identical to this path (tests/test_gemm_stream.py)
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr ((FLAGS & EF_SCALE) != 0) v[r] = v[r] * sc[r];
+                if constexpr ((FLAGS & EF_SHIFT) != 0) v[r] = v[r] + sh[r];
+            }
+        }
+        if constexpr ((FLAGS & EF_GELU2) != 0) {
+            f32x2 dv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gelu_erf_both2(v[r], v[r], dv[r]);
+            __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(dv), rc2, (uint32_t)m * ldc2b + nb, 0, 16 /* sc1 */);
+        }
+        if constexpr ((FLAGS & EF_RELU) != 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = f32x2{fmaxf(v[r][0], 0.f), fmaxf(v[r][1], 0.f)};
+        }
+        if constexpr ((FLAGS & EF_DROP) != 0) {
+            const uint64_t grp = (uint64_t)m * ((p.N + 3) >> 2) + (n >> 2);
+            const f32x4 d0 = dropout_mult4(p.seed, grp, p.dropout_p), d1 = dropout_mult4(p.seed, grp + 1, p.dropout_p);
+            v[0] = v[0] * f32x2{d0[0], d0[1]}; v[1] = v[1] * f32x2{d0[2], d0[3]};
+            v[2] = v[2] * f32x2{d1[0], d1[1]}; v[3] = v[3] * f32x2{d1[2], d1[3]};
+        }
+        if constexpr (HAS_RES) {
+            f32x2 t[4];
+            unpack_bf16x8(res[slot], t);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] + t[r];
+        }
+        if constexpr ((FLAGS & EF_RELU_AFTER) != 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = f32x2{fmaxf(v[r][0], 0.f), fmaxf(v[r][1], 0.f)};
+        }
+        if constexpr (HAS_AUX) {
+            f32x2 t[4];
+            unpack_bf16x8(aux[slot], t);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr ((FLAGS & EF_MASK) != 0) v[r] = f32x2{t[r][0] > 0.f ? v[r][0] : 0.f, t[r][1] > 0.f ? v[r][1] : 0.f};
+                else v[r] = v[r] * t[r];
+            }
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v), rc, (uint32_t)m * ldcb + nb, 0, 16 /* sc1 */);
+    };
+    auto pass = [&](int h) __attribute__((always_inline)) {
+        if constexpr ((HAS_RES || HAS_AUX) && !ALL) request(h);
+        __syncthreads();
+        stage(h);
+        __syncthreads();
+        if constexpr ((FLAGS & EF_GELU2) != 0) {
+#pragma unroll 1
+            for (int it = 0; it < ITER; ++it) chunk(h, it, 0);
+        } else {
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) chunk(h, it, (ALL ? h * ITER : 0) + it);
+        }
+    };
+    if constexpr ((HAS_RES || HAS_AUX) && ALL) {
+#pragma unroll
+        for (int h = 0; h < NPASS; ++h) request(h);
+    }
+    if constexpr (ROLL && !((HAS_RES || HAS_AUX) && ALL)) {
+#pragma unroll 1
+        for (int h = 0; h < NPASS; ++h) pass(h);
+    } else {
+#pragma unroll
+        for (int h = 0; h < NPASS; ++h) pass(h);
+    }
+}
+
+// runtime index -> compile-time combination (a wave-uniform switch: the kernel argument lives in SGPRs)
+template <int NT, int BN, int PR, int NPASS, typename StageFn>
+__device__ __forceinline__ void fast_epilogue_dispatch(const GP& p, unsigned char* smem, int m0, int n0, int tid, StageFn stage) {
+    switch (p.fast_epi) {
+#define CB_FE_CASE(I) case I: fast_epilogue<FAST_EPI_COMBOS[I], NT, BN, PR, NPASS>(p, smem, m0, n0, tid, stage); break;
+        CB_FE_CASE(1) CB_FE_CASE(2) CB_FE_CASE(3) CB_FE_CASE(4) CB_FE_CASE(5) CB_FE_CASE(6) CB_FE_CASE(7) CB_FE_CASE(8) CB_FE_CASE(9) CB_FE_CASE(10)
+        CB_FE_CASE(11)
+#undef CB_FE_CASE
+        default: break;
+    }
+}
+static_assert(FAST_EPI_N == 12, "fast_epilogue_dispatch lists every combination");
+
+// ---------------------------------------------------------------------------------------------
 // Epilogue-operand prefetch (row-contiguous bf16 epilogue only).  The epilogue's global READS -- the residual and the ReLU mask
 // / GELU pre-activation -- do not depend on the product, so the thread's chunks are requested before the K loop and land while it
 // runs: for the short-K 1x1 convolutions of the ResNet (1-4 K tiles, HBM-bound) the block otherwise waits a full HBM round trip
@@ -1102,6 +1269,22 @@ __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 
     const int wm = wave >> 1, wn = wave & 1;
     if (p.dropout_p > 0.f && p.seed_ptr) p.seed += *p.seed_ptr;
     const bool fast = p.c_vec && (n0 + BN <= p.N);      // block-uniform
+    if constexpr (sizeof(T) == 2) {
+        if (p.c_vec8 && p.fast_epi != 0 && !use_pre) {        // specialised body for this call's option combination (block-uniform)
+            static_assert((BM / 2) * (BN * 4 + 16) <= SMEM_BYTES, "staging does not fit");
+            auto stage = [&](int h) __attribute__((always_inline)) {
+                if (wm == h) {
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j)
+                            *reinterpret_cast<f32x4*>(smem + (i * 16 + (lane & 15)) * (BN * 4 + 16) + (wn * WN + j * 16 + 4 * (lane >> 4)) * 4) = acc[i][j];
+                }
+            };
+            fast_epilogue_dispatch<NTHREADS, BN, BM / 2, 2>(p, smem, m0, n0, tid, stage);
+            return;
+        }
+    }
     if (p.c_vec8) {
         // Row-contiguous epilogue: the fp32 accumulators go through LDS (free after the main loop), half the tile
         // rows at a time, so that each thread then owns 8 consecutive columns of one row: residual / mask reads and

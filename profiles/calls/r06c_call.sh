@@ -1,4 +1,4 @@
-# Round 6, call C: specialised 8-wave epilogues (FE_BIAS / FE_GELU2 packed fp32 / FE_MULAUX with hoisted aux loads) vs the generic epilogue8
+# Round 6, call C (run twice: first with the three 8-wave kinds, then -- this record -- with the flags-templated fast epilogue on every tile):
 # (CB_GEMM_FAST_EPI=0), alternating; kernel tests; per-shape in-step durations of both arms
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06c; mkdir -p $O; cd $R
 timeout 1500 python -m pytest tests/test_kernels_gemm8.py tests/test_kernels_gemm.py tests/test_bench_step.py tests/test_parity_record.py -m gpu -x -q 2>&1 | tail -4

@@ -200,7 +200,8 @@ __global__ void __launch_bounds__(NW * 64) layernorm_bwd_kernel(const T* dy, con
 // (independent shuffles interleave), stores, and keeps the column sums of its rows in registers -- the cross-wave reduction is NW-way
 // (4 instead of 16) behind ONE barrier pair per 1024 columns.  Same arithmetic per element and the same order of the column additions
 // inside a wave's rows; the partial-sum layout part[block][gamma | beta][D] and cb_ln_partials_reduce are unchanged.
-template <typename T, int MAXCH, int NW, int RPW>
+// FULL: D == MAXCH * 256 (the encoder's 768): no column guards anywhere -- every `e < D` test is an exec-mask branch per chunk otherwise.
+template <typename T, int MAXCH, int NW, int RPW, bool FULL>
 __global__ void __launch_bounds__(NW * 64) layernorm_bwd_rows_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
                                                                     const float* rstd, T* dx, float* dgamma, float* dbeta,
                                                                     int64_t rows, int D, T* dx2, float drop_p, uint64_t seed,
@@ -216,10 +217,11 @@ __global__ void __launch_bounds__(NW * 64) layernorm_bwd_rows_kernel(const T* dy
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
         ag[c] = z; ab[c] = z;
         const int e = (lane + 64 * c) * 4;
-        gm[c] = e < D ? load4(gamma + e) : z;
+        gm[c] = (FULL || e < D) ? load4(gamma + e) : z;
     }
     auto phys = [&](int64_t lrow) { return seg_len > 0 ? (lrow / seg_len) * seg_stride + seg_off + lrow % seg_len : lrow; };
     constexpr int RPB = NW * RPW;
+    const float inv_d = 1.0f / (float)D;
     for (int64_t base = (int64_t)blockIdx.x * RPB; base < rows; base += (int64_t)gridDim.x * RPB) {
         f32x4 g[RPW][MAXCH], xv[RPW][MAXCH];
         float mu[RPW], rs[RPW];
@@ -231,8 +233,8 @@ __global__ void __launch_bounds__(NW * 64) layernorm_bwd_rows_kernel(const T* dy
             ok[j] = lrow < rows;
             row[j] = ok[j] ? phys(lrow) : 0;
             if (ok[j]) {
-                load_row(dy + row[j] * D, D, lane, g[j]);
-                load_row(x + row[j] * D, D, lane, xv[j]);
+                load_row(dy + row[j] * D, FULL ? MAXCH * 256 : D, lane, g[j]);
+                load_row(x + row[j] * D, FULL ? MAXCH * 256 : D, lane, xv[j]);
                 mu[j] = mean[row[j]]; rs[j] = rstd[row[j]];
             } else {
 #pragma unroll
@@ -247,7 +249,7 @@ __global__ void __launch_bounds__(NW * 64) layernorm_bwd_rows_kernel(const T* dy
 #pragma unroll
             for (int c = 0; c < MAXCH; ++c) {
                 const int e = (lane + 64 * c) * 4;
-                if (e < D) {
+                if (FULL || e < D) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float xh = (xv[j][c][i] - mu[j]) * rs[j];
@@ -268,11 +270,11 @@ __global__ void __launch_bounds__(NW * 64) layernorm_bwd_rows_kernel(const T* dy
 #pragma unroll
         for (int j = 0; j < RPW; ++j) {
             if (!ok[j]) continue;
-            const float c1 = s1[j] / (float)D, c2 = s2[j] / (float)D;
+            const float c1 = s1[j] * inv_d, c2 = s2[j] * inv_d;
 #pragma unroll
             for (int c = 0; c < MAXCH; ++c) {
                 const int e = (lane + 64 * c) * 4;
-                if (e < D) {
+                if (FULL || e < D) {
                     f32x4 o;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o[i] = rs[j] * (g[j][c][i] - c1 - xv[j][c][i] * c2);
@@ -534,12 +536,19 @@ void run_ln_bwd(hipStream_t st, const void* dy, const void* x, const float* gamm
             if (blocks > cap) blocks = cap;
             if (part) blocks = (unsigned)part_blocks;
 #define CB_LN_ROWS(NW_, RPW_)                                                                                                              \
-            hipLaunchKernelGGL((layernorm_bwd_rows_kernel<T, NCH, NW_, RPW_>), dim3(blocks), dim3(NW_ * 64), 0, st, (const T*)dy, (const T*)x, gamma, \
-                               mean, rstd, (T*)dx, dgamma, dbeta, rows, D, (T*)dx2, p, seed, seed_ptr, seg_len, seg_stride, seg_off, part)
-            if (nw == 4 && rpw == 4) { CB_LN_ROWS(4, 4); return; }
+            do {                                                                                                                           \
+                if (D == NCH * 256)                                                                                                        \
+                    hipLaunchKernelGGL((layernorm_bwd_rows_kernel<T, NCH, NW_, RPW_, true>), dim3(blocks), dim3(NW_ * 64), 0, st, (const T*)dy, (const T*)x, gamma, \
+                                       mean, rstd, (T*)dx, dgamma, dbeta, rows, D, (T*)dx2, p, seed, seed_ptr, seg_len, seg_stride, seg_off, part); \
+                else                                                                                                                       \
+                    hipLaunchKernelGGL((layernorm_bwd_rows_kernel<T, NCH, NW_, RPW_, false>), dim3(blocks), dim3(NW_ * 64), 0, st, (const T*)dy, (const T*)x, gamma, \
+                                       mean, rstd, (T*)dx, dgamma, dbeta, rows, D, (T*)dx2, p, seed, seed_ptr, seg_len, seg_stride, seg_off, part); \
+            } while (0)
             if (nw == 8 && rpw == 2) { CB_LN_ROWS(8, 2); return; }
-            if (nw == 4 && rpw == 2) { CB_LN_ROWS(4, 2); return; }
             if (nw == 8 && rpw == 1) { CB_LN_ROWS(8, 1); return; }
+            if (nw == 12 && rpw == 1) { CB_LN_ROWS(12, 1); return; }
+            if (nw == 16 && rpw == 1) { CB_LN_ROWS(16, 1); return; }
+            if (nw == 4 && rpw == 1) { CB_LN_ROWS(4, 1); return; }
 #undef CB_LN_ROWS
         }
     }

@@ -11,16 +11,16 @@ dev = torch.device("cuda", 0)
 D = 768
 g = (1 + 0.1 * torch.randn(D, device=dev))
 res = {}
-for rows in (2624, 2720 * 2, 1312):
+for rows in (2624,):
     sets = []
     for i in range(24):
         x = torch.randn(rows, D, device=dev).bfloat16(); dy = torch.randn(rows, D, device=dev).bfloat16()
         mean = x.float().mean(-1); rstd = (x.float().var(-1, unbiased=False) + 1e-12).rsqrt()
         sets.append((x, dy, mean, rstd, torch.empty_like(x), torch.empty_like(x)))
     ref = None
-    for geom in (0, 44, 82, 42, 81):
+    for geom in (0, 82, 81, 121, 161, 41):
         os.environ["CB_LN_BWD_GEOM"] = str(geom)
-        for nb in (ops.ln_part_blocks(rows), 256, 128, 328, 512):
+        for nb in (ops.ln_part_blocks(rows), 219, 256, 328, 512, 656):
             part = torch.empty(24, nb, 2, D, device=dev)
 
             def run():

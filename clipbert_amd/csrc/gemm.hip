@@ -309,11 +309,17 @@ int gemm_prepare(const cb_gemm_desc* d, Prepared& out) {
         static const bool fe_off = getenv("CB_GEMM_FAST_EPI") != nullptr && atoi(getenv("CB_GEMM_FAST_EPI")) == 0;
         p.fast_epi = 0;
         auto rows_ok = [&](const void* q, int64_t ld) { return q == nullptr || (ld % 8 == 0 && aligned16(q) && (int64_t)d->M * ld * 2 < 0x7fffffffll); };
-        const bool plain = !fe_off && p.wt == 1 && p.batch == 1 && !d->accumulate && p.alpha == 1.f && !d->zero_fill_pitch && !d->relu_bwd && !d->a_rowsum &&
+        const bool plain = !fe_off && p.wt == 1 && p.batch == 1 && !d->accumulate && p.alpha == 1.f && !d->zero_fill_pitch && !d->a_rowsum &&
                            d->N % 8 == 0 && d->ldc % 8 == 0 && aligned16(d->C) && (!d->shift || aligned16(d->shift)) && (!d->scale || aligned16(d->scale)) &&
                            rows_ok(d->residual, d->ldr) && rows_ok(d->mask, d->ldm) && rows_ok(d->gelu_grad_pre, d->ld_gelu) &&
                            !(d->mask && d->gelu_grad_pre);
-        if (plain) {
+        if (plain && d->relu_bwd) {                                          // (validated above: mask, no scale / shift / act / dropout / relu_after)
+            const bool ok = d->C2 && d->post_scale && d->ldc2 % 8 == 0 && aligned16(d->C2) && (int64_t)d->M * d->ldc2 * 2 < 0xffffffffll;
+            const int flags = EF_RBWD | (d->residual ? EF_RES : 0) | (d->post_scale2 ? EF_PS2 : 0);
+            if (ok)
+                for (int i = 1; i < FAST_EPI_N; ++i)
+                    if (FAST_EPI_COMBOS[i] == flags) { p.fast_epi = i; break; }
+        } else if (plain) {
             int flags = 0;
             bool ok = true;
             if (d->scale) flags |= EF_SCALE;
@@ -419,7 +425,11 @@ int gemm_run(const cb_gemm_desc* d, void* stream, int32_t* plan, bool use_table)
         static const int min_rows = getenv("CB_GEMM_STREAM_MIN_ROWS") ? atoi(getenv("CB_GEMM_STREAM_MIN_ROWS")) : 32768;
         const int sv = stream_variant(d, p, fast, cv8);
         CB_REQUIRE(tile != 8 || sv >= 0, "cb_gemm: tile 8 (streaming) does not cover this problem (M=%d N=%d K=%d modes %d/%d)", d->M, d->N, d->K, d->a_mode, d->b_mode);
-        if (tile == 8 || (tile == 0 && use_table && !no_stream && sv >= 0 && d->M >= min_rows && d->N <= 512)) {
+        // (shapes of the measured table follow the table: since the specialised epilogues of round 6 the 128x128 two-per-CU tile beats the
+        // streaming kernel on the res3 conv3 shape in the step, profiles/r06d_instep_tuning.json -- tile 8 is not a table entry)
+        const bool tabled = d->dtype == CB_BF16 && getenv("CB_GEMM_NO_TUNED") == nullptr &&
+                            cbgemm::tuned_lookup(d->a_mode, d->b_mode, d->M, d->N, d->K, p.batch, p.R * p.S, p.split_k) != nullptr;
+        if (tile == 8 || (tile == 0 && use_table && !no_stream && !tabled && sv >= 0 && d->M >= min_rows && d->N <= 512)) {
             p.c_vec8 = 1;
             p.xcd_remap = 0;
             if (plan) { plan[0] = 8; plan[1] = 1; plan[2] = sv; plan[3] = 2; return 0; }

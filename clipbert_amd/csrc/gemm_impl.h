@@ -55,7 +55,9 @@ struct GP {
 // body (fast_epilogue<FLAGS> below: `if constexpr` per option, packed fp32 math, 32-bit buffer offsets, write-through stores) whose
 // operand loads leave BEFORE the staging barriers.  The host (gemm_prepare) maps a call's options to the index of its combination
 // (GP::fast_epi, 0 = none: generic path); bf16 row-contiguous epilogues only, alpha 1, no row map / zero fill / accumulate / relu_bwd.
-enum { EF_SCALE = 1, EF_SHIFT = 2, EF_RELU = 4, EF_GELU2 = 8, EF_DROP = 16, EF_RES = 32, EF_RELU_AFTER = 64, EF_MASK = 128, EF_MULAUX = 256 };
+enum { EF_SCALE = 1, EF_SHIFT = 2, EF_RELU = 4, EF_GELU2 = 8, EF_DROP = 16, EF_RES = 32, EF_RELU_AFTER = 64, EF_MASK = 128, EF_MULAUX = 256,
+       EF_RBWD = 512,      // cb_gemm_desc.relu_bwd: t = (acc [+ residual]) where mask > 0; C2 = t [* post_scale2]; C = t * post_scale
+       EF_PS2 = 1024 };
 constexpr int FAST_EPI_COMBOS[] = {
     -1,                                                  // 0: generic
     0,                                                   // 1: C = acc                                  (data gradients without epilogue, grid conv)
@@ -69,6 +71,10 @@ constexpr int FAST_EPI_COMBOS[] = {
     EF_SCALE | EF_SHIFT,                                 // 9: FrozenBN                                 (projection shortcut)
     EF_SCALE | EF_SHIFT | EF_RES | EF_RELU_AFTER,        // 10: FrozenBN + shortcut + ReLU              (bottleneck conv3)
     EF_SCALE | EF_MASK,                                  // 11: x FrozenBN scale where the producer's ReLU was open (data gradients inside a block)
+    EF_RBWD,                                             // 12-15: the ReLU x FrozenBN backward of the block that consumes the result, fused
+    EF_RBWD | EF_RES,                                    //        (identity shortcut: + its gradient)
+    EF_RBWD | EF_PS2,                                    //        (projection shortcut: second output x its FrozenBN scale)
+    EF_RBWD | EF_PS2 | EF_RES,
 };
 constexpr int FAST_EPI_N = sizeof(FAST_EPI_COMBOS) / sizeof(int);
 
@@ -1086,23 +1092,26 @@ __device__ __forceinline__ void unpack_bf16x8(u32x4 raw, f32x2 (&v)[4]) {
     for (int r = 0; r < 4; ++r) v[r] = f32x2{(float)u.x[2 * r], (float)u.x[2 * r + 1]};
 }
 
+// pre_r / pre_a: the residual / (mask | stored derivative) chunks already in registers (epi_prefetch: requested before the K loop), in
+// the slot order h * ITER + it; null: requested here.
 template <int FLAGS, int NT, int BN, int PR, int NPASS, typename StageFn>
-__device__ __forceinline__ void fast_epilogue(const GP& p, unsigned char* smem, int m0, int n0, int tid, StageFn stage) {
+__device__ __forceinline__ void fast_epilogue(const GP& p, unsigned char* smem, int m0, int n0, int tid, StageFn stage, const bf16x8* pre_r = nullptr,
+                                              const bf16x8* pre_a = nullptr) {
     constexpr int SROW = BN * 4 + 16, CPR = BN / 8, ITER = PR * CPR / NT, RSTEP = NT / CPR, NCH = NPASS * ITER;
     static_assert(PR * CPR % NT == 0 && NT % CPR == 0, "chunk map");
-    constexpr bool HAS_RES = (FLAGS & EF_RES) != 0, HAS_AUX = (FLAGS & (EF_MASK | EF_MULAUX)) != 0;
+    constexpr bool HAS_RES = (FLAGS & EF_RES) != 0, HAS_AUX = (FLAGS & (EF_MASK | EF_MULAUX | EF_RBWD)) != 0;
     constexpr bool ALL = NCH <= 8;                               // every chunk's operands in flight at once, else pass by pass
     constexpr bool ROLL = (FLAGS & EF_GELU2) != 0 || NPASS > 2;
     const int cc = tid % CPR, n = n0 + cc * 8, rl0 = tid / CPR;
     const bool nok = n < p.N;
     const unsigned char* const read_base = smem + rl0 * SROW + cc * 32;
     const rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, (short)0, (int)0xffffffffu, 0x00020000);
-    const rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc((FLAGS & EF_GELU2) ? p.C2 : p.C, (short)0, (int)0xffffffffu, 0x00020000);
+    const rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc((FLAGS & (EF_GELU2 | EF_RBWD)) ? p.C2 : p.C, (short)0, (int)0xffffffffu, 0x00020000);
     const uint32_t ldcb = (uint32_t)p.ldc * 2u, ldc2b = (uint32_t)p.ldc2 * 2u, nb = (uint32_t)n * 2u;
     // operands are read through range-checked descriptors: rows past M (and chunks past N) take the out-of-range offset and read zeros
     const rsrc_t rr = make_rsrc(HAS_RES ? p.residual : p.C, HAS_RES ? (uint32_t)((int64_t)p.M * p.ldr * 2) : 0u);
-    const void* auxp = (FLAGS & EF_MASK) ? p.mask : p.dact_pre;
-    const int64_t lda = (FLAGS & EF_MASK) ? p.ldm : p.ldd;
+    const void* auxp = (FLAGS & (EF_MASK | EF_RBWD)) ? p.mask : p.dact_pre;
+    const int64_t lda = (FLAGS & (EF_MASK | EF_RBWD)) ? p.ldm : p.ldd;
     const rsrc_t ra = make_rsrc(HAS_AUX ? auxp : p.C, HAS_AUX ? (uint32_t)((int64_t)p.M * lda * 2) : 0u);
     const uint32_t ldrb = (uint32_t)p.ldr * 2u, ldab = (uint32_t)lda * 2u;
     f32x2 sc[4], sh[4];
@@ -1117,6 +1126,14 @@ __device__ __forceinline__ void fast_epilogue(const GP& p, unsigned char* smem, 
             const f32x4 a = load4(p.shift + n), b = load4(p.shift + n + 4);
             sh[0] = f32x2{a[0], a[1]}; sh[1] = f32x2{a[2], a[3]}; sh[2] = f32x2{b[0], b[1]}; sh[3] = f32x2{b[2], b[3]};
         }
+        if constexpr ((FLAGS & EF_RBWD) != 0) {                  // (sc / sh hold post_scale / post_scale2)
+            const f32x4 a = load4(p.post_scale + n), b = load4(p.post_scale + n + 4);
+            sc[0] = f32x2{a[0], a[1]}; sc[1] = f32x2{a[2], a[3]}; sc[2] = f32x2{b[0], b[1]}; sc[3] = f32x2{b[2], b[3]};
+            if constexpr ((FLAGS & EF_PS2) != 0) {
+                const f32x4 c = load4(p.post_scale2 + n), e = load4(p.post_scale2 + n + 4);
+                sh[0] = f32x2{c[0], c[1]}; sh[1] = f32x2{c[2], c[3]}; sh[2] = f32x2{e[0], e[1]}; sh[3] = f32x2{e[2], e[3]};
+            }
+        }
     }
     u32x4 res[HAS_RES ? (ALL ? NCH : ITER) : 1], aux[HAS_AUX ? (ALL ? NCH : ITER) : 1];
     auto request = [&](int h) __attribute__((always_inline)) {
@@ -1124,8 +1141,15 @@ __device__ __forceinline__ void fast_epilogue(const GP& p, unsigned char* smem, 
         for (int it = 0; it < ITER; ++it) {
             const int m = m0 + h * PR + rl0 + it * RSTEP;
             const bool ok = m < p.M && nok;
-            if constexpr (HAS_RES) res[(ALL ? h * ITER : 0) + it] = bload16(rr, ok ? (uint32_t)m * ldrb + nb : OOB);
-            if constexpr (HAS_AUX) aux[(ALL ? h * ITER : 0) + it] = bload16(ra, ok ? (uint32_t)m * ldab + nb : OOB);
+            const int slot = (ALL ? h * ITER : 0) + it;
+            if constexpr (HAS_RES) {
+                if (ALL && pre_r) { union { bf16x8 x; u32x4 r; } u; u.x = pre_r[h * ITER + it]; res[slot] = u.r; }
+                else res[slot] = bload16(rr, ok ? (uint32_t)m * ldrb + nb : OOB);
+            }
+            if constexpr (HAS_AUX) {
+                if (ALL && pre_a) { union { bf16x8 x; u32x4 r; } u; u.x = pre_a[h * ITER + it]; aux[slot] = u.r; }
+                else aux[slot] = bload16(ra, ok ? (uint32_t)m * ldab + nb : OOB);
+            }
         }
     };
     auto chunk = [&](int h, int it, int slot) __attribute__((always_inline)) {
@@ -1134,6 +1158,25 @@ __device__ __forceinline__ void fast_epilogue(const GP& p, unsigned char* smem, 
         const f32x4 a = *reinterpret_cast<const f32x4*>(read_base + it * RSTEP * SROW);
         const f32x4 b = *reinterpret_cast<const f32x4*>(read_base + it * RSTEP * SROW + 16);
         f32x2 v[4] = {f32x2{a[0], a[1]}, f32x2{a[2], a[3]}, f32x2{b[0], b[1]}, f32x2{b[2], b[3]}};
+        if constexpr ((FLAGS & EF_RBWD) != 0) {
+            f32x2 t[4];
+            if constexpr (HAS_RES) {
+                unpack_bf16x8(res[slot], t);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] + t[r];
+            }
+            unpack_bf16x8(aux[slot], t);
+            f32x2 u[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = f32x2{t[r][0] > 0.f ? v[r][0] : 0.f, t[r][1] > 0.f ? v[r][1] : 0.f};
+                u[r] = (FLAGS & EF_PS2) != 0 ? v[r] * sh[r] : v[r];
+                v[r] = v[r] * sc[r];
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(u), rc2, (uint32_t)m * ldc2b + nb, 0, 16 /* sc1 */);
+            __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v), rc, (uint32_t)m * ldcb + nb, 0, 16 /* sc1 */);
+            return;
+        }
         {   // scale, then shift, as TWO roundings -- what the generic epilogue8 does behind its runtime branches; the streaming kernel and the
             // K-split reduce run that one and must stay bit-identical to this path (tests/test_gemm_stream.py)
 #pragma clang fp contract(off)
@@ -1208,16 +1251,17 @@ __device__ __forceinline__ void fast_epilogue(const GP& p, unsigned char* smem, 
 
 // runtime index -> compile-time combination (a wave-uniform switch: the kernel argument lives in SGPRs)
 template <int NT, int BN, int PR, int NPASS, typename StageFn>
-__device__ __forceinline__ void fast_epilogue_dispatch(const GP& p, unsigned char* smem, int m0, int n0, int tid, StageFn stage) {
+__device__ __forceinline__ void fast_epilogue_dispatch(const GP& p, unsigned char* smem, int m0, int n0, int tid, StageFn stage,
+                                                       const bf16x8* pre_r = nullptr, const bf16x8* pre_a = nullptr) {
     switch (p.fast_epi) {
-#define CB_FE_CASE(I) case I: fast_epilogue<FAST_EPI_COMBOS[I], NT, BN, PR, NPASS>(p, smem, m0, n0, tid, stage); break;
+#define CB_FE_CASE(I) case I: fast_epilogue<FAST_EPI_COMBOS[I], NT, BN, PR, NPASS>(p, smem, m0, n0, tid, stage, pre_r, pre_a); break;
         CB_FE_CASE(1) CB_FE_CASE(2) CB_FE_CASE(3) CB_FE_CASE(4) CB_FE_CASE(5) CB_FE_CASE(6) CB_FE_CASE(7) CB_FE_CASE(8) CB_FE_CASE(9) CB_FE_CASE(10)
-        CB_FE_CASE(11)
+        CB_FE_CASE(11) CB_FE_CASE(12) CB_FE_CASE(13) CB_FE_CASE(14) CB_FE_CASE(15)
 #undef CB_FE_CASE
         default: break;
     }
 }
-static_assert(FAST_EPI_N == 12, "fast_epilogue_dispatch lists every combination");
+static_assert(FAST_EPI_N == 16, "fast_epilogue_dispatch lists every combination");
 
 // ---------------------------------------------------------------------------------------------
 // Epilogue-operand prefetch (row-contiguous bf16 epilogue only).  The epilogue's global READS -- the residual and the ReLU mask
@@ -1261,7 +1305,7 @@ __device__ __forceinline__ void epi_prefetch(const GP& p, EpiPre<BM, BN, WITH_R>
 // ---------------------------------------------------------------------------------------------
 // Tile epilogue shared by both kernel structures.  acc[i][j] = 4 consecutive n of row m (swapped MFMA operands).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int SMEM_BYTES, int EPF = 0>
+template <typename T, int BM, int BN, int SMEM_BYTES, int EPF = 0, bool FAST = true>
 __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 32], unsigned char* smem, int m0, int n0, int tid,
                                               const EpiPre<BM, BN, EPF != 1>& pre = EpiPre<BM, BN, EPF != 1>{}, bool use_pre = false) {
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
@@ -1269,8 +1313,8 @@ __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 
     const int wm = wave >> 1, wn = wave & 1;
     if (p.dropout_p > 0.f && p.seed_ptr) p.seed += *p.seed_ptr;
     const bool fast = p.c_vec && (n0 + BN <= p.N);      // block-uniform
-    if constexpr (sizeof(T) == 2) {
-        if (p.c_vec8 && p.fast_epi != 0 && !use_pre) {        // specialised body for this call's option combination (block-uniform)
+    if constexpr (sizeof(T) == 2 && FAST) {                   // (FAST off: weight-gradient forms -- fp32 output, never a listed combination)
+        if (p.c_vec8 && p.fast_epi != 0) {                    // specialised body for this call's option combination (block-uniform)
             static_assert((BM / 2) * (BN * 4 + 16) <= SMEM_BYTES, "staging does not fit");
             auto stage = [&](int h) __attribute__((always_inline)) {
                 if (wm == h) {
@@ -1281,7 +1325,11 @@ __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 
                             *reinterpret_cast<f32x4*>(smem + (i * 16 + (lane & 15)) * (BN * 4 + 16) + (wn * WN + j * 16 + 4 * (lane >> 4)) * 4) = acc[i][j];
                 }
             };
-            fast_epilogue_dispatch<NTHREADS, BN, BM / 2, 2>(p, smem, m0, n0, tid, stage);
+            const bf16x8* pre_r = nullptr;
+            const bf16x8* pre_a = nullptr;
+            if constexpr (EPF == 2) { if (use_pre) pre_r = pre.r; }
+            if constexpr (EPF != 0) { if (use_pre) pre_a = pre.a; }
+            fast_epilogue_dispatch<NTHREADS, BN, BM / 2, 2>(p, smem, m0, n0, tid, stage, pre_r, pre_a);
             return;
         }
     }
@@ -1670,7 +1718,7 @@ __device__ __forceinline__ void gemm_tile(GP& p, TileId bid, int kt0_in = 0, int
         }
     }
     if constexpr (EPF != 0) tile_epilogue<T, BM, BN, SMEM_BYTES, EPF>(p, acc, smem, m0, n0, tid, epre, epf_on);
-    else tile_epilogue<T, BM, BN, SMEM_BYTES>(p, acc, smem, m0, n0, tid);
+    else tile_epilogue<T, BM, BN, SMEM_BYTES, 0, !LA::KROW>(p, acc, smem, m0, n0, tid);
     CB_STAMP(3);
     CB_STAMP_FLUSH(p, stamp_lin, tid);
 }

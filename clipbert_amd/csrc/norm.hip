@@ -73,11 +73,9 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const T* x, const fl
     }
 }
 
-// Each wave walks rows with stride gridDim*NW; dgamma/dbeta partials stay in registers, are combined across the block's
-// NW waves through LDS and flushed with one atomic per element per block.  NW = 16 (1024 threads) for the encoder's
-// token counts: the 2*D atomics per block bound the number of blocks (~128), so rows in flight come from waves per block --
-// with 4 waves a 2624-row problem made every wave walk 5 rows one after the other (two dependent reductions and a
-// load round trip each); with 16 it is 1-2, and the next row's loads are issued before the current row's reductions.
+// Each wave walks rows with stride gridDim*NW (next row prefetched); dgamma/dbeta partials stay in registers, are combined across the
+// block's NW waves through LDS and flushed with one atomic (or one partial-sum store) per element per block.  Since round 6 only rows
+// wider than 1024 elements (8 chunks: too many registers for the rows-in-flight kernel below) run it, with NW = 4.
 template <typename T, int MAXCH, int NW>
 __global__ void __launch_bounds__(NW * 64) layernorm_bwd_kernel(const T* dy, const T* x, const float* gamma, const float* mean,
                                                                const float* rstd, T* dx, float* dgamma, float* dbeta,
@@ -526,41 +524,20 @@ void run_ln_bwd(hipStream_t st, const void* dy, const void* x, const float* gamm
                 int seg_len, int seg_stride, int seg_off, float* part, int part_blocks) {
     // grid cap: every block ends with 2*D atomics, but a block per CU (one row per wave at the encoder's 2624 rows) measured faster
     // next to other kernels than 128 blocks with two rows per wave (tools/small_kernel_probe.py: 13.3 vs 16.5 us)
-    static const unsigned cap = getenv("CB_LN_BWD_BLOCKS") ? (unsigned)atoi(getenv("CB_LN_BWD_BLOCKS")) : 256u;
-    // CB_LN_BWD_GEOM=NW*10+RPW (44 / 82 / 42 / 81): the rows-in-flight kernel above with that block shape (round-6 A/B; 0: the kernel below)
-    const int geom = getenv("CB_LN_BWD_GEOM") ? atoi(getenv("CB_LN_BWD_GEOM")) : 0;      // (read per call: the probe switches it)
+    constexpr unsigned cap = 256;
     if constexpr (NCH <= 4) {
-        if (geom != 0) {
-            const int nw = geom / 10, rpw = geom % 10;
-            unsigned blocks = nblk(rows, nw * rpw);
-            if (blocks > cap) blocks = cap;
-            if (part) blocks = (unsigned)part_blocks;
-#define CB_LN_ROWS(NW_, RPW_)                                                                                                              \
-            do {                                                                                                                           \
-                if (D == NCH * 256)                                                                                                        \
-                    hipLaunchKernelGGL((layernorm_bwd_rows_kernel<T, NCH, NW_, RPW_, true>), dim3(blocks), dim3(NW_ * 64), 0, st, (const T*)dy, (const T*)x, gamma, \
-                                       mean, rstd, (T*)dx, dgamma, dbeta, rows, D, (T*)dx2, p, seed, seed_ptr, seg_len, seg_stride, seg_off, part); \
-                else                                                                                                                       \
-                    hipLaunchKernelGGL((layernorm_bwd_rows_kernel<T, NCH, NW_, RPW_, false>), dim3(blocks), dim3(NW_ * 64), 0, st, (const T*)dy, (const T*)x, gamma, \
-                                       mean, rstd, (T*)dx, dgamma, dbeta, rows, D, (T*)dx2, p, seed, seed_ptr, seg_len, seg_stride, seg_off, part); \
-            } while (0)
-            if (nw == 8 && rpw == 2) { CB_LN_ROWS(8, 2); return; }
-            if (nw == 8 && rpw == 1) { CB_LN_ROWS(8, 1); return; }
-            if (nw == 12 && rpw == 1) { CB_LN_ROWS(12, 1); return; }
-            if (nw == 16 && rpw == 1) { CB_LN_ROWS(16, 1); return; }
-            if (nw == 4 && rpw == 1) { CB_LN_ROWS(4, 1); return; }
-#undef CB_LN_ROWS
-        }
-    }
-    if constexpr (NCH <= 4) {
-        if (rows >= 1024) {                  // many rows: 16 waves per block (see the kernel comment)
-            unsigned blocks = nblk(rows, 16);
-            if (blocks > cap) blocks = cap;
-            if (part) blocks = (unsigned)part_blocks;
-            hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH, 16>), dim3(blocks), dim3(1024), 0, st, (const T*)dy, (const T*)x, gamma, mean,
-                               rstd, (T*)dx, dgamma, dbeta, rows, D, (T*)dx2, p, seed, seed_ptr, seg_len, seg_stride, seg_off, part);
-            return;
-        }
+        // rows-in-flight kernel, 12 waves x 1 row per block: measured best at the encoder's 2624 rows (219 blocks: 7.6 us against 12.8 us for
+        // the 16-wave one-row-per-wave kernel it replaces, profiles/r06d_ln_bwd_probe.txt; 8 x 2: 8.3, 16 x 1: 7.8, 4 x 1 on 656 blocks: 8.8)
+        unsigned blocks = nblk(rows, 12);
+        if (blocks > cap) blocks = cap;
+        if (part) blocks = (unsigned)part_blocks;
+        if (D == NCH * 256)
+            hipLaunchKernelGGL((layernorm_bwd_rows_kernel<T, NCH, 12, 1, true>), dim3(blocks), dim3(12 * 64), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd,
+                               (T*)dx, dgamma, dbeta, rows, D, (T*)dx2, p, seed, seed_ptr, seg_len, seg_stride, seg_off, part);
+        else
+            hipLaunchKernelGGL((layernorm_bwd_rows_kernel<T, NCH, 12, 1, false>), dim3(blocks), dim3(12 * 64), 0, st, (const T*)dy, (const T*)x, gamma, mean, rstd,
+                               (T*)dx, dgamma, dbeta, rows, D, (T*)dx2, p, seed, seed_ptr, seg_len, seg_stride, seg_off, part);
+        return;
     }
     unsigned blocks = nblk(rows, 4);
     if (blocks > cap) blocks = cap;          // every block ends with 2*D atomics: keep them few

@@ -294,9 +294,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dropout_p=0.0, dropou
 
 
 def ln_part_blocks(rows: int) -> int:
-    """blocks cb_layernorm_bwd_part is launched with for `rows` rows (one row per wave, 16 / 4 waves per block, <= 256 blocks)"""
-    per = 16 if rows >= 1024 else 4
-    return max(1, min(256, (rows + per - 1) // per))
+    """blocks cb_layernorm_bwd_part is launched with for `rows` rows (one row per wave, 12 waves per block, <= 256 blocks)"""
+    return max(1, min(256, (rows + 11) // 12))
 
 
 def layernorm_bwd_part(dy, x, gamma, mean, rstd, part, dropout_p=0.0, dropout_seed=0, seed_ptr=None, dx=None, dx2=None):

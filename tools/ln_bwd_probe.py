@@ -11,16 +11,16 @@ dev = torch.device("cuda", 0)
 D = 768
 g = (1 + 0.1 * torch.randn(D, device=dev))
 res = {}
-for rows in (2624,):
+for rows in (2624, 5440, 1312):
     sets = []
     for i in range(24):
         x = torch.randn(rows, D, device=dev).bfloat16(); dy = torch.randn(rows, D, device=dev).bfloat16()
         mean = x.float().mean(-1); rstd = (x.float().var(-1, unbiased=False) + 1e-12).rsqrt()
         sets.append((x, dy, mean, rstd, torch.empty_like(x), torch.empty_like(x)))
     ref = None
-    for geom in (0, 82, 81, 121, 161, 41):
+    for geom in (0,):
         os.environ["CB_LN_BWD_GEOM"] = str(geom)
-        for nb in (ops.ln_part_blocks(rows), 219, 256, 328, 512, 656):
+        for nb in (ops.ln_part_blocks(rows),):
             part = torch.empty(24, nb, 2, D, device=dev)
 
             def run():
@@ -30,7 +30,8 @@ for rows in (2624,):
             got = (sets[3][4].clone(), sets[3][5].clone(), part[3].sum(0))
             if ref is None:
                 ref = got
-            ok = torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.allclose(got[2], ref[2], rtol=1e-4, atol=1e-3)
+            err = max(float((got[0].float() - ref[0].float()).abs().max()), float((got[1].float() - ref[1].float()).abs().max()))
+            ok = err <= 2e-2 and torch.allclose(got[2], ref[2], rtol=1e-4, atol=1e-3)       # (bf16 dx: the reciprocal of D instead of a division moves a few last bits)
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
                 run()

@@ -87,9 +87,8 @@ def log(msg):
         print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-# ---- launching N > 1: tools/bench_launch.py (supervisor, fallback ladder, stub workers of the CPU tests) ---------------------------------
-sys.path.insert(0, os.path.join(ROOT, "tools"))
-from bench_launch import ATTEMPTS, ATTEMPT_TIMEOUT_S, _marker, _run_attempts, _stub_worker, _touch, supervise  # noqa: E402,F401
+# ---- launching N > 1: clipbert_amd/bench/launch.py (supervisor, fallback ladder, stub workers of the CPU tests) ---------------------------------
+from clipbert_amd.bench.launch import ATTEMPTS, ATTEMPT_TIMEOUT_S, _marker, _run_attempts, _stub_worker, _touch, supervise  # noqa: E402,F401
 
 
 def main():
@@ -182,10 +181,9 @@ def main():
                         shard=os.environ.get("CB_BENCH_SHARD") == "1")      # opt-in: reduce-scatter -> owner-only AdamW -> all-gather
         sync.broadcast_parameters(0)
         opt = FusedAdamW(bank, lr=5e-5, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0)
-    # ---- the pieces of a step: tools/bench_step.make_step builds them (tests/test_bench_step.py checks exactly these closures: eager
+    # ---- the pieces of a step: clipbert_amd.bench.step.make_step builds them (tests/test_bench_step.py checks exactly these closures: eager
     # == captured replay, gradients against the oracle's autograd) ------------------------------------------------------------------
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import bench_step
+    from clipbert_amd.bench import step as bench_step
     if train:
         _fns = bench_step.make_step(model, batch, tcfg, opt, sync, labels, counts, nclip, T, args.pool, fold=fold)
         state, one = _fns.state, _fns.one
@@ -199,8 +197,8 @@ def main():
             return tasks.training_loss(model, stack, labels, counts, args.pool)                  # clip pooling (a20) + loss
         host_prepare = device_step_single = None
 
-    # diagnostic step variants (CB_BENCH_PIPELINE / CB_BENCH_CHAINS): tools/bench_diag.py
-    import bench_diag
+    # diagnostic step variants (CB_BENCH_PIPELINE / CB_BENCH_CHAINS): clipbert_amd/bench/diag.py
+    from clipbert_amd.bench import diag as bench_diag
     _diag = bench_diag.build(SimpleNamespace(model=model, bank=bank, opt=opt, args=args, frames=frames, ids=ids, mask=mask, labels=labels, counts=counts,
                                              tcfg=tcfg, one=one, bv=bv, nclip=nclip, T=T, rep=rep, fold=fold, train=train, world=world))
     device_step_pipelined, device_step_chains, chains = _diag.device_step_pipelined, _diag.device_step_chains, _diag.chains

@@ -2,8 +2,16 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "clipbert_hip.h"
+
+// gfx950 only: the kernels rely on its MFMA shapes, LDS-DMA, transpose reads -- and on its memory behaviour (the slab K split publishes
+// partial tiles with sc1 write-through stores / sc1 loads around a relaxed ticket instead of release / acquire fences: measured safe on
+// MI355X under uneven load, tests/test_gemm_group.py stale-line test, tools/replay_determinism.py; NOT a HIP memory-model guarantee).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libclipbert_hip is written for gfx950 (MI355X) only"
+#endif
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -23,6 +31,12 @@ int cb_launch_status(const char* what);
     } while (0)
 
 static inline hipStream_t cb_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+// CB_PERSISTENT_MAXWG=n (tests only): the persistent kernels (cb_stem_pool, cb_res2_block, the streaming cb_gemm) launch at most n
+// workgroups, so that a few workgroups walk many tiles and the tile loops are exercised on small problems.  Read per call.
+static inline int cb_persistent_max_workgroups(int dflt) {
+    const char* cap = getenv("CB_PERSISTENT_MAXWG");
+    return cap && atoi(cap) > 0 ? atoi(cap) : dflt;
+}
 
 // ---- scalar conversions ----------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }

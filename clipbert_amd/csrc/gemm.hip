@@ -41,7 +41,6 @@ extern template int launch_gemm<bf16, 128, 128, 1, 2>(const GP&, bool, hipStream
 extern template int launch_gemm_group<float, 64, 64, 2, 1>(const GroupArgs&, int, hipStream_t);
 extern template int launch_gemm_group<bf16, 64, 64, 3, 1>(const GroupArgs&, int, hipStream_t);
 extern template int launch_gemm_group<bf16, 128, 128, 1, 2>(const GroupArgs&, int, hipStream_t);
-extern template int launch_gemm_streamk<128, 128, 1, 2>(const StreamKArgs&, int, unsigned, hipStream_t);
 // 8-wave LDS-DMA structure (gemm8_impl.h), instantiated in gemm8_inst_*.hip
 #define CB_G8_DECL(BM, BN, WGM, WGN, NST)                                                             \
     extern template int launch_gemm8_fwd<BM, BN, WGM, WGN, NST>(const GP&, int, float*, hipStream_t);   \
@@ -422,7 +421,7 @@ int gemm_run(const cb_gemm_desc* d, void* stream, int32_t* plan, bool use_table)
     // (measured on MI355X, profiles/r04c_stream_probe.json; CB_GEMM_NO_STREAM=1 restores the one-workgroup-per-tile kernels)
     {
         static const bool no_stream = getenv("CB_GEMM_NO_STREAM") != nullptr;
-        static const int min_rows = getenv("CB_GEMM_STREAM_MIN_ROWS") ? atoi(getenv("CB_GEMM_STREAM_MIN_ROWS")) : 32768;
+        constexpr int min_rows = 32768;
         const int sv = stream_variant(d, p, fast, cv8);
         CB_REQUIRE(tile != 8 || sv >= 0, "cb_gemm: tile 8 (streaming) does not cover this problem (M=%d N=%d K=%d modes %d/%d)", d->M, d->N, d->K, d->a_mode, d->b_mode);
         // (shapes of the measured table follow the table: since the specialised epilogues of round 6 the 128x128 two-per-CU tile beats the
@@ -442,8 +441,7 @@ int gemm_run(const cb_gemm_desc* d, void* stream, int32_t* plan, bool use_table)
     int split_tuned = 0, sched_tuned = 0;      // K split / K-loop schedule measured best for the table's tile (0: none recorded)
     if (d->dtype == CB_BF16 && !no_tuned && use_table && (tile == 0 || xcd == 0)) {
         if (const cbgemm::TunedEntry* e = cbgemm::tuned_lookup(d->a_mode, d->b_mode, d->M, d->N, d->K, p.batch, p.R * p.S, p.split_k)) {
-            static const bool no8w = getenv("CB_GEMM_NO8W") != nullptr;          // diagnostic: ignore the table's 8-wave entries
-            if (tile == 0 && !(no8w && e->tile >= 5)) { tile = e->tile; split_tuned = e->new_split; sched_tuned = e->sched; }
+            if (tile == 0) { tile = e->tile; split_tuned = e->new_split; sched_tuned = e->sched; }
             if (xcd == 0) xcd = e->xcd;
         }
     }
@@ -489,15 +487,10 @@ int gemm_run(const cb_gemm_desc* d, void* stream, int32_t* plan, bool use_table)
     if (trace) fprintf(stderr, "cb_gemm: M=%d N=%d K=%d modes=%d/%d tile=%d (asked %d) form8=%d split=%d ws=%d\n", d->M, d->N, d->K, d->a_mode, d->b_mode,
                        tile, d->tile, form8, tile >= 5 ? p.split_k : split_caller, ws8 != nullptr);
     if (tile >= 5) {
-        static const int mode8_env = getenv("CB_GEMM8_MODE") ? atoi(getenv("CB_GEMM8_MODE")) : 2;
-        CB_REQUIRE(d->schedule >= 0 && d->schedule <= 4, "cb_gemm: bad schedule %d", d->schedule);
-        const int mode8 = d->schedule > 0 ? d->schedule - 1 : (sched_tuned > 0 ? sched_tuned - 1 : mode8_env);
+        CB_REQUIRE(d->schedule >= 0 && d->schedule <= 3, "cb_gemm: bad schedule %d", d->schedule);
+        const int mode8 = d->schedule > 0 ? d->schedule - 1 : (sched_tuned > 0 ? sched_tuned - 1 : 2);
         p.c_vec8 = 1;
         p.xcd_remap = !no_remap && xcd != 2;
-        {   // round-5 experiment (tools/r05a_call.sh): CB_GEMM_RASTER_W=w -> column-panel tile order for the 8-wave kernels
-            static const int rw = getenv("CB_GEMM_RASTER_W") ? atoi(getenv("CB_GEMM_RASTER_W")) : 0;
-            p.raster_w = p.xcd_remap ? rw : 0;
-        }
         if (plan) { plan[0] = tile; plan[1] = p.split_k; plan[2] = mode8 + 1; plan[3] = p.xcd_remap ? 1 : 2; return 0; }
         hipStream_t st8 = cb_stream(stream);
         CB_STAMP_ASSIGN(p, d, tile, p.split_k, mode8 + 1, 0, 1);
@@ -531,8 +524,7 @@ int gemm_run(const cb_gemm_desc* d, void* stream, int32_t* plan, bool use_table)
         if (p.split_k > p.ktiles) p.split_k = p.ktiles;
     }
     cv8 = cv8 && p.split_k == 1;                                  // (atomics keep the 4-wide path)
-    static const bool no_wide = getenv("CB_GEMM_NO_WIDE_EPILOGUE") != nullptr;
-    p.c_vec8 = cv8 && (!no_wide || d->zero_fill_pitch > 0);
+    p.c_vec8 = cv8;
     if (d->zero_fill_pitch != 0)
         CB_REQUIRE(d->zero_fill_pitch > 0 && d->c_rowmap && p.c_vec8 && d->batch <= 1,
                    "cb_gemm: zero_fill_pitch needs c_rowmap and 16-byte-aligned 8-column chunks (N, ldc %% 8 == 0)");
@@ -616,67 +608,12 @@ double group_cost(const std::vector<GroupItem*>& g, int tile, int s, int* splits
     if (tile == 4) unit = per_cu <= 1 ? 1.0 : 0.77;
     else unit = per_cu <= 1 ? 0.45 : (per_cu == 2 ? 0.35 : 0.30);
     // workgroups beyond what a CU holds at once (2 / 4) queue behind the first round: their K loops do not overlap
-    static const double atom_scale = getenv("CB_GROUP_ATOM_SCALE") ? atof(getenv("CB_GROUP_ATOM_SCALE")) : 1.0;      // (diagnostic)
-    return 8.0 + (double)per_cu * kt_per_max * unit + atom_scale * atom / 2.0e6;
+    return 8.0 + (double)per_cu * kt_per_max * unit + atom / 2.0e6;
 }
 
 int launch_group_chunk(std::vector<GroupItem*>& g, int dtype, int cls, hipStream_t st) {
     static const bool no_remap = getenv("CB_GEMM_NO_XCD_REMAP") != nullptr;
-    static const bool no_wide = getenv("CB_GEMM_NO_WIDE_EPILOGUE") != nullptr;
     static const bool trace = getenv("CB_GEMM_TRACE") != nullptr;
-    // ---- stream-K (round 5, OPT-IN: CB_GEMM_STREAMK=1): the weight gradients of a stage whose K split is free (fp32 gradient accumulated
-    // in place through atomics) as ONE persistent launch of two workgroups per CU, every workgroup the same number of K tiles
-    // (gemm_streamk_kernel).  Correct (tests/test_gemm_group.py, emulator and MI355X) and MEASURED SLOWER than the split-K grouped launches
-    // it was meant to replace: +0.24 ms per step with a tile-major unit line (no L2 sharing of a K range between concurrent workgroups),
-    // +0.15 ... +0.25 ms with K chunks of 1 - 2 workgroup shares, +0.5 / +1.0 ms with shorter chunks (profiles/r05n_streamk_ab.txt).  Every
-    // cut a workgroup's share makes inside a (chunk, tile) piece is one more 64 KB burst of memory-side fp32 atomics (27-30 us of a
-    // workgroup's life, profiles/r05a_stamps_before.md), and the shares of a heterogeneous group never line up with the pieces: balance
-    // gained, atomics doubled.  Kept as a switch; the split-K grouped launch stays the default.
-    {
-        static const bool want_sk = getenv("CB_GEMM_STREAMK") != nullptr && atoi(getenv("CB_GEMM_STREAMK")) != 0;
-        bool ok = want_sk && dtype == CB_BF16 && (cls == GC_WGRAD || cls == GC_WGRAD_GATHER) && g[0]->d->tile == 0 && g.size() <= (size_t)STREAMK_MAX;
-        for (auto* it : g) ok = ok && split_is_free(it->d) && it->pr.p.c_vec && it->d->N > 64 && it->d->M > 64 && it->pr.p.batch == 1;
-        if (ok) {
-            StreamKArgs sa{};
-            sa.n = (int)g.size();
-            long long acc = 0;
-            int xcd = 0;
-            for (size_t i = 0; i < g.size(); ++i) {
-                const cb_gemm_desc* d = g[i]->d;
-                GP p = g[i]->pr.p;
-                p.c_vec8 = 0;
-                if (d->xcd_order != 0) xcd = d->xcd_order;
-                acc += (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * p.ktiles;
-                sa.unit_end[i] = (int)acc;
-                sa.g[i] = p;
-                if (trace) fprintf(stderr, "cb_gemm_group[%zu/%zu]: M=%d N=%d K=%d modes=%d/%d cls=%d stream-K units %lld\n", i, g.size(), d->M, d->N, d->K, d->a_mode,
-                                   d->b_mode, cls, acc);
-            }
-            CB_REQUIRE(acc < (1ll << 31), "cb_gemm_group: too many K-tile units");
-            sa.xcd_remap = !no_remap && xcd != 2;
-            static const unsigned cus_ = [] {
-                int dev = 0, n = 0;
-                return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? (unsigned)n : 256u;
-            }();
-            const char* cap = getenv("CB_GEMM_STREAMK_WG");             // (tests: few workgroups, many segments each)
-            unsigned wgs = cap && atoi(cap) > 0 ? (unsigned)atoi(cap) : 2u * cus_;
-            if ((long long)wgs * 4 > acc) wgs = (unsigned)((acc + 3) / 4);       // (at least ~4 K tiles per workgroup)
-            if (wgs < 1) wgs = 1;
-            // K chunks of about one workgroup's share: a workgroup's range is then (mostly) one chunk of a few neighbouring tiles
-            const long long share = (acc + wgs - 1) / wgs;
-            const char* kcs = getenv("CB_GEMM_STREAMK_CHUNK");          // diagnostic: chunk length in units of the share (default 1.0)
-            const double chunk_scale = kcs ? atof(kcs) : 1.0;
-            for (size_t i = 0; i < g.size(); ++i) {
-                const int kt = sa.g[i].ktiles;
-                long long kc = (long long)(share * chunk_scale + 0.5);
-                if (kc < 4) kc = 4;
-                int nchunks = (int)((kt + kc - 1) / kc);
-                if (nchunks < 1) nchunks = 1;
-                sa.kchunk[i] = (kt + nchunks - 1) / nchunks;             // equal chunks (the last one at most nchunks - 1 tiles shorter)
-            }
-            return launch_gemm_streamk<128, 128, 1, 2>(sa, cls, wgs, st);
-        }
-    }
     int splits[GROUP_MAX];
     int tile = 2;
     if (dtype == CB_F32) {
@@ -751,7 +688,7 @@ int launch_group_chunk(std::vector<GroupItem*>& g, int dtype, int cls, hipStream
             CB_REQUIRE(!d->C2 && !d->residual && !d->mask && !d->gelu_grad_pre && d->act == CB_ACT_NONE && !d->relu_after && !d->shift && d->dropout_p <= 0.f,
                        "cb_gemm_group: split_k > 1 supports only scale/alpha in the epilogue");
         }
-        p.c_vec8 = g[i]->pr.cv8 && (p.split_k == 1 || slab_ws) && !no_wide;
+        p.c_vec8 = g[i]->pr.cv8 && (p.split_k == 1 || slab_ws);
         if (slab_ws && p.split_k > 1) {
             const int tiles = ((d->M + B - 1) / B) * ((d->N + B - 1) / B);
             CB_REQUIRE(slab_units < (1ll << 31), "cb_gemm_group: slab index overflow");

@@ -15,7 +15,8 @@
 //   1  the K tile in P phases {ds_read fragments, [DMA slice], barrier, MFMA cluster (s_setprio 1), barrier}: lockstep;
 //   2  as 1 with the two wave groups (waves 0-3 / 4-7 = one wave of every SIMD each) offset by one barrier: while one group runs
 //      its MFMA cluster the other reads / issues DMA (the ping-pong of cdna_hip_programming.md section 5).
-//   (cb_gemm_desc.schedule 4: gemm8p_kernel below, a persistent walk over the tiles with schedule 0's K loop -- an experiment.)
+//   (A persistent variant -- one workgroup per CU walking the tiles, next tile's DMA issued before the epilogue -- was built in round 3,
+//   measured slower on every shape, profiles/r03r_persistent_probe.txt, and deleted in round 6.)
 // Hazards (MODE 1 / 2): a stage is re-filled >= 2 phases after its last ds_read (the groups are one barrier apart and a read is
 // only complete at its consumer's lgkmcnt wait); a tile is read one phase AFTER the counted vmcnt + barrier that retire it.
 #pragma once
@@ -194,19 +195,16 @@ template <int ROWS, int KMODE> struct KrowDma8 {
 // 8 consecutive columns of one row (16-byte, line-contiguous global accesses), then either the full cb_gemm epilogue (epilogue8)
 // or -- K-split partial products -- plain fp32 stores into this split's slab of the workspace.
 // ---------------------------------------------------------------------------------------------
-// RAW (the persistent kernel, round 4): the staging passes synchronise with s_waitcnt lgkmcnt(0) + a raw s_barrier instead of
-// __syncthreads() -- whose workgroup-scope fence, with LDS-DMA transfers of the NEXT tile in flight, compiles to s_waitcnt vmcnt(0):
-// every pass then waited for the whole prefetch and for the previous pass's stores (the reason the persistent variant lost in round 3).
 // Code size (round 5, profiles/r05a_stamps.md): the epilogue8 body is ~10 KB of branchy straight-line code (every epilogue option is a
 // wave-uniform runtime branch).  Fully unrolled -- BM / PR passes x ITER chunks = 8 copies -- the epilogue was 78 KB that each workgroup
 // executes ONCE, i.e. entirely out of instruction-cache misses: ~1.1 us per chunk, 9 us for a bias-only 128x256 tile, 17 us for FFN1's
 // GELU + two outputs (longer than its 11 us K loop).  The pass loop and the chunk loop are therefore ROLLED: one copy of the body, warm
 // after its first trip.  Only the accumulator -> LDS staging needs compile-time register indices: a switch over the WM / PR row blocks.
-template <int BM, int BN, int WGM, int WGN, int SMEM_BYTES, int PR = 64, bool RAW = false, bool FAST = true>
+template <int BM, int BN, int WGM, int WGN, int SMEM_BYTES, int PR = 64, bool FAST = true>
 __device__ __forceinline__ void tile_epilogue8w(GP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], unsigned char* smem, int m0, int n0,
                                                 int tid, float* slab) {
     using T = bf16;
-    if constexpr (!RAW && FAST) {                               // (FAST off: weight-gradient forms -- fp32 output, never a listed combination)
+    if constexpr (FAST) {                               // (FAST off: weight-gradient forms -- fp32 output, never a listed combination)
         if (!slab && p.fast_epi != 0) {                         // specialised body for this call's option combination (gemm_impl.h fast_epilogue)
             constexpr int WM_ = BM / WGM, WN_ = BN / WGN, FN_ = WN_ / 16, SROW_ = BN * 4 + 16, SUB_ = WM_ / PR;
             static_assert(WM_ % PR == 0 && PR * SROW_ <= SMEM_BYTES, "epilogue staging");
@@ -251,7 +249,7 @@ __device__ __forceinline__ void tile_epilogue8w(GP& p, f32x4 (&acc)[BM / WGM / 1
     unsigned char* const stage_base = smem + (lane & 15) * SROW + (wn * WN + 4 * (lane >> 4)) * 4;
 #pragma unroll 1
     for (int h = 0; h < NPASS; ++h) {
-        if constexpr (RAW) { CB_LDS_BARRIER(); } else { __syncthreads(); }
+        __syncthreads();
         if (wm == h / SUB) {
             const int sub = h % SUB;
 #pragma unroll
@@ -265,7 +263,7 @@ __device__ __forceinline__ void tile_epilogue8w(GP& p, f32x4 (&acc)[BM / WGM / 1
                 }
             }
         }
-        if constexpr (RAW) { CB_LDS_BARRIER(); } else { __syncthreads(); }
+        __syncthreads();
 #pragma unroll 1
         for (int it = 0; it < ITER; ++it) {
             const int rl = (tid + it * NT8) / CPR;
@@ -468,196 +466,20 @@ __global__ void __launch_bounds__(NT8, 2) gemm8_kernel(GP p, float* ws) {
         }
     }
     CB_STAMP(2);
-    tile_epilogue8w<BM, BN, WGM, WGN, SMEM_BYTES, 64, false, !LA::TR>(p, acc, smem, m0, n0, tid, slab);
+    tile_epilogue8w<BM, BN, WGM, WGN, SMEM_BYTES, 64, !LA::TR>(p, acc, smem, m0, n0, tid, slab);
     CB_STAMP(3);
     CB_STAMP_FLUSH(p, stamp_lin, tid);
 }
 
 
 // ---------------------------------------------------------------------------------------------
-// Persistent variant (schedule 4, opt-in): at most one workgroup per CU walks the tiles lin = blockIdx.x, + gridDim.x, ... (the
-// XCD-compact order of tile_id(): a workgroup's tiles stay on its XCD).  Before the epilogue of a tile the first NST-1 K tiles of the
-// NEXT tile are already requested into the ring stages the epilogue does not use (the epilogue stages 32 rows per pass inside the
-// stage the K loop read last), so the next tile's cold start runs under the current tile's store burst.  K loop = schedule 0.
-// Hazards: a stage other than the last-read one was consumed before the last barrier every wave passed; the last-read stage is
-// written by the epilogue only behind its own __syncthreads, and by DMA again only behind the first barrier of the next K loop,
-// which every wave reaches after its epilogue.  vmcnt is in order and counts the epilogue's stores: the first wait of a
-// following tile drains everything (vmcnt(0)); from then on the queue holds DMA loads only and the counted waits apply.
-// ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, int NST, typename LA, typename LB, bool RS>
-__global__ void __launch_bounds__(NT8, 2) gemm8p_kernel(GP p0, float* ws) {
-    using T = bf16;
-    constexpr int BK = 64;
-    static_assert(WGM * WGN == 8, "eight waves");
-    constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
-    constexpr int TILE_A = BM * 128, TILE_B = BN * 128, STAGE = TILE_A + TILE_B;
-    constexpr int SMEM_BYTES = NST * STAGE;
-    constexpr int LPT = LA::NI + LB::NI;
-    constexpr int D = NST - 1;
-    constexpr int EPR = 32;                                    // epilogue rows per pass: 32 x (BN * 4 + 16) bytes fit one stage
-    static_assert(EPR * (BN * 4 + 16) <= STAGE, "epilogue staging inside one ring stage");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
-    const unsigned gx = (unsigned)((p0.N + BN - 1) / BN), gy = (unsigned)((p0.M + BM - 1) / BM);
-    const unsigned total = gx * gy * (unsigned)(p0.split_k * (p0.batch > 1 ? p0.batch : 1));
-    const int kt_per = (p0.ktiles + p0.split_k - 1) / p0.split_k;
-    auto coords = [&](unsigned lin) {
-        unsigned l2 = lin;
-        if (p0.xcd_remap) {
-            const unsigned xcd = lin & 7u, i = lin >> 3;
-            const unsigned q = total >> 3, r = total & 7u;
-            l2 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-        }
-        TileId t;
-        t.bx = (int)(l2 % gx);
-        const unsigned rest = l2 / gx;
-        t.by = (int)(rest % gy);
-        t.bz = (int)(rest / gy);
-        return t;
-    };
-    bf16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
-
-    LA la;
-    LB lb;
-    GP p = p0;                                                 // the tile whose K loop runs (batch-rebased)
-    int m0 = 0, n0 = 0, nt = 0, bx = 0;
-    float* slab = nullptr;
-    auto open_tile = [&](unsigned lin) __attribute__((always_inline)) {    // coordinates + DMA addressing of tile `lin`
-        p = p0;
-        TileId bid = coords(lin);
-        const int zsplit = bid.bz % p.split_k, zbatch = bid.bz / p.split_k;
-        apply_batch(p, bid);
-        m0 = bid.by * BM; n0 = bid.bx * BN; bx = bid.bx;
-        const int kt0 = bid.bz * kt_per;
-        nt = ((kt0 + kt_per < p.ktiles) ? kt0 + kt_per : p.ktiles) - kt0;
-        if (nt < 0) nt = 0;
-        slab = ws ? ws + ((int64_t)zbatch * p.split_k + zsplit) * (int64_t)p.M * p.N : nullptr;
-        Opnd oa = {p.A, p.a_tab, p.lda, p.a_mode, p.a_bytes};
-        Opnd ob = {p.B, p.b_tab, p.ldb, p.b_mode, p.b_bytes};
-        la.init(p, oa, m0, p.M, kt0, lane, wave);
-        lb.init(p, ob, n0, p.N, kt0, lane, wave);
-    };
-    auto issue_tile = [&](int stage) __attribute__((always_inline)) {      // this wave's share of the next K tile into `stage`
-        unsigned char* base = smem + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            if (i < LA::NI) {
-                la.issue_one(p, base, wave, i);
-                if (i == LA::NI - 1) la.advance(p);
-            } else {
-                lb.issue_one(p, base + TILE_A, wave, i - LA::NI);
-                if (i == LPT - 1) lb.advance(p);
-            }
-        }
-    };
-    auto ring = [](int s) { return s >= NST ? s - NST : s; };
-
-    unsigned lin = blockIdx.x;
-    if (lin >= total) return;
-    open_tile(lin);
-    int stage0 = 0;
-#pragma unroll
-    for (int s = 0; s < D; ++s)
-        if (s < nt) issue_tile(ring(stage0 + s));
-    bool first = true;
-    for (;;) {
-        f32x4 acc[FM][FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
-        f32x4 accr[RS ? FM : 1];
-#pragma unroll
-        for (int i = 0; i < (RS ? FM : 1); ++i) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; accr[i] = z; }
-        const bool rs_on = RS && p.a_rowsum != nullptr && bx == 0 && wn == 0;      // wave-uniform
-
-        int stage = stage0;
-        for (int t = 0; t < nt; ++t) {
-            if (t == 0 && !first) { CB_WAIT_VMCNT(0); }                   // (the previous tile's stores are in the queue behind the DMA)
-            else if (nt - 1 - t >= D - 1) { CB_WAIT_VMCNT(LPT * (D - 1)); }
-            else { CB_WAIT_VMCNT(0); }
-            __builtin_amdgcn_s_barrier();
-            if (t + D < nt) issue_tile(ring(stage + D));
-            const unsigned char* As = smem + stage * STAGE;
-            const unsigned char* Bs = As + TILE_A;
-#pragma unroll
-            for (int kk = 0; kk < BK / 32; ++kk) {
-                bf16x8 af[FM], bfr[FN];
-#pragma unroll
-                for (int j = 0; j < FN; ++j) bfr[j] = lb.frag(Bs, wn * WN + j * 16, kk, lane);
-#pragma unroll
-                for (int i = 0; i < FM; ++i) af[i] = la.frag(As, wm * WM + i * 16, kk, lane);
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-                if constexpr (RS) {
-                    if (rs_on) {
-#pragma unroll
-                        for (int i = 0; i < FM; ++i) accr[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accr[i], 0, 0, 0);
-                    }
-                }
-            }
-            stage = ring(stage + 1);
-        }
-        // `stage` is the ring position after the last K tile: the stage read last is the one before it (nt == 0: nothing was read)
-        const int last = nt > 0 ? (stage == 0 ? NST - 1 : stage - 1) : stage0;
-        if constexpr (RS) {
-            if (rs_on && (lane >> 4) == 0) {
-#pragma unroll
-                for (int i = 0; i < FM; ++i) {
-                    const int m = m0 + wm * WM + i * 16 + lane;
-                    if (m < p.M) atomicAdd(p.a_rowsum + m, accr[i][0]);
-                }
-            }
-        }
-        // what the epilogue of THIS tile needs, before the loaders and p move on to the next tile
-        GP pe = p;
-        const int m0e = m0, n0e = n0;
-        float* slab_e = slab;
-        const int nt_e = nt;
-        const unsigned nxt = lin + gridDim.x;
-        const bool more = nxt < total;
-        if (more) {
-            if (nt_e == 0) { CB_WAIT_VMCNT(0); __builtin_amdgcn_s_barrier(); }    // (no K loop ran: nobody may still read the ring)
-            open_tile(nxt);
-            stage0 = ring(last + 1);
-#pragma unroll
-            for (int s = 0; s < D; ++s)
-                if (s < nt) issue_tile(ring(stage0 + s));
-        }
-        if (nt_e > 0 || slab_e)
-            tile_epilogue8w<BM, BN, WGM, WGN, STAGE, EPR, true>(pe, acc, smem + last * STAGE, m0e, n0e, tid, slab_e);
-        if (!more) return;
-        lin = nxt;
-        first = false;
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
 // launchers (explicitly instantiated per tile in gemm8_inst_*.hip so that the tiles compile in parallel)
 // ---------------------------------------------------------------------------------------------
-// workgroups of the persistent kernel: one per CU (CB_GEMM8P_MAXWG: tests make a few workgroups walk many tiles)
-inline unsigned gemm8p_max_workgroups() {
-    static const unsigned cap = getenv("CB_GEMM8P_MAXWG") && atoi(getenv("CB_GEMM8P_MAXWG")) > 0 ? (unsigned)atoi(getenv("CB_GEMM8P_MAXWG")) : 256u;
-    return cap;
-}
-
 #define CB_G8_LAUNCH(LA_, LB_, RS_)                                                                                        \
     do {                                                                                                                   \
         if (mode == 0) hipLaunchKernelGGL((gemm8_kernel<BM, BN, WGM, WGN, NST, 0, LA_, LB_, RS_>), grid, dim3(NT8), 0, st, p, ws);      \
         else if (mode == 1) hipLaunchKernelGGL((gemm8_kernel<BM, BN, WGM, WGN, NST, 1, LA_, LB_, RS_>), grid, dim3(NT8), 0, st, p, ws); \
-        else if (mode == 3) {                                                                                              \
-            const unsigned total = grid.x * grid.y * grid.z, cap = gemm8p_max_workgroups();                                \
-            hipLaunchKernelGGL((gemm8p_kernel<BM, BN, WGM, WGN, NST, LA_, LB_, RS_>), dim3(total < cap ? total : cap), dim3(NT8), 0, st, p, ws); \
-        } else hipLaunchKernelGGL((gemm8_kernel<BM, BN, WGM, WGN, NST, 2, LA_, LB_, RS_>), grid, dim3(NT8), 0, st, p, ws);         \
+        else hipLaunchKernelGGL((gemm8_kernel<BM, BN, WGM, WGN, NST, 2, LA_, LB_, RS_>), grid, dim3(NT8), 0, st, p, ws);         \
         return cb_launch_status("cb_gemm");                                                                                \
     } while (0)
 

@@ -40,7 +40,6 @@ struct GP {
     int xcd_remap;              // 1: remap workgroup ids so that each XCD (own L2) owns a contiguous chunk of tiles
     uint32_t a_bytes, b_bytes;
     int ktiles;
-    int raster_w;               // > 0: the XCD-compact tile order walks column panels of this many N tiles (tile_id)
     int wt;                     // 1: the row-contiguous epilogue's bf16 C / C2 stores are write-through (sc1), see store8_wt
     int slab_base, cnt_base;    // grouped launch with slab K split (gemm_tile): this problem's first slab unit / first tile counter
     int fast_epi;               // index into FAST_EPI_COMBOS: the specialised epilogue of this call (fast_epilogue), 0: the generic epilogue8
@@ -689,24 +688,6 @@ __device__ __forceinline__ TileId tile_id(const GP& p) {
     const unsigned xcd = lin & 7u, i = lin >> 3;
     const unsigned q = total >> 3, r = total & 7u;
     const unsigned l2 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-    const unsigned w = (unsigned)p.raster_w;
-    if (w > 0 && w < gx) {
-        // column panels of w N tiles, M tiles fastest across the panel's rows: an XCD's contiguous run of ~total/8 tiles then covers
-        // ~(total/8/w) A panels x w B panels instead of ~(total/8/gx) x gx -- fewer distinct operand bytes per K tile in its L2
-        const unsigned per_z = gx * gy, z = l2 / per_z, rz = l2 - z * per_z;
-        const unsigned nfull = gx / w, full = nfull * w * gy;
-        if (rz < full) {
-            const unsigned panel = rz / (w * gy), within = rz - panel * (w * gy);
-            t.by = (int)(within / w);
-            t.bx = (int)(panel * w + (within - (unsigned)t.by * w));
-        } else {
-            const unsigned r2 = rz - full, wl = gx - nfull * w;
-            t.by = (int)(r2 / wl);
-            t.bx = (int)(nfull * w + (r2 - (unsigned)t.by * wl));
-        }
-        t.bz = (int)z;
-        return t;
-    }
     t.bx = (int)(l2 % gx);
     const unsigned rest = l2 / gx;
     t.by = (int)(rest % gy);
@@ -1470,10 +1451,8 @@ __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 
 // OCC = blocks per CU the register allocation must leave room for (__launch_bounds__'s second argument counts waves per SIMD;
 // a 256-thread block puts one wave on each SIMD)
 // One output tile of one problem: everything a workgroup of gemm_kernel / gemm_group_kernel does once it knows its (problem, tile).
-// KRANGE: the K tiles [kt0_in, kt0_in + nt_in) of the output tile instead of the bid.bz-th of p.split_k equal parts (stream-K: a
-// workgroup's share of a tile is whatever its unit range cuts out of it)
-template <typename T, int BM, int BN, typename LA, typename LB, int PF, bool RS, int OCC, bool KRANGE = false>
-__device__ __forceinline__ void gemm_tile(GP& p, TileId bid, int kt0_in = 0, int nt_in = 0, float* slab = nullptr, int* cnt = nullptr) {
+template <typename T, int BM, int BN, typename LA, typename LB, int PF, bool RS, int OCC>
+__device__ __forceinline__ void gemm_tile(GP& p, TileId bid, float* slab = nullptr, int* cnt = nullptr) {
     using X = Tr<T>;
     constexpr int BK = X::BK;
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
@@ -1491,8 +1470,8 @@ __device__ __forceinline__ void gemm_tile(GP& p, TileId bid, int kt0_in = 0, int
     apply_batch(p, bid);
     const int m0 = bid.by * BM, n0 = bid.bx * BN;
     const int kt_per = (p.ktiles + p.split_k - 1) / p.split_k;
-    const int kt0 = KRANGE ? kt0_in : bid.bz * kt_per;
-    const int nt = KRANGE ? nt_in : ((kt0 + kt_per < p.ktiles) ? kt0 + kt_per : p.ktiles) - kt0;
+    const int kt0 = bid.bz * kt_per;
+    const int nt = ((kt0 + kt_per < p.ktiles) ? kt0 + kt_per : p.ktiles) - kt0;
     if (nt <= 0) return;
 
     LA la;
@@ -1544,17 +1523,9 @@ __device__ __forceinline__ void gemm_tile(GP& p, TileId bid, int kt0_in = 0, int
     // The 128x128 two-blocks-per-CU data-gradient kernel prefetches ONE operand, for the GELU' epilogue (dgrad of BertOutput.dense: the
     // 16 MB pre-activation would otherwise be requested by all blocks at once after their last MFMA).
     constexpr bool DGRAD = sizeof(T) == 2 && !LA::KROW && LB::KROW;
-    // CB_FWD_EPF (round-3 experiment, tools/r03_fwd_epf.sh): forward kernels of the small tiles prefetch the RESIDUAL when the reduction is
-    // at most four K tiles (the ResNet conv3 1x1 convolutions with K = 64 ... 256: one block lives ~5 dependent memory round trips)
-#ifndef CB_FWD_EPF
-#define CB_FWD_EPF 0
-#endif
-    constexpr bool FWD = sizeof(T) == 2 && !LA::KROW && !LB::KROW && CB_FWD_EPF != 0;
-    constexpr int EPF = FWD ? (BM * BN <= 128 * 64 ? 2 : 0) : (!DGRAD ? 0 : (BM * BN <= 128 * 64 ? 2 : (OCC >= 2 ? 1 : 0)));
+    constexpr int EPF = !DGRAD ? 0 : (BM * BN <= 128 * 64 ? 2 : (OCC >= 2 ? 1 : 0));
     EpiPre<BM, BN, EPF != 1> epre;
-    const bool epf_on = EPF != 0 && p.c_vec8 &&
-        (FWD ? (p.residual != nullptr && !p.relu_bwd && !p.mask && !p.dact_pre && nt <= 4)
-             : (EPF == 2 ? p.relu_bwd != 0 : (p.dact_pre != nullptr && !p.relu_bwd)));      // block-uniform
+    const bool epf_on = EPF != 0 && p.c_vec8 && (EPF == 2 ? p.relu_bwd != 0 : (p.dact_pre != nullptr && !p.relu_bwd));      // block-uniform
     if constexpr (EPF != 0) {
         if (epf_on) epi_prefetch<T, BM, BN, EPF != 1>(p, epre, m0, n0, tid);
     }
@@ -1670,52 +1641,50 @@ __device__ __forceinline__ void gemm_tile(GP& p, TileId bid, int kt0_in = 0, int
     // (sc1 on both: the accesses of an agent-scope atomic store / load), the ticket is taken after s_waitcnt vmcnt(0) + a barrier.  A
     // __threadfence() pair here (buffer_wbl2 + buffer_inv: the whole L2 of the XCD invalidated once per workgroup) cost the co-resident
     // workgroups their operand reuse: +0.45 ms per step (profiles/r05x_slab_ksplit_ab.txt, first variant).
-    if constexpr (!KRANGE) {
-        if (slab != nullptr && p.split_k > 1) {                                 // (block-uniform)
-            __shared__ int s_last;
-            constexpr int SC1 = 16;
-            const int tile_lin = bid.by * ((p.N + BN - 1) / BN) + bid.bx;
-            const int parts = (p.ktiles + kt_per - 1) / kt_per;                 // K parts that hold K tiles (the others returned above)
-            float* const base = slab + ((int64_t)p.slab_base + (int64_t)tile_lin * p.split_k) * (BM * BN);
-            {
-                const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base + (int64_t)bid.bz * (BM * BN), (short)0, BM * BN * 4, 0x00020000);
-#pragma unroll
-                for (int i = 0; i < BM / 32; ++i)
-#pragma unroll
-                    for (int j = 0; j < BN / 32; ++j) {
-                        union { f32x4 f; u32x4 r; } u;
-                        u.f = acc[i][j];
-                        __builtin_amdgcn_raw_buffer_store_b128(u.r, rs, (uint32_t)(((i * (BN / 32) + j) * NTHREADS + tid) * 16), 0, SC1);
-                    }
-            }
-            __builtin_amdgcn_s_waitcnt(0x0f70);                                 // vmcnt(0): this thread's parts have left for the memory side
-            __syncthreads();
-            if (tid == 0) s_last = atomicAdd(cnt + p.cnt_base + tile_lin, 1) == parts - 1;
-            __syncthreads();
-            if (!s_last) {
-                CB_STAMP(3);
-                CB_STAMP_FLUSH(p, stamp_lin, tid);
-                return;
-            }
+    if (slab != nullptr && p.split_k > 1) {                                 // (block-uniform)
+        __shared__ int s_last;
+        constexpr int SC1 = 16;
+        const int tile_lin = bid.by * ((p.N + BN - 1) / BN) + bid.bx;
+        const int parts = (p.ktiles + kt_per - 1) / kt_per;                 // K parts that hold K tiles (the others returned above)
+        float* const base = slab + ((int64_t)p.slab_base + (int64_t)tile_lin * p.split_k) * (BM * BN);
+        {
+            const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base + (int64_t)bid.bz * (BM * BN), (short)0, BM * BN * 4, 0x00020000);
 #pragma unroll
             for (int i = 0; i < BM / 32; ++i)
 #pragma unroll
-                for (int j = 0; j < BN / 32; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
-#pragma unroll 2                                                                 // (two parts' loads in flight; the additions keep the part order)
-            for (int z = 0; z < parts; ++z) {
-                const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base + (int64_t)z * (BM * BN), (short)0, BM * BN * 4, 0x00020000);
-#pragma unroll
-                for (int i = 0; i < BM / 32; ++i)
-#pragma unroll
-                    for (int j = 0; j < BN / 32; ++j) {
-                        union { u32x4 r; f32x4 f; } u;
-                        u.r = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(((i * (BN / 32) + j) * NTHREADS + tid) * 16), 0, SC1);
-                        acc[i][j] += u.f;
-                    }
-            }
-            if (tid == 0) atomicExch(cnt + p.cnt_base + tile_lin, 0);           // ready for the next launch (same stream: ordered)
-            p.split_k = 1;                                                      // the epilogue below is the plain one
+                for (int j = 0; j < BN / 32; ++j) {
+                    union { f32x4 f; u32x4 r; } u;
+                    u.f = acc[i][j];
+                    __builtin_amdgcn_raw_buffer_store_b128(u.r, rs, (uint32_t)(((i * (BN / 32) + j) * NTHREADS + tid) * 16), 0, SC1);
+                }
         }
+        __builtin_amdgcn_s_waitcnt(0x0f70);                                 // vmcnt(0): this thread's parts have left for the memory side
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(cnt + p.cnt_base + tile_lin, 1) == parts - 1;
+        __syncthreads();
+        if (!s_last) {
+            CB_STAMP(3);
+            CB_STAMP_FLUSH(p, stamp_lin, tid);
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i)
+#pragma unroll
+            for (int j = 0; j < BN / 32; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
+#pragma unroll 2                                                                 // (two parts' loads in flight; the additions keep the part order)
+        for (int z = 0; z < parts; ++z) {
+            const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base + (int64_t)z * (BM * BN), (short)0, BM * BN * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < BM / 32; ++i)
+#pragma unroll
+                for (int j = 0; j < BN / 32; ++j) {
+                    union { u32x4 r; f32x4 f; } u;
+                    u.r = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(((i * (BN / 32) + j) * NTHREADS + tid) * 16), 0, SC1);
+                    acc[i][j] += u.f;
+                }
+        }
+        if (tid == 0) atomicExch(cnt + p.cnt_base + tile_lin, 0);           // ready for the next launch (same stream: ordered)
+        p.split_k = 1;                                                      // the epilogue below is the plain one
     }
     if constexpr (EPF != 0) tile_epilogue<T, BM, BN, SMEM_BYTES, EPF>(p, acc, smem, m0, n0, tid, epre, epf_on);
     else tile_epilogue<T, BM, BN, SMEM_BYTES, 0, !LA::KROW>(p, acc, smem, m0, n0, tid);
@@ -1774,76 +1743,14 @@ __global__ void __launch_bounds__(256, OCC) gemm_group_kernel(GroupArgs ga) {
     TileId bid;
     const int pi = group_locate<BM, BN>(ga, bid);
     GP p = ga.g[pi];
-    gemm_tile<T, BM, BN, LA, LB, PF, RS, OCC>(p, bid, 0, 0, ga.slab, ga.cnt);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Stream-K form of the grouped WEIGHT-GRADIENT launch (round 5).  The split-K launches above give every output tile `split` equal K
-// parts: 6 x 16 tiles x 8 parts = 768 workgroups for two rounds of 512 resident ones (the second round starts 60-115 us into a 105-170 us
-// launch, profiles/r05a_stamps_before.md), and every part ends with a 64 KB burst of fp32 atomics (27-30 us per launch).  Here the launch is
-// PERSISTENT: the work of all problems is one line of units (one K tile of one output tile, tile-major), workgroup g of G owns the units
-// [g U / G, (g + 1) U / G) and walks them -- a tile's K range is cut only where a workgroup's share ends.  Every workgroup does the same
-// number of K tiles (no second round, no tail), and the number of atomics epilogues drops from tiles x split to ~tiles + G.  The partial
-// products combine through the same fp32 atomics as the split-K path (zero-initialised gradient buffer, order-independent up to fp32
-// rounding -- exactly the semantics the convolution weight gradients already had).
-// ---------------------------------------------------------------------------------------------
-constexpr int STREAMK_MAX = GROUP_MAX - 1;        // (two int arrays beside the problems: one problem fewer fits the 4 KiB argument block)
-struct StreamKArgs {
-    int n, xcd_remap;
-    int unit_end[STREAMK_MAX];        // problem i owns units [unit_end[i-1], unit_end[i]): its tiles x its K tiles
-    int kchunk[STREAMK_MAX];          // K tiles per chunk of problem i (see the unit order below)
-    GP g[STREAMK_MAX];
-};
-static_assert(sizeof(StreamKArgs) + 256 <= 4096, "kernel arguments (+ the hidden ones) are limited to 4 KiB");
-
-// Unit order inside a problem: (K chunk, tile, K tile inside the chunk).  Workgroups with neighbouring unit ranges therefore work on
-// NEIGHBOURING TILES OVER THE SAME K RANGE at the same time and share the operand rows of that range in L2 -- what the split-K launch
-// order gave for free; a plain tile-major line (every workgroup a different K range of a different tile) streamed every operand byte
-// from HBM once per tile and measured 0.24 ms SLOWER per step than split-K (profiles/r05m_streamk_ab.txt).  The chunk length is about
-// one workgroup's share, so most segments are whole (chunk, tile) pieces.
-template <typename T, int BM, int BN, typename LA, typename LB, int PF, int OCC>
-__global__ void __launch_bounds__(256, OCC) gemm_streamk_kernel(StreamKArgs ga) {
-    const unsigned G = gridDim.x;
-    unsigned wg = blockIdx.x;
-    if (ga.xcd_remap) {                                     // consecutive unit ranges on one XCD (its L2 sees a K range's operands once)
-        const unsigned xcd = wg & 7u, i = wg >> 3;
-        const unsigned q = G >> 3, r = G & 7u;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-    }
-    const long long U = ga.unit_end[ga.n - 1];
-    long long u = U * wg / G;
-    const long long u1 = U * (wg + 1) / G;
-    int pi = 0;
-    while (u < u1) {
-        while (pi + 1 < ga.n && u >= ga.unit_end[pi]) ++pi;
-        GP p = ga.g[pi];
-        const long long local = u - (pi > 0 ? ga.unit_end[pi - 1] : 0);
-        const unsigned gx = (unsigned)((p.N + BN - 1) / BN), gy = (unsigned)((p.M + BM - 1) / BM);
-        const long long tiles = (long long)gx * gy;
-        const int kc = ga.kchunk[pi];
-        const long long per_chunk = tiles * kc;
-        const int chunk = (int)(local / per_chunk);
-        const long long within = local - (long long)chunk * per_chunk;
-        const int klen = (chunk + 1) * kc <= p.ktiles ? kc : p.ktiles - chunk * kc;       // (the last chunk may be shorter)
-        const int tile = (int)(within / klen), kk = (int)(within - (long long)tile * klen);
-        long long len = klen - kk;
-        if (len > u1 - u) len = u1 - u;
-        TileId bid;
-        bid.bx = (int)((unsigned)tile % gx);
-        bid.by = (int)((unsigned)tile / gx);
-        bid.bz = 0;
-        p.split_k = 2;                                      // (any value > 1: partial products leave through the atomics epilogue)
-        gemm_tile<T, BM, BN, LA, LB, PF, false, OCC, true>(p, bid, chunk * kc + kk, (int)len);
-        __syncthreads();                                    // the next segment's first K tile overwrites the LDS the epilogue staged through
-        u += len;
-    }
+    gemm_tile<T, BM, BN, LA, LB, PF, RS, OCC>(p, bid, ga.slab, ga.cnt);
 }
 
 // =============================================================================================
-// v6 structure (bf16 fast path without convolution-gathered KROW operands): operands go global -> LDS by
-// LDS-DMA (buffer_load_dwordx4 ... lds): no VGPR staging, no ds_write, and an NST-deep LDS ring whose depth is
-// spent with counted s_waitcnt vmcnt(N) + one raw s_barrier per K step.  The LDS destination of an LDS-DMA is
-// wave-uniform base + lane*16, so the XOR swizzles of the tile images are applied to each lane's SOURCE address.
+// LDS-DMA helpers (buffer_load_dwordx4 ... lds: no VGPR staging, no ds_write) shared by the 8-wave kernels (gemm8_impl.h) and the
+// streaming kernel (gemm_stream_impl.h).  The LDS destination of an LDS-DMA is wave-uniform base + lane*16, so the XOR swizzles of the
+// tile images are applied to each lane's SOURCE address.  (A 4-wave LDS-DMA ring kernel lived here in rounds 1-5: measured equal or
+// slower than the register ring on every shape, profiles/r01_gemm_microbench.md, tools/dma_probe history -- deleted in round 6.)
 // =============================================================================================
 __device__ __forceinline__ void dma16(rsrc_t rs, unsigned char* lds_wave_base, uint32_t voff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
@@ -1922,146 +1829,6 @@ template <int ROWS, bool GATHER> struct RowkDma {
     }
 };
 
-// KROW natural image [64 k-lines][ROWS*2 B], 16-byte chunk c of line k stored at chunk c ^ tr_chunk_swz(k)
-template <int ROWS, int KMODE> struct KrowDma {
-    using X = Tr<bf16>;
-    static constexpr bool TR = true;
-    static constexpr int CH = ROWS / 8;                 // chunks per k-line
-    static constexpr int LPI = 64 / CH;                 // k-lines per DMA instruction
-    static constexpr int NI = X::BK / LPI / 4;          // DMA instructions per wave per tile
-    static_assert(KMODE != KM_GATHER, "gathered KROW operands use the register path");
-    rsrc_t rs;
-    uint32_t ldb, bound;
-    uint32_t voff[NI];
-    int kl[NI], co[NI], tap[NI];
-    bool act;
-
-    __device__ __forceinline__ void init(const GP& p, const Opnd& o, int row0, int bnd, int kt0, int tid) {
-        rs = make_rsrc(o.base, o.bytes);
-        ldb = (uint32_t)o.ld * 2u; bound = (uint32_t)bnd;
-        const int lane = tid & 63, wave = tid >> 6;
-        act = false;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int kline = (i * 4 + wave) * LPI + lane / CH;
-            const int lchunk = (lane % CH) ^ tr_chunk_swz<ROWS>(kline);
-            const int row = row0 + lchunk * 8;
-            act = row < bnd;                                        // (lchunk depends on kline only through the swizzle:
-            kl[i] = kt0 * X::BK + kline;                            //  validity is tracked per instruction below)
-            co[i] = kl[i]; tap[i] = 0;
-            if constexpr (KMODE == KM_PLAIN) {
-                voff[i] = (row < bnd) ? ((uint32_t)kl[i] * (uint32_t)o.ld + (uint32_t)row) * 2u : OOB;
-            } else {
-                tap[i] = kl[i] / p.Ct;
-                co[i] = kl[i] - tap[i] * p.Ct;
-                voff[i] = (row < bnd) ? (uint32_t)row * 2u : OOB;
-            }
-        }
-    }
-    template <bool CHECK> __device__ __forceinline__ void issue(const GP& p, unsigned char* tile, int wave) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            if constexpr (KMODE == KM_PLAIN) {
-                uint32_t o32 = voff[i];
-                if (CHECK && kl[i] >= p.K) o32 = OOB;
-                dma16(rs, tile + (i * 4 + wave) * 1024, o32);
-                voff[i] += X::BK * ldb;                             // (OOB + n * BK * ld stays >= 2 GiB: K * ld < 2 GiB)
-                kl[i] += X::BK;
-            } else {
-                const int tapw = p.flip ? (p.R * p.S - 1 - tap[i]) : tap[i];
-                const bool v = tap[i] < p.R * p.S;
-                dma16(rs, tile + (i * 4 + wave) * 1024, v ? (uint32_t)co[i] * ldb + (uint32_t)tapw * bound * 2u + voff[i] : OOB);
-                co[i] += X::BK;
-                while (co[i] >= p.Ct) { co[i] -= p.Ct; ++tap[i]; }
-            }
-        }
-    }
-};
-
-template <int BM, int BN, typename LA, typename LB, int NST, int OCC = 1>
-__global__ void __launch_bounds__(256, OCC) gemm_dma_kernel(GP p) {
-    using T = bf16;
-    using X = Tr<bf16>;
-    constexpr int BK = X::BK;
-    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
-    constexpr int TILE_A = BM * 128, TILE_B = BN * 128, STAGE = TILE_A + TILE_B;
-    constexpr int SMEM_BYTES = NST * STAGE;
-    constexpr int LPT = LA::NI + LB::NI;                      // DMA instructions per wave per K tile
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    TileId bid = tile_id(p);
-    apply_batch(p, bid);
-    const int m0 = bid.by * BM, n0 = bid.bx * BN;
-    const int kt_per = (p.ktiles + p.split_k - 1) / p.split_k;
-    const int kt0 = bid.bz * kt_per;
-    const int nt = ((kt0 + kt_per < p.ktiles) ? kt0 + kt_per : p.ktiles) - kt0;
-    if (nt <= 0) return;
-
-    LA la;
-    LB lb;
-    {
-        Opnd oa = {p.A, p.a_tab, p.lda, p.a_mode, p.a_bytes};
-        Opnd ob = {p.B, p.b_tab, p.ldb, p.b_mode, p.b_bytes};
-        la.init(p, oa, m0, p.M, kt0, tid);
-        lb.init(p, ob, n0, p.N, kt0, tid);
-    }
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) { f32x4 z = {0.f, 0.f, 0.f, 0.f}; acc[i][j] = z; }
-
-    auto issue = [&](int stage) {                     // (K tails and rows past M/N read zeros through the descriptor)
-        unsigned char* base = smem + stage * STAGE;
-        la.template issue<true>(p, base, wave);
-        lb.template issue<true>(p, base + TILE_A, wave);
-    };
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
-        if (s < nt) issue(s);
-
-    int stage = 0;                                    // stage holding K tile t
-    for (int t = 0; t < nt; ++t) {
-        // this wave's share of tile t has landed when at most min(NST-2, tiles issued beyond t) tiles are in flight
-        if (nt - 1 - t >= NST - 2) { CB_WAIT_VMCNT(LPT * (NST - 2)); }
-        else { CB_WAIT_VMCNT(0); }
-        __builtin_amdgcn_s_barrier();                 // everyone's share landed; everyone is done reading stage (t-1)
-        if (t + NST - 1 < nt) {
-            int ns = stage + NST - 1;
-            if (ns >= NST) ns -= NST;
-            issue(ns);
-        }
-        const unsigned char* As = smem + stage * STAGE;
-        const unsigned char* Bs = As + TILE_A;
-#pragma unroll
-        for (int kk = 0; kk < BK / 32; ++kk) {
-            bf16x8 af[FM], bfr[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                if constexpr (LA::TR) af[i] = tr_frag<BM>(As, wm * WM + i * 16, kk, lane);
-                else af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off<T>(wm * WM + i * 16 + (lane & 15), kk * 4 + (lane >> 4)));
-            }
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                if constexpr (LB::TR) bfr[j] = tr_frag<BN>(Bs, wn * WN + j * 16, kk, lane);
-                else bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off<T>(wn * WN + j * 16 + (lane & 15), kk * 4 + (lane >> 4)));
-            }
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        }
-        if (++stage == NST) stage = 0;
-    }
-    __syncthreads();
-    tile_epilogue<T, BM, BN, SMEM_BYTES>(p, acc, smem, m0, n0, tid);
-}
-
-
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <typename T, int BM, int BN, int PF, int OCC, typename LA, typename LB, bool RS = false>
@@ -2086,46 +1853,6 @@ int launch_gemm(const GP& p, bool fast, hipStream_t st) {
     if (fast) {
         const int taps = p.R * p.S;
         if constexpr (sizeof(T) == 2) {
-            // The LDS-DMA ring kernel is OPT-IN (CB_GEMM_DMA=1).  Round 2 re-measured it on 128x128 tiles with 3 / 4 / 5 stages
-            // (2-4 K tiles in flight, tools/dma_probe.py): 366 / 370 / 400 TF on 2624x3072x768 against 542 TF of the two-blocks-
-            // per-CU register ring, 465-514 vs 734 TF on 8192x8192x1024 -- its one block per CU and one barrier per K step lose
-            // more than the deeper prefetch gains.  Round 1: measured on MI355X against the register-staged kernel
-            // below for every GEMM of the step: equal where K is long (both run into the L2->LDS bandwidth of the 64x64
-            // tile, profiles/r01_gemm_l2_analysis.md; an 8-stage ring, CB_GEMM_DMA_DEEP=1, changes nothing either) and
-            // 10-20 % slower for short-K convolutions (its 64 KiB ring halves the blocks per CU).
-            static const bool use_dma = getenv("CB_GEMM_DMA") != nullptr;
-            constexpr int NST = (BM >= 128 && BN >= 128) ? (OCC >= 2 ? 2 : 3) : 4;    // (OCC 2: 64 KiB ring, two blocks per CU)
-            const bool ct_ok = p.Ct % Tr<bf16>::BK == 0;
-            if (use_dma) {
-                dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.split_k * (p.batch > 1 ? p.batch : 1));
-                static const int deep_env = getenv("CB_GEMM_DMA_DEEP") ? atoi(getenv("CB_GEMM_DMA_DEEP")) : 0;
-                const int64_t nblk = (int64_t)grid.x * grid.y * grid.z;
-                const bool deep = (BM == 64 && BN == 64) && deep_env != 0 && nblk <= 320 && p.ktiles / p.split_k >= 8;
-#define CB_LAUNCH_DMA(LA_, LB_)                                                                               \
-    do {                                                                                                      \
-        if constexpr (BM == 64 && BN == 64) {                                                                 \
-            if (deep) {                                                                                       \
-                hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, LA_, LB_, 8>), grid, dim3(NTHREADS), 0, st, p);   \
-                return cb_launch_status("cb_gemm");                                                           \
-            }                                                                                                 \
-        }                                                                                                     \
-        hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, LA_, LB_, NST, OCC>), grid, dim3(NTHREADS), 0, st, p);    \
-        return cb_launch_status("cb_gemm");                                                                   \
-    } while (0)
-                using RA0 = RowkDma<BM, false>; using RA1 = RowkDma<BM, true>; using RB0 = RowkDma<BN, false>;
-                using KA0 = KrowDma<BM, KM_PLAIN>; using KB0 = KrowDma<BN, KM_PLAIN>; using KB1 = KrowDma<BN, KM_TAPS>;
-                if (p.a_mode == CB_ROWK && p.b_mode == CB_ROWK) CB_LAUNCH_DMA(RA0, RB0);
-                if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_ROWK) CB_LAUNCH_DMA(RA1, RB0);
-                // measured (profiles/r01_gemm_microbench.md): the DMA ring wins for k-contiguous operands only; with a
-                // transpose-read (KROW) operand the register-staged kernels below are faster, so those stay opt-in
-                static const bool dma_krow = getenv("CB_GEMM_DMA_KROW") != nullptr;
-                if (dma_krow) {
-                    if (p.a_mode == CB_ROWK && (p.b_mode == CB_KROW || (p.b_mode == CB_KROW_TAPS && taps == 1))) CB_LAUNCH_DMA(RA0, KB0);
-                    if (p.a_mode == CB_ROWK_GATHER && p.b_mode == CB_KROW_TAPS && ct_ok) CB_LAUNCH_DMA(RA1, KB1);
-                    if (p.a_mode == CB_KROW && p.b_mode == CB_KROW && !p.a_rowsum) CB_LAUNCH_DMA(KA0, KB0);
-                }
-#undef CB_LAUNCH_DMA
-            }
             // measured on MI355X: next to a ROWK operand the transpose-read image wins for 64-row tiles, the
             // register transpose (KB = 4, all 256 threads) for 128-row tiles; with two KROW operands the
             // transpose-read image wins for both tile sizes (profiles/r01_gemm_microbench.md)
@@ -2171,14 +1898,6 @@ enum { GC_WGRAD = 0,        // A KROW, B KROW            (weight gradient of a L
        GC_COUNT = 4 };
 
 // stream-K launcher: bf16 weight-gradient classes only (A KROW, B KROW | KROW_GATHER, transpose-read loaders)
-template <int BM, int BN, int PF, int OCC>
-int launch_gemm_streamk(const StreamKArgs& ga, int cls, unsigned workgroups, hipStream_t st) {
-    using KA = KrowTr<BM, KM_PLAIN>; using KB0 = KrowTr<BN, KM_PLAIN>; using KB2 = KrowTr<BN, KM_GATHER>;
-    if (cls == GC_WGRAD) hipLaunchKernelGGL((gemm_streamk_kernel<bf16, BM, BN, KA, KB0, PF, OCC>), dim3(workgroups), dim3(NTHREADS), 0, st, ga);
-    else hipLaunchKernelGGL((gemm_streamk_kernel<bf16, BM, BN, KA, KB2, PF, OCC>), dim3(workgroups), dim3(NTHREADS), 0, st, ga);
-    return cb_launch_status("cb_gemm_group (stream-K)");
-}
-
 template <typename T, int BM, int BN, int PF, int OCC>
 int launch_gemm_group(const GroupArgs& ga, int cls, hipStream_t st) {
     const dim3 grid((unsigned)ga.tile_end[ga.n - 1]);

@@ -6,5 +6,4 @@
 namespace cbgemm {
 template int launch_gemm<bf16, 128, 128, 1, 2>(const GP&, bool, hipStream_t);
 template int launch_gemm_group<bf16, 128, 128, 1, 2>(const GroupArgs&, int, hipStream_t);
-template int launch_gemm_streamk<128, 128, 1, 2>(const StreamKArgs&, int, unsigned, hipStream_t);
 }

@@ -193,15 +193,15 @@ __global__ void __launch_bounds__(256, OCC) gemm_stream_kernel(GP p) {
 // epilogue-operand prefetch runs that one at 5.5 TB/s).
 constexpr int STREAM_VARIANTS = 2;
 inline int stream_workgroups_per_cu(int) { return 2; }
-inline unsigned stream_cus() {                                  // CUs of the current device (MI355X: 256); CB_GEMM_STREAM_CUS overrides
+inline unsigned stream_cus() {                                  // CUs of the current device (MI355X: 256)
     static const unsigned n = [] {
-        if (getenv("CB_GEMM_STREAM_CUS") && atoi(getenv("CB_GEMM_STREAM_CUS")) > 0) return (unsigned)atoi(getenv("CB_GEMM_STREAM_CUS"));
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             return (unsigned)cus;
         return 256u;
     }();
-    return n;
+    const int cap = cb_persistent_max_workgroups(0);            // (tests: CB_PERSISTENT_MAXWG workgroups in all, at least one "CU")
+    return cap > 0 ? (unsigned)((cap + 1) / 2) : n;
 }
 
 template <int BM, int BN, int KT, int OCC>

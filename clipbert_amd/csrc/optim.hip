@@ -120,11 +120,8 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* p, const G* g, float*
     }
 }
 
-bool adamw_nt() {
-    // round 3 (profiles/r03p_adamw_nt.txt): 6.09 -> 6.38 TB/s on a 96 M-element range, the step unchanged to -0.01 ms; CB_ADAMW_NT=0 turns it off
-    static const bool on = !(getenv("CB_ADAMW_NT") != nullptr && atoi(getenv("CB_ADAMW_NT")) == 0);
-    return on;
-}
+// non-temporal fp32 state traffic (round 3, profiles/r03p_adamw_nt.txt: 6.09 -> 6.38 TB/s on a 96 M-element range)
+constexpr bool adamw_nt() { return true; }
 }  // namespace
 
 extern "C" int cb_sq_sum(const float* g, int64_t n, float* out_accum, void* stream) {

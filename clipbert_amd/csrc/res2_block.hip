@@ -281,8 +281,7 @@ extern "C" int cb_res2_block(const cb_res2_desc* d, void* stream) {
     const int64_t xb = (int64_t)d->N * d->H * d->W * d->cin * 2;
     CB_REQUIRE(xb < 0x7fffffffll, "cb_res2_block: input larger than 2 GiB");
     p.x_bytes = (uint32_t)xb;
-    const char* cap = getenv("CB_RES2_MAXWG");               // (tests: a few workgroups walk many tiles)
-    const int max_wg = cap && atoi(cap) > 0 ? atoi(cap) : 512;                                                                        // two per CU
+    const int max_wg = cb_persistent_max_workgroups(512);                                                                           // two per CU
     const unsigned grid = (unsigned)(nt < max_wg ? nt : max_wg);
     hipStream_t st = cb_stream(stream);
     if (d->cin == 64) hipLaunchKernelGGL((res2_block_kernel<64, true>), dim3(grid), dim3(256), 0, st, p);

@@ -162,10 +162,7 @@ extern "C" int cb_stem_pool(const void* packed, const void* weight, const float*
     const int64_t nt = (int64_t)N * p.tiles_h * p.tiles_w;
     CB_REQUIRE(nt < (1ll << 31), "cb_stem_pool: too many tiles");
     p.ntiles = (int)nt;
-    const char* cap = getenv("CB_STEM_MAXWG");                // (tests: a few workgroups walk many tiles)
-    const int max_wg = cap && atoi(cap) > 0 ? atoi(cap) : 512;
-    static const bool four_waves = getenv("CB_STEM_4WAVE") != nullptr;          // diagnostic: the 256-thread form
-    if (four_waves) hipLaunchKernelGGL((stem_pool_kernel<256>), dim3((unsigned)(nt < max_wg ? nt : max_wg)), dim3(256), 0, cb_stream(stream), p);
-    else hipLaunchKernelGGL((stem_pool_kernel<512>), dim3((unsigned)(nt < max_wg ? nt : max_wg)), dim3(512), 0, cb_stream(stream), p);
+    const int max_wg = cb_persistent_max_workgroups(512);
+    hipLaunchKernelGGL((stem_pool_kernel<512>), dim3((unsigned)(nt < max_wg ? nt : max_wg)), dim3(512), 0, cb_stream(stream), p);
     return cb_launch_status("cb_stem_pool");
 }

@@ -762,18 +762,18 @@ def encoder_forward(model: ClipBertBaseModel, grid, ids, mask, src_row, pooled_d
         a, mean1, rstd1 = ops.layernorm_fwd(a_pre, so.LayerNorm.weight, so.LayerNorm.bias, eps, save_stats=save,
                                             out=stk.a[li] if save else None)
         hact = stk.hact[li] if save else torch.empty(M, ff, dtype=dt, device=dev)
-        hpre = torch.empty(M, ff, dtype=dt, device=dev) if save else None
+        hsave = torch.empty(M, ff, dtype=dt, device=dev) if save else None     # gelu'(pre) (pack.gelu_saved_grad) or the pre-activation
         # (training: the second output is gelu'(pre-activation), all the backward needs of it -- one evaluation of exp / erfc for both, and
         # the FFN2 data-gradient epilogue multiplies by the stored value instead of evaluating the derivative: CB_ACT_GELU_SAVE_GRAD)
         ops.gemm(a, bank.compute(it.dense.weight), M, ff, d, out=hact, shift=it.dense.bias,
-                 act=ops.ACT_GELU_SAVE_GRAD if (save and _GELU_SAVE_GRAD) else ACT_GELU, out2=hpre)
+                 act=ops.ACT_GELU_SAVE_GRAD if (save and _GELU_SAVE_GRAD) else ACT_GELU, out2=hsave)
         o_pre = torch.empty(M, d, dtype=dt, device=dev)
         ops.gemm(hact, bank.compute(ou.dense.weight), M, d, ff, out=o_pre, shift=ou.dense.bias, residual=a, dropout_p=p_h,
                  dropout_seed=_seed(_SITE_OUT, li, fwd_i), seed_ptr=rt.seed_dev)
         out, mean2, rstd2 = ops.layernorm_fwd(o_pre, ou.LayerNorm.weight, ou.LayerNorm.bias, eps, save_stats=save,
                                               out=stk.x[li + 1] if (save and li + 1 < nl) else None)
         if save:
-            layers.append((x, qkv, ctx, lse, a_pre, mean1, rstd1, a, hpre, hact, o_pre, mean2, rstd2))
+            layers.append((x, qkv, ctx, lse, a_pre, mean1, rstd1, a, hsave, hact, o_pre, mean2, rstd2))
         x = out
     pooled = torch.empty(bsz, d, dtype=dt, device=dev)
     p_pool = p_h if pooled_dropout else 0.0
@@ -789,7 +789,8 @@ def encoder_forward(model: ClipBertBaseModel, grid, ids, mask, src_row, pooled_d
     if save:
         pack = SimpleNamespace(layers=layers, x_final=x, pooled=pooled, pooled_raw=pooled_raw, p_pool=p_pool, pre=pre,
                                mean0=mean0, rstd0=rstd0, ids=ids_c, key_mask=key_mask, src_row=src_row, sel=sel, bsz=bsz,
-                               lt=lt, lv=lv, L=L, grid_shape=tuple(grid.shape), p_h=p_h, p_a=p_a, stk=stk, fwd_i=fwd_i, text_repeat=text_repeat)
+                               lt=lt, lv=lv, L=L, grid_shape=tuple(grid.shape), p_h=p_h, p_a=p_a, stk=stk, fwd_i=fwd_i, text_repeat=text_repeat,
+                               gelu_saved_grad=bool(_GELU_SAVE_GRAD))
     return x, pooled, pack
 
 
@@ -931,13 +932,14 @@ def encoder_backward(model: ClipBertBaseModel, pk, d_seq, d_pooled):
     for li in range(nl - 1, -1, -1):
         layer = model.encoder.layer[li]
         att, so, it, ou = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
-        x, qkv, ctx, lse, a_pre, mean1, rstd1, a, hpre, hact, o_pre, mean2, rstd2 = pk.layers[li]
+        x, qkv, ctx, lse, a_pre, mean1, rstd1, a, hsave, hact, o_pre, mean2, rstd2 = pk.layers[li]
         keep = dict(dx2=gs.out[li]) if pk.p_h > 0 else dict(dx=gs.out[li])
         d_o_pre, d_o_drop = ln_bwd(2 * li + 1, dx, o_pre, ou.LayerNorm, mean2, rstd2, _seed(_SITE_OUT, li, pk.fwd_i), keep)
         g = d_o_drop if d_o_drop is not None else d_o_pre
         dhp = gs.hp[li]
-        ops.gemm(g, bank.compute(ou.dense.weight), M, ff, d, out=dhp, b_mode=KROW, gelu_grad_pre=hpre,      # dgrad x GELU'
-                 act=ops.ACT_SAVED_GRAD if _GELU_SAVE_GRAD else ACT_NONE)
+        # (which form the forward saved travels in the pack: a backward never multiplies by the wrong one whatever the flag says by now)
+        ops.gemm(g, bank.compute(ou.dense.weight), M, ff, d, out=dhp, b_mode=KROW, gelu_grad_pre=hsave,      # dgrad x GELU'
+                 act=ops.ACT_SAVED_GRAD if pk.gelu_saved_grad else ACT_NONE)
         da = torch.empty(M, d, dtype=dt, device=dev)
         ops.gemm(dhp, bank.compute(it.dense.weight), M, d, ff, out=da, b_mode=KROW, residual=d_o_pre)
         keep = dict(dx2=gs.att[li]) if pk.p_h > 0 else dict(dx=gs.att[li])

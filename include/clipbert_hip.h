@@ -65,9 +65,7 @@ typedef struct {
     int64_t sH, sW;           /* element strides of one image row / one pixel                        */
     int32_t flip_taps;        /* CB_KROW_TAPS: read weight tap (R-1-r, S-1-s) (transposed conv)      */
     int32_t schedule;         /* tiles 5-7 only: 0 = default K-loop schedule, 1 / 2 / 3 = force schedule 0 / 1 / 2 of
-                                 csrc/gemm8_impl.h (diagnostic: tools/gemm8_probe.py, tests); 4 = the persistent kernel (one
-                                 workgroup per CU walks the tiles, next tile's first K tiles requested before the epilogue:
-                                 an experiment, measured slower -- profiles/r03r_persistent_probe.txt -- never chosen by itself) */
+                                 csrc/gemm8_impl.h (diagnostic: tools/gemm8_probe.py, tests) */
     /* output */
     void* C; int64_t ldc;
     const int32_t* c_rowmap;  /* optional: output row m is written at row c_rowmap[m]                */

@@ -1,4 +1,4 @@
-"""Parity of THE THING THAT IS TIMED: the training step bench.py captures and replays (tools/bench_step.py builds
+"""Parity of THE THING THAT IS TIMED: the training step bench.py captures and replays (clipbert_amd/bench/step.py builds
 it; bench.py's default path uses these very closures).
 
 1. dropout off: one EAGER step and one REPLAY of the captured hipGraph from the same state give the same gradients and the same
@@ -17,7 +17,6 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 import parity_bounds as PB  # noqa: E402
 from clipbert_amd import synthetic as S  # noqa: E402
@@ -35,7 +34,7 @@ def _restore(bank, snap):
 
 
 def test_captured_step_equals_eager_step_and_gradients_match_the_oracle():
-    import bench_step
+    from clipbert_amd.bench import step as bench_step
     videos = 4
     st = bench_step.build(videos=videos, dropout=False)
     bank, opt = st.bank, st.opt

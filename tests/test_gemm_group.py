@@ -172,36 +172,6 @@ def test_group_more_problems_than_one_launch_holds(hw):
         torch.testing.assert_close(o.cpu(), g.float().cpu().t() @ x.float().cpu(), **tol(dt))
 
 
-@pytest.mark.parametrize("wgs", [0, 3, 7])
-def test_group_stream_k_weight_gradients(hw, monkeypatch, wgs):
-    """round 5: a group of weight gradients whose K split is free (fp32 gradient accumulated in place) runs as ONE persistent stream-K
-    launch -- every workgroup walks an equal share of the (tile, K tile) units across tile and problem boundaries and adds its partial
-    products with fp32 atomics.  Checked against fp32 references with a few workgroups (many segments each, cuts inside tiles and at the
-    K tail) and with the default grid; outputs start from ONES (accumulate semantics)."""
-    if os.environ.get("CB_GEMM_STREAMK", "0") in ("", "0"):
-        pytest.skip("stream-K is opt-in (measured slower than the split-K groups, profiles/r05n_streamk_ab.txt): run with CB_GEMM_STREAMK=1")
-    if wgs:
-        monkeypatch.setenv("CB_GEMM_STREAMK_WG", str(wgs))
-    dt = torch.bfloat16
-    lin = _wgrad_problems(hw, dt, [(1100, 136, 200), (700, 264, 136), (330, 128, 128)])          # (reduction, out rows, out cols): K tails 1100 % 64, 330 % 64
-    descs, outs = [], []
-    for g, x, m, n, k in lin:
-        o = torch.ones(n, k, device=hw.dev)
-        descs.append(ops.gemm_desc(g, x, n, k, m, out=o, a_mode=ops.KROW, b_mode=ops.KROW, accumulate=True))
-        outs.append((o, g.float().cpu().t() @ x.float().cpu() + 1.0))
-    ops.gemm_group(descs, outs[0][0])
-    conv = _conv_wgrad_problems(hw, dt, [(2, 12, 12, 32, 72, 3, 1, 1), (2, 12, 12, 72, 136, 3, 1, 1)])
-    cdescs = []
-    for pr in conv:
-        cout, kk = pr[7], pr[8] * pr[8] * pr[6]
-        o = torch.zeros(cout, kk, device=hw.dev)
-        cdescs.append(_conv_desc(pr, o, accumulate=True))
-        outs.append((o, _conv_ref(pr)))
-    ops.gemm_group(cdescs, outs[0][0])
-    for o, ref in outs:
-        torch.testing.assert_close(o.cpu(), ref, **tol(dt))
-
-
 @pytest.mark.parametrize("tile", [4, 2, 0])
 def test_group_slab_k_split_is_ordered_and_reproducible(hw, monkeypatch, tile):
     """round 5: with the K-split scratch at hand the split problems of a grouped weight-gradient launch write their partial tiles to it and

@@ -41,7 +41,7 @@ FWD = [
 def test_stream_forward_equals_tile_kernel_bitwise(hw, case, monkeypatch):
     M, N, K, res, relu = case
     if hw.name == "emul":
-        monkeypatch.setenv("CB_GEMM_STREAM_CUS", "1")          # a couple of workgroups walk many tiles: the persistent loop is exercised
+        monkeypatch.setenv("CB_PERSISTENT_MAXWG", "2")         # a couple of workgroups walk many tiles: the persistent loop is exercised
     a, w = hw(rnd(M, K, seed=1).bfloat16()), hw(rnd(N, K, seed=2, scale=0.2).bfloat16())
     scale, shift = hw(rnd(N, seed=3) * 0.1 + 1.0), hw(rnd(N, seed=4) * 0.1)
     r = hw(rnd(M, N, seed=5).bfloat16()) if res else None

@@ -233,25 +233,3 @@ def test_dropout_epilogue_is_consistent_and_unbiased(hw):
     kept = (a > 0).float().mean().item()
     assert abs(kept - 0.75) < 0.03
     torch.testing.assert_close(a[a > 0], torch.full_like(a[a > 0], 1 / 0.75))
-
-
-def _run_dma_subprocess(marker):
-    """The LDS-DMA ring kernels are opt-in (CB_GEMM_DMA=1, read once per process): re-run the forward GEMM / conv tests
-    of this file in a child process with the switch on."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, CB_GEMM_DMA="1", CB_GEMM_DMA_DEEP="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", marker, "-k",
-                        "linear_forward or conv_forward or dropout_epilogue", "-p", "no:cacheprovider"],
-                       env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-
-
-def test_dma_ring_kernels_emul():
-    _run_dma_subprocess("not gpu")
-
-
-@pytest.mark.gpu
-def test_dma_ring_kernels_gpu():
-    _run_dma_subprocess("gpu")

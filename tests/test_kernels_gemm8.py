@@ -19,19 +19,12 @@ from clipbert_amd import ops
 BF = torch.bfloat16
 TOL = dict(rtol=2e-2, atol=3e-2)
 TILES = [5, 6, 7]
-SCHEDULES = [1, 2, 3, 4]         # cb_gemm_desc.schedule: forces schedule 0 / 1 / 2 of gemm8_impl.h; 4 = the persistent kernel
+SCHEDULES = [1, 2, 3]            # cb_gemm_desc.schedule: forces schedule 0 / 1 / 2 of gemm8_impl.h
 
 
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g) * scale
-
-
-def _sched4_once(hw, sched):
-    """schedule 4 (persistent kernel) on the emulator runs only inside test_persistent_kernel_walks_several_tiles_lazy_dma's child
-    process (few workgroups walking many tiles, late-landing DMA): the single-tile-per-workgroup run adds nothing to it"""
-    if sched == 4 and hw.dev.type != "cuda" and "CB_GEMM8P_MAXWG" not in os.environ:
-        pytest.skip("covered by the multi-tile child run")
 
 
 def ws(hw, nbytes=8 << 20):
@@ -41,7 +34,6 @@ def ws(hw, nbytes=8 << 20):
 @pytest.mark.parametrize("tile", TILES)
 @pytest.mark.parametrize("sched", SCHEDULES)
 def test_linear_forward_epilogues(hw, tile, sched):
-    _sched4_once(hw, sched)
     # ragged M, N edges; 7 K tiles + a K tail (ring wraps more than twice for every NST)
     M, N, K = 300, 264, 64 * 7 + 40
     x, w, b = hw(rnd(M, K, seed=1).to(BF)), hw(rnd(N, K, seed=2, scale=0.1).to(BF)), hw(rnd(N, seed=3))
@@ -60,11 +52,10 @@ def test_linear_forward_epilogues(hw, tile, sched):
 
 
 @pytest.mark.parametrize("tile", TILES)
-@pytest.mark.parametrize("sched", [1, 3, 4])
+@pytest.mark.parametrize("sched", [1, 3])
 def test_split_k_slabs_any_epilogue(hw, tile, sched):
     """K split of the 8-wave tiles: partial products in workspace slabs, summed in index order by the reduce kernel, which also
     applies the whole epilogue (here: bias + dropout + residual into a bf16 output -- impossible with the atomics path)."""
-    _sched4_once(hw, sched)
     M, N, K = 200, 136, 64 * 5
     x, w, b = hw(rnd(M, K, seed=1).to(BF)), hw(rnd(N, K, seed=2, scale=0.1).to(BF)), hw(rnd(N, seed=3))
     res = hw(rnd(M, N, seed=4).to(BF))
@@ -95,7 +86,6 @@ def test_split_k_slabs_any_epilogue(hw, tile, sched):
 @pytest.mark.parametrize("tile", TILES)
 @pytest.mark.parametrize("sched", SCHEDULES)
 def test_dgrad_wgrad_rowsum_batched(hw, tile, sched):
-    _sched4_once(hw, sched)
     M, N, K = 264, 200, 64 * 4 + 24                      # tokens, out features, in features
     x, w, g = hw(rnd(M, K, seed=1).to(BF)), hw(rnd(N, K, seed=2, scale=0.1).to(BF)), hw(rnd(M, N, seed=3).to(BF))
     # dX = g W (W as [N][K]: reduction index outermost -> transpose-read image), GELU' fused
@@ -146,10 +136,9 @@ def _nhwc(x):
 
 
 @pytest.mark.parametrize("tile", TILES)
-@pytest.mark.parametrize("sched", [1, 3, 4])
+@pytest.mark.parametrize("sched", [1, 3])
 @pytest.mark.parametrize("k,stride,pad,H,W,Cin,Cout", [(3, 1, 1, 9, 11, 64, 136), (3, 1, 1, 6, 7, 64, 128), (1, 2, 0, 8, 6, 64, 72), (1, 1, 0, 7, 5, 128, 64)])
 def test_conv_forward_backward(hw, tile, sched, k, stride, pad, H, W, Cin, Cout):
-    _sched4_once(hw, sched)
     n = 3
     x = hw(rnd(n, Cin, H, W, seed=1).to(BF))
     w = hw(rnd(Cout, Cin, k, k, seed=2, scale=0.05).to(BF))
@@ -259,16 +248,5 @@ def test_lazy_dma_emulation():
     """Re-run the emulator cases of this file with LDS-DMA data landing as LATE as the counted waits allow."""
     env = dict(os.environ, EMUL_DMA_LAZY="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "not gpu", "-k",
-                        "not lazy_dma and not persistent", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=3000)
+                        "not lazy_dma", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=3000)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-
-
-def test_persistent_kernel_walks_several_tiles_lazy_dma():
-    """Schedule 4 with THREE workgroups for every launch (CB_GEMM8P_MAXWG=3: each walks up to a dozen tiles, K splits and batch
-    members included) and LDS-DMA data landing as late as the waits allow: the next tile's first K tiles are requested before the
-    current tile's epilogue -- a stage re-filled too early or a fragment read before its counted wait fails here."""
-    env = dict(os.environ, EMUL_DMA_LAZY="1", CB_GEMM8P_MAXWG="3")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "not gpu", "-k",
-                        "emul and 4 and not lazy_dma and not persistent", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=3000)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "no tests ran" not in r.stdout, r.stdout[-500:]

@@ -56,7 +56,7 @@ def _krsc(w):
 @pytest.mark.parametrize("n,h,w,maxwg", [(2, 16, 16, 0), (1, 12, 20, 0), (3, 16, 8, 2), (1, 9, 7, 0)])
 def test_res2_block_equals_the_block_op_by_op(hw, monkeypatch, cin, n, h, w, maxwg):
     if maxwg:
-        monkeypatch.setenv("CB_RES2_MAXWG", str(maxwg))  # persistent loop: each workgroup walks several tiles
+        monkeypatch.setenv("CB_PERSISTENT_MAXWG", str(maxwg))  # persistent loop: each workgroup walks several tiles
     w1, w2, w3, wsc, ss1, ss2, ss3, sssc = _make(cin, 3 + cin)
     x = (torch.randn(n, h, w, cin, generator=_gen(7)) * 1.5).to(torch.bfloat16)
     if cin == 256:
@@ -102,7 +102,7 @@ def test_stem_pool_equals_conv_then_pool(hw, monkeypatch, n, h, w, maxwg):
     """cb_stem_pool against the two launches it replaces (cb_gemm in its stem form + cb_maxpool_fwd) on the same packed image, and
     against conv2d + max_pool2d in fp32 PyTorch with the convolution output rounded to bf16 where the unfused path stores it"""
     if maxwg:
-        monkeypatch.setenv("CB_STEM_MAXWG", str(maxwg))
+        monkeypatch.setenv("CB_PERSISTENT_MAXWG", str(maxwg))
     from clipbert_amd import modeling as M
     g = _gen(21)
     frames = torch.randint(0, 256, (n, 3, h, w), generator=g, dtype=torch.uint8)

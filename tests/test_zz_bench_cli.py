@@ -34,7 +34,7 @@ def test_supervisor_retries_with_the_next_plan_and_honours_the_done_marker(monke
     sys.path.insert(0, ROOT)
     import bench
     monkeypatch.setenv("TMPDIR", str(tmp_path))
-    import bench_launch                                   # (the supervisor lives in tools/bench_launch.py since round 5; bench re-exports it)
+    from clipbert_amd.bench import launch as bench_launch                                   # (the supervisor lives in clipbert_amd/bench/launch.py since round 5; bench re-exports it)
     monkeypatch.setattr(bench_launch, "ATTEMPT_TIMEOUT_S", 3.0)
     log = tmp_path / "log.txt"
 

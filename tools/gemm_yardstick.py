@@ -114,7 +114,7 @@ def conv_rows(nframes=64):
     """MIOpen (NHWC bf16, immediate mode) forward / input gradient / weight gradient next to the product's launches of the same
     convolutions (clipbert_amd.modeling._conv_fwd / _conv_dgrad / _conv_wgrad: FrozenBN scale + shift in the forward epilogue, which
     the library call does not do)"""
-    import bench_step
+    from clipbert_amd.bench import step as bench_step
     from clipbert_amd import modeling as Mo
     st = bench_step.build(videos=2)
     model, rt = st.model, st.model.rt

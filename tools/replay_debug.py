@@ -13,7 +13,7 @@ def main():
     ap.add_argument("--prezero", type=int, default=0)
     ap.add_argument("--replays", type=int, default=4)
     a = ap.parse_args()
-    import bench_step
+    from clipbert_amd.bench import step as bench_step
     st = bench_step.build(videos=a.videos, dropout=False)
     bank, opt = st.bank, st.opt
     init = dict(master=bank.master.clone(), m=bank.exp_avg.clone(), v=bank.exp_avg_sq.clone(), w16=bank.w16.clone())

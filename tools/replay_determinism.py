@@ -31,7 +31,7 @@ def main():
     if a.lib:
         from clipbert_amd.build import variant_path
         _lib._LIB = _lib.load(variant_path(a.lib))
-    import bench_step
+    from clipbert_amd.bench import step as bench_step
     st = bench_step.build(videos=a.videos, dropout=bool(a.dropout))
     bank, opt = st.bank, st.opt
     init = dict(master=bank.master.clone(), m=bank.exp_avg.clone(), v=bank.exp_avg_sq.clone(), w16=bank.w16.clone())

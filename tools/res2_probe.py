@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 from gemm_yardstick import hot_cold
 
 def main():
-    import bench_step
+    from clipbert_amd.bench import step as bench_step
     from clipbert_amd import modeling as M
     st = bench_step.build(videos=2)
     rt = st.model.rt

@@ -44,7 +44,7 @@ def main():
     lib.cb_debug_stamps_area_words.restype = C.c_int64
     lib.cb_debug_stamps_count.restype = C.c_int64
     lib.cb_debug_stamps_desc.argtypes = [C.c_int64, C.c_char_p, C.c_int64]
-    import bench_step
+    from clipbert_amd.bench import step as bench_step
     st = bench_step.build(videos=a.videos)
     dev = st.dev
     words = int(lib.cb_debug_stamps_area_words())

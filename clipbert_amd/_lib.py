@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("xcd_order", i32), ("a_bytes", i64), ("b_bytes", i64), ("gelu_grad_pre", vp), ("ld_gelu", i64), ("a_rowsum", vp),
         ("batch", i32), ("relu_bwd", i32), ("batch_stride_a", i64), ("batch_stride_b", i64), ("batch_stride_c", i64),
         ("batch_stride_rowsum", i64), ("post_scale", vp), ("post_scale2", vp), ("splitk_ws", vp), ("splitk_ws_bytes", i64),
+        ("sq_slots", vp), ("sq_slots_n", i64),
     ]
 
 
@@ -72,6 +73,7 @@ _SIGNATURES = {
     "cb_text_embed_bwd": [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i32, vp],
     "cb_head_loss": [i32, vp, vp, vp, vp, vp, i64, i32, f32, vp],
     "cb_retrieval_scores": [vp, vp, i64, i32, vp],
+    "cb_sq_sum_fold": [vp, vp, i32, vp, i64, vp, vp, i32, vp],
     "cb_mean_fwd": [vp, i64, vp, vp],
     "cb_mean_bwd": [vp, i64, vp, vp],
     "cb_counter_add": [vp, i64, vp],

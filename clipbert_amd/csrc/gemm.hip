@@ -290,7 +290,8 @@ int gemm_prepare(const cb_gemm_desc* d, Prepared& out) {
     p.M = d->M; p.N = d->N; p.K = d->K;
     p.a_mode = d->a_mode; p.b_mode = d->b_mode;
     p.R = d->R > 0 ? d->R : 1; p.S = d->S > 0 ? d->S : 1; p.Ct = d->Cin; p.H = d->H; p.W = d->W; p.flip = d->flip_taps;
-    p.c_f32 = d->c_f32; p.accumulate = d->accumulate; p.split_k = d->split_k > 0 ? d->split_k : 1;
+    CB_REQUIRE(d->accumulate >= 0 && d->accumulate <= 2 && (d->accumulate != 2 || d->dtype == CB_BF16), "cb_gemm: bad accumulate %d (2 = first writer: bf16 problems)", d->accumulate);
+    p.c_f32 = d->c_f32; p.accumulate = d->accumulate == 1; p.split_k = d->split_k > 0 ? d->split_k : 1;
     p.act = d->act; p.relu_after = d->relu_after;
     p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
     p.dropout_p = d->dropout_p; p.seed = d->dropout_seed; p.seed_ptr = d->dropout_seed_ptr;
@@ -308,7 +309,19 @@ int gemm_prepare(const cb_gemm_desc* d, Prepared& out) {
         static const bool fe_off = getenv("CB_GEMM_FAST_EPI") != nullptr && atoi(getenv("CB_GEMM_FAST_EPI")) == 0;
         p.fast_epi = 0;
         auto rows_ok = [&](const void* q, int64_t ld) { return q == nullptr || (ld % 8 == 0 && aligned16(q) && (int64_t)d->M * ld * 2 < 0x7fffffffll); };
-        const bool plain = !fe_off && p.wt == 1 && p.batch == 1 && !d->accumulate && p.alpha == 1.f && !d->zero_fill_pitch && !d->a_rowsum &&
+        // weight-gradient forms that STORE an fp32 C (first writer): the lean fp32 epilogue, which also leaves the tile's share of the squared norm
+        const bool wg_store = !fe_off && d->dtype == CB_BF16 && d->c_f32 && d->a_mode == CB_KROW && d->accumulate != 1 && p.alpha == 1.f && !d->scale && !d->shift &&
+                              d->act == CB_ACT_NONE && !d->C2 && !d->residual && !d->mask && !d->gelu_grad_pre && d->dropout_p <= 0.f && !d->relu_after && !d->c_rowmap &&
+                              !d->zero_fill_pitch && !d->relu_bwd && d->N % 8 == 0 && d->ldc % 8 == 0 && aligned16(d->C) && (int64_t)d->M * d->ldc * 4 < 0xffffffffll;
+        if (wg_store) p.fast_epi = FAST_EPI_F32;
+        p.sq_slots = nullptr;
+        if (d->sq_slots) {
+            const int64_t need = (int64_t)((d->M + 63) / 64) * ((d->N + 63) / 64) * p.batch;
+            CB_REQUIRE(wg_store, "cb_gemm: sq_slots needs a bf16 weight-gradient form storing an aligned fp32 C with a plain epilogue (accumulate 0 / 2)");
+            CB_REQUIRE(d->sq_slots_n >= need, "cb_gemm: sq_slots_n %lld < %lld (one slot per 64x64 tile and batch member)", (long long)d->sq_slots_n, (long long)need);
+            p.sq_slots = d->sq_slots;
+        }
+        const bool plain = !wg_store && !fe_off && p.wt == 1 && p.batch == 1 && d->accumulate != 1 && p.alpha == 1.f && !d->zero_fill_pitch && !d->a_rowsum &&
                            d->N % 8 == 0 && d->ldc % 8 == 0 && aligned16(d->C) && (!d->shift || aligned16(d->shift)) && (!d->scale || aligned16(d->scale)) &&
                            rows_ok(d->residual, d->ldr) && rows_ok(d->mask, d->ldm) && rows_ok(d->gelu_grad_pre, d->ld_gelu) &&
                            !(d->mask && d->gelu_grad_pre);
@@ -454,7 +467,8 @@ int gemm_run(const cb_gemm_desc* d, void* stream, int32_t* plan, bool use_table)
     float* ws8 = nullptr;
     if (tile >= 5 && form8 == 0) { tile = 0; split_tuned = sched_tuned = 0; }      // not covered: the 4-wave kernels decide
     // the 4-wave kernels may choose their own K split where the result is accumulated in place through atomics (weight-gradient form)
-    const bool free_split = d->tile == 0 && d->a_mode == CB_KROW && d->c_f32 && d->accumulate && !d->C2 && !d->residual && !d->mask && !d->gelu_grad_pre &&
+    const bool no_atomics = d->accumulate == 2 || d->sq_slots != nullptr;      // first writer / norm share: partial sums only through slabs
+    const bool free_split = d->tile == 0 && d->a_mode == CB_KROW && d->c_f32 && d->accumulate == 1 && !d->sq_slots && !d->C2 && !d->residual && !d->mask && !d->gelu_grad_pre &&
                             d->act == CB_ACT_NONE && !d->relu_after && !d->shift && d->dropout_p <= 0.f;
     const bool ws_usable = d->splitk_ws && aligned16(d->splitk_ws);
     static const bool no_model = getenv("CB_GEMM_NO_MODEL") != nullptr;       // diagnostic: 64x64 tiles for everything outside the table
@@ -466,6 +480,10 @@ int gemm_run(const cb_gemm_desc* d, void* stream, int32_t* plan, bool use_table)
         sched_tuned = mp.sched;
     };
     if (tile == 0) ask_model(true);
+    if (tile >= 5 && d->sq_slots && (d->tile == 0 ? split_tuned : split_caller) > 1) {        // (the slab reduce kernel leaves no norm share)
+        tile = 0; split_tuned = sched_tuned = 0;
+        ask_model(false);
+    }
     if (tile >= 5) {
         int split = d->tile == 0 ? (split_tuned > 0 ? split_tuned : 1) : split_caller;       // (table / model: its own split)
         if (split > p.ktiles) split = p.ktiles;
@@ -510,15 +528,16 @@ int gemm_run(const cb_gemm_desc* d, void* stream, int32_t* plan, bool use_table)
     p.split_k = split_caller;
     {   // a split asked for WITH an 8-wave tile means "through slabs": if this problem ended up here (shape not covered, no workspace) the
         // split only survives where the atomics path can take it (fp32 C accumulated in place, scale/alpha-only epilogue)
-        const bool atomics_ok = d->c_f32 && d->accumulate && !d->C2 && !d->residual && !d->mask && !d->gelu_grad_pre && d->act == CB_ACT_NONE &&
+        const bool atomics_ok = d->c_f32 && d->accumulate == 1 && !d->C2 && !d->residual && !d->mask && !d->gelu_grad_pre && d->act == CB_ACT_NONE &&
                                 !d->relu_after && !d->shift && d->dropout_p <= 0.f;
         if (d->tile >= 5 && p.split_k > 1 && !atomics_ok) p.split_k = 1;
     }
-    if (split_tuned > 0 && d->tile == 0 && d->a_mode == CB_KROW && d->c_f32 && d->accumulate && !d->C2 && !d->residual &&
+    if (no_atomics) p.split_k = 1;                                 // (a caller's split means atomics here)
+    if (split_tuned > 0 && d->tile == 0 && d->a_mode == CB_KROW && d->c_f32 && d->accumulate == 1 && !d->sq_slots && !d->C2 && !d->residual &&
         !d->mask && !d->gelu_grad_pre && d->act == CB_ACT_NONE && !d->relu_after && !d->shift && d->dropout_p <= 0.f)
         p.split_k = split_tuned;       // weight-gradient form (plain epilogue, fp32 C accumulated in place: any K split is valid): the measured best
     if (p.split_k > 1) {
-        CB_REQUIRE(d->c_f32, "cb_gemm: split_k > 1 needs an fp32 output");
+        CB_REQUIRE(d->c_f32 && d->accumulate == 1, "cb_gemm: split_k > 1 needs an fp32 output that is accumulated into (accumulate = 1)");
         CB_REQUIRE(!d->C2 && !d->residual && !d->mask && !d->gelu_grad_pre && d->act == CB_ACT_NONE && !d->relu_after && !d->shift && d->dropout_p <= 0.f,
                    "cb_gemm: split_k > 1 supports only scale/alpha in the epilogue");
         if (p.split_k > p.ktiles) p.split_k = p.ktiles;
@@ -673,6 +692,9 @@ int launch_group_chunk(std::vector<GroupItem*>& g, int dtype, int cls, hipStream
             if (slab_cnt) slab_ws = reinterpret_cast<float*>(first->splitk_ws);
         }
     }
+    if (!slab_ws)                                                   // first writers / norm shares never combine through atomics: unsplit without a scratch
+        for (size_t i = 0; i < g.size(); ++i)
+            if (g[i]->d->accumulate == 2 || g[i]->d->sq_slots) splits[i] = 1;
     ga.slab = slab_ws;
     ga.cnt = slab_ws ? slab_cnt : nullptr;
     int64_t slab_units = 0;
@@ -684,7 +706,7 @@ int launch_group_chunk(std::vector<GroupItem*>& g, int dtype, int cls, hipStream
         GP p = g[i]->pr.p;
         p.split_k = splits[i] > p.ktiles ? (p.ktiles > 0 ? p.ktiles : 1) : splits[i];
         if (p.split_k > 1) {
-            CB_REQUIRE(d->c_f32, "cb_gemm_group: split_k > 1 needs an fp32 output");
+            CB_REQUIRE(d->c_f32 && (d->accumulate == 1 || slab_ws), "cb_gemm_group: split_k > 1 needs an fp32 output accumulated into, or the slab scratch");
             CB_REQUIRE(!d->C2 && !d->residual && !d->mask && !d->gelu_grad_pre && d->act == CB_ACT_NONE && !d->relu_after && !d->shift && d->dropout_p <= 0.f,
                        "cb_gemm_group: split_k > 1 supports only scale/alpha in the epilogue");
         }

@@ -35,14 +35,15 @@ struct GP {
     float alpha, dropout_p;
     uint64_t seed;
     const uint64_t* seed_ptr;
-    int c_vec, c_vec8;
-    int zfill;                 // zero_fill_pitch (see the header)
-    int xcd_remap;              // 1: remap workgroup ids so that each XCD (own L2) owns a contiguous chunk of tiles
+    short c_vec, c_vec8;        // (shorts: ten of these structs travel in the 4 KiB argument block of a grouped launch)
+    short xcd_remap;            // 1: remap workgroup ids so that each XCD (own L2) owns a contiguous chunk of tiles
+    short wt;                   // 1: the row-contiguous epilogue's bf16 C / C2 stores are write-through (sc1), see store8_wt
+    int zfill;                  // zero_fill_pitch (see the header)
     uint32_t a_bytes, b_bytes;
     int ktiles;
-    int wt;                     // 1: the row-contiguous epilogue's bf16 C / C2 stores are write-through (sc1), see store8_wt
     int slab_base, cnt_base;    // grouped launch with slab K split (gemm_tile): this problem's first slab unit / first tile counter
     int fast_epi;               // index into FAST_EPI_COMBOS: the specialised epilogue of this call (fast_epilogue), 0: the generic epilogue8
+    float* sq_slots;            // cb_gemm_desc.sq_slots (this problem's first slot): output tile t stores the sum of the squares of its C to sq_slots[t]
 #ifdef CB_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/stamps_*.py): this launch's record area, or null
 #endif
@@ -56,7 +57,8 @@ struct GP {
 // (GP::fast_epi, 0 = none: generic path); bf16 row-contiguous epilogues only, alpha 1, no row map / zero fill / accumulate / relu_bwd.
 enum { EF_SCALE = 1, EF_SHIFT = 2, EF_RELU = 4, EF_GELU2 = 8, EF_DROP = 16, EF_RES = 32, EF_RELU_AFTER = 64, EF_MASK = 128, EF_MULAUX = 256,
        EF_RBWD = 512,      // cb_gemm_desc.relu_bwd: t = (acc [+ residual]) where mask > 0; C2 = t [* post_scale2]; C = t * post_scale
-       EF_PS2 = 1024 };
+       EF_PS2 = 1024,
+       EF_F32 = 2048 };    // fp32 C STORED (accumulate 0 / 2), nothing else: the weight-gradient forms; + the tile's share of the squared norm
 constexpr int FAST_EPI_COMBOS[] = {
     -1,                                                  // 0: generic
     0,                                                   // 1: C = acc                                  (data gradients without epilogue, grid conv)
@@ -74,7 +76,9 @@ constexpr int FAST_EPI_COMBOS[] = {
     EF_RBWD | EF_RES,                                    //        (identity shortcut: + its gradient)
     EF_RBWD | EF_PS2,                                    //        (projection shortcut: second output x its FrozenBN scale)
     EF_RBWD | EF_PS2 | EF_RES,
+    EF_F32,                                              // 16: dW stored by its first writer (+ sum of squares to GP::sq_slots) -- weight-gradient kernels only
 };
+constexpr int FAST_EPI_F32 = 16;
 constexpr int FAST_EPI_N = sizeof(FAST_EPI_COMBOS) / sizeof(int);
 
 // ---------------------------------------------------------------------------------------------
@@ -1077,7 +1081,7 @@ __device__ __forceinline__ void unpack_bf16x8(u32x4 raw, f32x2 (&v)[4]) {
 // the slot order h * ITER + it; null: requested here.
 template <int FLAGS, int NT, int BN, int PR, int NPASS, typename StageFn>
 __device__ __forceinline__ void fast_epilogue(const GP& p, unsigned char* smem, int m0, int n0, int tid, StageFn stage, const bf16x8* pre_r = nullptr,
-                                              const bf16x8* pre_a = nullptr) {
+                                              const bf16x8* pre_a = nullptr, int tile_lin = 0) {
     constexpr int SROW = BN * 4 + 16, CPR = BN / 8, ITER = PR * CPR / NT, RSTEP = NT / CPR, NCH = NPASS * ITER;
     static_assert(PR * CPR % NT == 0 && NT % CPR == 0, "chunk map");
     constexpr bool HAS_RES = (FLAGS & EF_RES) != 0, HAS_AUX = (FLAGS & (EF_MASK | EF_MULAUX | EF_RBWD)) != 0;
@@ -1088,7 +1092,9 @@ __device__ __forceinline__ void fast_epilogue(const GP& p, unsigned char* smem, 
     const unsigned char* const read_base = smem + rl0 * SROW + cc * 32;
     const rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, (short)0, (int)0xffffffffu, 0x00020000);
     const rsrc_t rc2 = __builtin_amdgcn_make_buffer_rsrc((FLAGS & (EF_GELU2 | EF_RBWD)) ? p.C2 : p.C, (short)0, (int)0xffffffffu, 0x00020000);
-    const uint32_t ldcb = (uint32_t)p.ldc * 2u, ldc2b = (uint32_t)p.ldc2 * 2u, nb = (uint32_t)n * 2u;
+    constexpr uint32_t CESZ = (FLAGS & EF_F32) ? 4u : 2u;         // bytes per element of C
+    const uint32_t ldcb = (uint32_t)p.ldc * CESZ, ldc2b = (uint32_t)p.ldc2 * 2u, nb = (uint32_t)n * 2u;
+    float sq = 0.f;                                              // EF_F32: this thread's share of sum(C^2)
     // operands are read through range-checked descriptors: rows past M (and chunks past N) take the out-of-range offset and read zeros
     const rsrc_t rr = make_rsrc(HAS_RES ? p.residual : p.C, HAS_RES ? (uint32_t)((int64_t)p.M * p.ldr * 2) : 0u);
     const void* auxp = (FLAGS & (EF_MASK | EF_RBWD)) ? p.mask : p.dact_pre;
@@ -1138,6 +1144,15 @@ __device__ __forceinline__ void fast_epilogue(const GP& p, unsigned char* smem, 
         if (!(m < p.M && nok)) return;
         const f32x4 a = *reinterpret_cast<const f32x4*>(read_base + it * RSTEP * SROW);
         const f32x4 b = *reinterpret_cast<const f32x4*>(read_base + it * RSTEP * SROW + 16);
+        if constexpr ((FLAGS & EF_F32) != 0) {
+            union { f32x4 f; u32x4 r; } ua, ub;
+            ua.f = a; ub.f = b;
+            const uint32_t off = (uint32_t)m * ldcb + (uint32_t)n * 4u;
+            __builtin_amdgcn_raw_buffer_store_b128(ua.r, rc, off, 0, 16 /* sc1 */);
+            __builtin_amdgcn_raw_buffer_store_b128(ub.r, rc, off + 16u, 0, 16 /* sc1 */);
+            sq += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]) + (b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]);
+            return;
+        }
         f32x2 v[4] = {f32x2{a[0], a[1]}, f32x2{a[2], a[3]}, f32x2{b[0], b[1]}, f32x2{b[2], b[3]}};
         if constexpr ((FLAGS & EF_RBWD) != 0) {
             f32x2 t[4];
@@ -1228,12 +1243,33 @@ __device__ __forceinline__ void fast_epilogue(const GP& p, unsigned char* smem, 
 #pragma unroll
         for (int h = 0; h < NPASS; ++h) pass(h);
     }
+    if constexpr ((FLAGS & EF_F32) != 0) {
+        if (p.sq_slots) {                                        // (block-uniform) waves added in wave order: a fixed order
+            sq = wave_sum(sq);
+            __syncthreads();                                     // the staging area is free again
+            float* red = reinterpret_cast<float*>(smem);
+            if ((tid & 63) == 0) red[tid >> 6] = sq;
+            __syncthreads();
+            if (tid == 0) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < NT / 64; ++w) t += red[w];
+                p.sq_slots[tile_lin] = t;
+            }
+        }
+    }
 }
 
 // runtime index -> compile-time combination (a wave-uniform switch: the kernel argument lives in SGPRs)
-template <int NT, int BN, int PR, int NPASS, typename StageFn>
+// WG: a weight-gradient kernel (both operands reduction-major): the only combination it ever meets is the stored fp32 C; the other forms
+// never meet that one -- neither instantiates what it cannot run.
+template <int NT, int BN, int PR, int NPASS, bool WG = false, typename StageFn>
 __device__ __forceinline__ void fast_epilogue_dispatch(const GP& p, unsigned char* smem, int m0, int n0, int tid, StageFn stage,
-                                                       const bf16x8* pre_r = nullptr, const bf16x8* pre_a = nullptr) {
+                                                       const bf16x8* pre_r = nullptr, const bf16x8* pre_a = nullptr, int tile_lin = 0) {
+    if constexpr (WG) {
+        fast_epilogue<EF_F32, NT, BN, PR, NPASS>(p, smem, m0, n0, tid, stage, nullptr, nullptr, tile_lin);
+        return;
+    }
     switch (p.fast_epi) {
 #define CB_FE_CASE(I) case I: fast_epilogue<FAST_EPI_COMBOS[I], NT, BN, PR, NPASS>(p, smem, m0, n0, tid, stage, pre_r, pre_a); break;
         CB_FE_CASE(1) CB_FE_CASE(2) CB_FE_CASE(3) CB_FE_CASE(4) CB_FE_CASE(5) CB_FE_CASE(6) CB_FE_CASE(7) CB_FE_CASE(8) CB_FE_CASE(9) CB_FE_CASE(10)
@@ -1242,7 +1278,7 @@ __device__ __forceinline__ void fast_epilogue_dispatch(const GP& p, unsigned cha
         default: break;
     }
 }
-static_assert(FAST_EPI_N == 16, "fast_epilogue_dispatch lists every combination");
+static_assert(FAST_EPI_N == 17 && FAST_EPI_COMBOS[FAST_EPI_F32] == EF_F32, "fast_epilogue_dispatch lists every combination");
 
 // ---------------------------------------------------------------------------------------------
 // Epilogue-operand prefetch (row-contiguous bf16 epilogue only).  The epilogue's global READS -- the residual and the ReLU mask
@@ -1286,16 +1322,16 @@ __device__ __forceinline__ void epi_prefetch(const GP& p, EpiPre<BM, BN, WITH_R>
 // ---------------------------------------------------------------------------------------------
 // Tile epilogue shared by both kernel structures.  acc[i][j] = 4 consecutive n of row m (swapped MFMA operands).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int SMEM_BYTES, int EPF = 0, bool FAST = true>
+template <typename T, int BM, int BN, int SMEM_BYTES, int EPF = 0, bool WG = false>
 __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 32], unsigned char* smem, int m0, int n0, int tid,
-                                              const EpiPre<BM, BN, EPF != 1>& pre = EpiPre<BM, BN, EPF != 1>{}, bool use_pre = false) {
+                                              const EpiPre<BM, BN, EPF != 1>& pre = EpiPre<BM, BN, EPF != 1>{}, bool use_pre = false, int tile_lin = 0) {
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     if (p.dropout_p > 0.f && p.seed_ptr) p.seed += *p.seed_ptr;
     const bool fast = p.c_vec && (n0 + BN <= p.N);      // block-uniform
-    if constexpr (sizeof(T) == 2 && FAST) {                   // (FAST off: weight-gradient forms -- fp32 output, never a listed combination)
-        if (p.c_vec8 && p.fast_epi != 0) {                    // specialised body for this call's option combination (block-uniform)
+    if constexpr (sizeof(T) == 2) {
+        if (p.c_vec8 && p.fast_epi != 0 && (WG == (p.fast_epi == FAST_EPI_F32))) {                    // specialised body for this call's option combination (block-uniform)
             static_assert((BM / 2) * (BN * 4 + 16) <= SMEM_BYTES, "staging does not fit");
             auto stage = [&](int h) __attribute__((always_inline)) {
                 if (wm == h) {
@@ -1310,7 +1346,7 @@ __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 
             const bf16x8* pre_a = nullptr;
             if constexpr (EPF == 2) { if (use_pre) pre_r = pre.r; }
             if constexpr (EPF != 0) { if (use_pre) pre_a = pre.a; }
-            fast_epilogue_dispatch<NTHREADS, BN, BM / 2, 2>(p, smem, m0, n0, tid, stage, pre_r, pre_a);
+            fast_epilogue_dispatch<NTHREADS, BN, BM / 2, 2, WG>(p, smem, m0, n0, tid, stage, pre_r, pre_a, tile_lin);
             return;
         }
     }
@@ -1467,6 +1503,8 @@ __device__ __forceinline__ void gemm_tile(GP& p, TileId bid, float* slab = nullp
 #ifdef CB_STAMPS
     const unsigned stamp_lin = (unsigned)bid.bx + (unsigned)((p.N + BN - 1) / BN) * ((unsigned)bid.by + (unsigned)((p.M + BM - 1) / BM) * (unsigned)bid.bz);
 #endif
+    // index of this output tile among the problem's tiles (batch member outermost; K parts of one tile share it): GP::sq_slots
+    const int tile_lin = ((p.batch > 1 ? bid.bz / p.split_k : 0) * ((p.M + BM - 1) / BM) + bid.by) * ((p.N + BN - 1) / BN) + bid.bx;
     apply_batch(p, bid);
     const int m0 = bid.by * BM, n0 = bid.bx * BN;
     const int kt_per = (p.ktiles + p.split_k - 1) / p.split_k;
@@ -1687,7 +1725,7 @@ __device__ __forceinline__ void gemm_tile(GP& p, TileId bid, float* slab = nullp
         p.split_k = 1;                                                      // the epilogue below is the plain one
     }
     if constexpr (EPF != 0) tile_epilogue<T, BM, BN, SMEM_BYTES, EPF>(p, acc, smem, m0, n0, tid, epre, epf_on);
-    else tile_epilogue<T, BM, BN, SMEM_BYTES, 0, !LA::KROW>(p, acc, smem, m0, n0, tid);
+    else tile_epilogue<T, BM, BN, SMEM_BYTES, 0, LA::KROW>(p, acc, smem, m0, n0, tid, EpiPre<BM, BN, true>{}, false, tile_lin);
     CB_STAMP(3);
     CB_STAMP_FLUSH(p, stamp_lin, tid);
 }

@@ -57,6 +57,47 @@ __global__ void __launch_bounds__(256) sq_sum_final_kernel(const float* partial,
     if (threadIdx.x == 0) out[0] += (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// cb_sq_sum_fold: up to four ranges of g as ONE index space (block b strides over it exactly as sq_sum_partial_kernel does), then the
+// partials and the per-tile shares the weight-gradient launches left in `slots`, added in index order by one block.
+struct SqSegs { int64_t lo[4], len[4]; int n; };
+__global__ void __launch_bounds__(256) sq_sum_segs_kernel(const float* g, SqSegs sg, float* partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+#pragma unroll 1
+    for (int k = 0; k < sg.n; ++k) {
+        const float* q = g + sg.lo[k];
+        const int64_t n = sg.len[k];
+        for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+            if (i + 3 < n && ((sg.lo[k] & 3) == 0)) {
+                f32x4 v = load4(q + i);
+                s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            } else {
+                for (int64_t j = i; j < n && j < i + 4; ++j) s += q[j] * q[j];
+            }
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void __launch_bounds__(1024) sum_two_final_kernel(const float* a, int na, const float* b, int64_t nb, float* out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < na; i += 1024) s += a[i];
+    for (int64_t i = threadIdx.x; i < nb; i += 1024) s += b[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w];
+        out[0] += t;
+    }
+}
+
 struct PMV { float p, m, v; };
 __device__ __forceinline__ PMV adamw_one(float p, float g, float m, float v, float gs, float b1, float b2, float eps,
                                          float step_size, float decay) {
@@ -142,6 +183,28 @@ extern "C" int cb_sq_sum_det(const float* g, int64_t n, float* out_accum, float*
     hipLaunchKernelGGL(sq_sum_partial_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, cb_stream(stream), g, n, ws);
     hipLaunchKernelGGL(sq_sum_final_kernel, dim3(1), dim3(256), 0, cb_stream(stream), ws, (int)blocks, out_accum);
     return cb_launch_status("cb_sq_sum_det");
+}
+
+extern "C" int cb_sq_sum_fold(const float* g, const int64_t* seg_lo_hi, int32_t nseg, const float* slots, int64_t nslots, float* out_accum, float* ws,
+                              int32_t ws_floats, void* stream) {
+    CB_REQUIRE(out_accum && ws && ws_floats >= 1 && nseg >= 0 && nseg <= 4 && (nseg == 0 || (g && seg_lo_hi)) && nslots >= 0 && (nslots == 0 || slots),
+               "cb_sq_sum_fold: bad arguments");
+    SqSegs sg{};
+    int64_t total = 0;
+    for (int i = 0; i < nseg; ++i) {
+        CB_REQUIRE(seg_lo_hi[2 * i] >= 0 && seg_lo_hi[2 * i + 1] >= seg_lo_hi[2 * i], "cb_sq_sum_fold: bad segment %d", i);
+        if (seg_lo_hi[2 * i + 1] == seg_lo_hi[2 * i]) continue;
+        sg.lo[sg.n] = seg_lo_hi[2 * i];
+        sg.len[sg.n] = seg_lo_hi[2 * i + 1] - seg_lo_hi[2 * i];
+        total = sg.len[sg.n] > total ? sg.len[sg.n] : total;
+        ++sg.n;
+    }
+    int64_t blocks = (total + 1023) / 1024;
+    if (blocks > ws_floats) blocks = ws_floats;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks > 0) hipLaunchKernelGGL(sq_sum_segs_kernel, dim3((unsigned)blocks), dim3(256), 0, cb_stream(stream), g, sg, ws);
+    hipLaunchKernelGGL(sum_two_final_kernel, dim3(1), dim3(1024), 0, cb_stream(stream), ws, (int)blocks, slots, nslots, out_accum);
+    return cb_launch_status("cb_sq_sum_fold");
 }
 
 // bf16 gradients (the data-parallel wire image after the all-reduce): the optimizer consumes them directly, no cast back to fp32

@@ -207,6 +207,10 @@ class GradSync:
         # loopback (single process, one GPU): the complete N-rank plan with REAL collectives on a world-size-1 communicator of the
         # library -- every cb_allreduce_bucket is issued (and can be captured into a hipGraph) although it adds nothing
         self.loopback = bool(loopback) and self.world == 1 and not self.dry
+        if self.world > 1 or self.loopback or self.dry:
+            # the gradient norm of a data-parallel step is the norm of the EXCHANGED gradients: the per-launch shares of the local ones
+            # (ParamBank.enable_norm_fold) say nothing about it -- FusedAdamW.launch runs its pass over the reduced gradients
+            bank.norm_fold_blocked = True
         t_end = bank.group_range[3][1]
         self.t_range = (0, t_end)
         self.c_range = (t_end, bank.n_train)

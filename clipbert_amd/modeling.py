@@ -343,17 +343,29 @@ def _conv_wgrad(rt: Runtime, g, x, conv, pending=None):
     m = n * oh * ow
     kk = k * k * cin
     split, tile = _pick_split(cout, kk, m)
+    # first writer of this step (ParamBank.set_fresh_params: the range was not zeroed): the launch STORES (no read-modify-write of the
+    # gradient) and leaves its share of the squared norm; a second backward of the step accumulates as before and voids the shares
+    bank = rt.bank
+    acc, slots = True, None
+    if bank.take_fresh_param(conv.weight):
+        if rt.dtype == torch.bfloat16 and kk % 8 == 0:
+            acc = 2
+            slots = bank.fold_take(ops.sq_slot_count(cout, kk), "cnn")
+        else:
+            ops.zero_(gw)                            # (a form the first-writer store does not cover: zero now, accumulate as ever)
+    else:
+        bank.fold_invalidate()
     # (descriptors that will be LAUNCHED on the side stream carry its scratch, whichever stream describes them)
     side_ws = rt.side_ws if (pending is not None and rt.overlap & 2) else None
     run = ops.gemm if pending is None else (lambda *a, **kw: pending.append(ops.gemm_desc(*a, splitk_ws=side_ws, **kw)))
     if k == 1 and s == 1:
         run(g.view(m, cout), x.view(m, cin), cout, cin, m, out=gw.view(cout, kk), a_mode=KROW, lda=cout,
-            b_mode=KROW, ldb=cin, accumulate=True, split_k=split, tile=tile)
+            b_mode=KROW, ldb=cin, accumulate=acc, split_k=split, tile=tile, sq_slots=slots)
     else:
         tab = rt.table(n, oh, ow, s, p, h * w * cin, w * cin, cin, x.device)
         run(g.view(m, cout), x, cout, kk, m, out=gw.view(cout, kk), a_mode=KROW, lda=cout, b_mode=KROW_GATHER,
-            b_tab=tab, ldb=0, R=k, S=k, Cin=cin, H=h, W=w, sH=w * cin, sW=cin, accumulate=True, split_k=split,
-            tile=tile)
+            b_tab=tab, ldb=0, R=k, S=k, Cin=cin, H=h, W=w, sH=w * cin, sW=cin, accumulate=acc, split_k=split,
+            tile=tile, sq_slots=slots)
 
 
 def _stem_weight(rt: Runtime, conv: Conv2d):
@@ -840,26 +852,29 @@ def _encoder_wgrads(model, pk, gs, M):
         return bank.grad_span(l.attention.self.query.bias, l.attention.self.value.bias, (3 * d,)) \
             if bank.is_trainable(l.attention.self.query.bias) else None
 
-    kinds = [  # (upstream gradient stack, input stack, out features, in features, dW images, db images)
-        (gs.out, stk.hact, d, ff, [bank.grad_image(l.output.dense.weight) for l in layers], [bank.grad_image(l.output.dense.bias) for l in layers]),
-        (gs.hp, stk.a, ff, d, [bank.grad_image(l.intermediate.dense.weight) for l in layers], [bank.grad_image(l.intermediate.dense.bias) for l in layers]),
-        (gs.att, stk.ctx, d, d, [bank.grad_image(l.attention.output.dense.weight) for l in layers], [bank.grad_image(l.attention.output.dense.bias) for l in layers]),
-        (gs.qkv, stk.x, 3 * d, d, [qkv_w(l) for l in layers], [qkv_b(l) for l in layers]),
+    kinds = [  # (upstream gradient stack, input stack, out features, in features, dW images, db images, name of the kind)
+        (gs.out, stk.hact, d, ff, [bank.grad_image(l.output.dense.weight) for l in layers], [bank.grad_image(l.output.dense.bias) for l in layers], "out"),
+        (gs.hp, stk.a, ff, d, [bank.grad_image(l.intermediate.dense.weight) for l in layers], [bank.grad_image(l.intermediate.dense.bias) for l in layers], "ffn"),
+        (gs.att, stk.ctx, d, d, [bank.grad_image(l.attention.output.dense.weight) for l in layers], [bank.grad_image(l.attention.output.dense.bias) for l in layers], "att"),
+        (gs.qkv, stk.x, 3 * d, d, [qkv_w(l) for l in layers], [qkv_b(l) for l in layers], "qkv"),
     ]
     # first-writer stores: after zero_grad(lazy=True) the encoder weight gradients were NOT zeroed -- the batched launches
     # overwrite them (no memset, no fp32 read-modify-write); any other path zeroes the span first
     fresh = bank.take_fresh()
-    batched = [(_uniform_stride(gws), _uniform_stride(gbs)) for _g, _x, _n, _k, gws, gbs in kinds]
-    all_batched = all(sw is not None and sb is not None and n % 8 == 0 and k % 8 == 0 for (sw, sb), (_g, _x, n, k, _w, _b) in zip(batched, kinds))
+    batched = [(_uniform_stride(gws), _uniform_stride(gbs)) for _g, _x, _n, _k, gws, gbs, _kind in kinds]
+    all_batched = all(sw is not None and sb is not None and n % 8 == 0 and k % 8 == 0 for (sw, sb), (_g, _x, n, k, _w, _b, _kd) in zip(batched, kinds))
     if fresh and not all_batched:
         a, b = bank.lazy_span
         bank.grad[a:b].zero_()
         fresh = False
-    for g, x, n, k, gws, gbs in kinds:
+    if not fresh:
+        bank.fold_invalidate()                       # (a second backward of the step accumulates: the first one's norm shares are void)
+    for g, x, n, k, gws, gbs, kind in kinds:
         sw, sb = _uniform_stride(gws), _uniform_stride(gbs)
         if sw is not None and sb is not None and n % 8 == 0 and k % 8 == 0:
+            slots = bank.fold_take(ops.sq_slot_count(n, k, nl), "enc:" + kind) if (fresh and rt.dtype == torch.bfloat16) else None
             ops.gemm(g, x, n, k, M, out=gws[0], a_mode=KROW, lda=n, b_mode=KROW, ldb=k, ldc=k, accumulate=not fresh, a_rowsum=gbs[0],
-                     batch=nl, batch_strides=(M * n, M * k, sw, sb))
+                     batch=nl, batch_strides=(M * n, M * k, sw, sb), sq_slots=slots)
         else:
             for li in range(nl):
                 _linear_wgrad(rt, g[li], x[li], None, None, M, n, k, grad_w=gws[li], grad_b=gbs[li])
@@ -1450,6 +1465,9 @@ class ClipBert(nn.Module):
             enc += [layer.attention.self.query.weight, layer.attention.self.key.weight, layer.attention.self.value.weight,
                     layer.attention.output.dense.weight, layer.intermediate.dense.weight, layer.output.dense.weight]
         rt.bank.set_lazy_span(enc)
+        # the ResNet's trainable convolution weights + the grid encoder's: one weight-gradient launch each per backward -> first-writer stores
+        if dtype == torch.bfloat16:
+            rt.bank.set_fresh_params([m.weight for m in self.cnn.modules() if isinstance(m, (Conv2d, _GridConv)) and rt.bank.is_trainable(m.weight)])
         return self
 
     def _ensure_prepared(self, device):

@@ -52,7 +52,7 @@ def gemm_desc(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: 
               sH=0, sW=0, flip_taps=False, c_rowmap=None, accumulate=False, split_k=1, act=ACT_NONE,
               scale=None, shift=None, residual=None, ldr=None, relu_after=False, mask=None, ldm=None,
               out2=None, ldc2=None, alpha=1.0, dropout_p=0.0, dropout_seed=0, seed_ptr=None, tile=0, gelu_grad_pre=None, a_rowsum=None, batch=1, batch_strides=None,
-              relu_bwd=False, post_scale=None, post_scale2=None, xcd_order=0, zero_fill_pitch=0, splitk_ws=None, schedule=0) -> GemmDesc:
+              relu_bwd=False, post_scale=None, post_scale2=None, xcd_order=0, zero_fill_pitch=0, splitk_ws=None, schedule=0, sq_slots=None) -> GemmDesc:
     """The cb_gemm_desc of C[M,N] (op)= epilogue(sum_k A(m,k) B(n,k)); see include/clipbert_hip.h.  ``splitk_ws``: fp32 scratch for
     the K split of the 8-wave tiles (default: the per-device workspace of ``splitk_workspace``).  The descriptor borrows the
     tensors' memory: the caller keeps them alive until the launch that consumes it has been enqueued (``_refs`` holds them)."""
@@ -72,7 +72,7 @@ def gemm_desc(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: 
     d.c_rowmap = _ptr(c_rowmap)
     d.zero_fill_pitch = zero_fill_pitch
     d.c_f32 = int(out.dtype == torch.float32)
-    d.accumulate = int(accumulate)
+    d.accumulate = int(accumulate)            # False / True, or 2 = first writer (C holds nothing; stored; K split only through slabs)
     d.split_k = split_k
     d.act = act
     d.scale, d.shift = _ptr(scale), _ptr(shift)
@@ -112,8 +112,11 @@ def gemm_desc(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: 
         splitk_ws = _SPLITK_SIDE if _SPLITK_SIDE is not None else splitk_workspace(a.device)
     if splitk_ws is not None:
         d.splitk_ws, d.splitk_ws_bytes = _ptr(splitk_ws), splitk_ws.numel() * splitk_ws.element_size()
+    if sq_slots is not None:                  # fp32 slots for the tiles' shares of sum(C^2) (cb_gemm_desc.sq_slots)
+        assert sq_slots.dtype == torch.float32 and sq_slots.is_contiguous()
+        d.sq_slots, d.sq_slots_n = _ptr(sq_slots), sq_slots.numel()
     d._refs = (a, b, out, a_tab, b_tab, c_rowmap, scale, shift, residual, mask, out2, seed_ptr, gelu_grad_pre, a_rowsum, post_scale,
-               post_scale2, splitk_ws)
+               post_scale2, splitk_ws, sq_slots)
     return d
 
 
@@ -478,6 +481,21 @@ def sq_sum(g, out, ws=None):
         _chk(_lib.get().cb_sq_sum_det(_ptr(g), g.numel(), _ptr(out), _ptr(ws), ws.numel(), _stream(g)), "cb_sq_sum_det")
     else:
         _chk(_lib.get().cb_sq_sum(_ptr(g), g.numel(), _ptr(out), _stream(g)), "cb_sq_sum")
+
+
+def sq_slot_count(M: int, N: int, batch: int = 1) -> int:
+    """slots a cb_gemm call with ``sq_slots`` needs at most: one per 64 x 64 output tile and batch member"""
+    return ((M + 63) // 64) * ((N + 63) // 64) * batch
+
+
+def sq_sum_fold(g, segments, slots, out, ws):
+    """out += sum of g[lo:hi]^2 over ``segments`` (<= 4 (lo, hi) element ranges) + sum(slots): the squared gradient norm of a step whose
+    weight-gradient launches left their shares in ``slots`` (cb_sq_sum_fold; fixed order of addition)"""
+    segs = [(int(lo), int(hi)) for lo, hi in segments if hi > lo]
+    assert len(segs) <= 4
+    arr = (C.c_int64 * (2 * max(1, len(segs))))(*[x for s in segs for x in s])
+    _chk(_lib.get().cb_sq_sum_fold(_ptr(g), C.cast(arr, C.c_void_p), len(segs), _ptr(slots), slots.numel() if slots is not None else 0, _ptr(out), _ptr(ws),
+                                   ws.numel(), _stream(out)), "cb_sq_sum_fold")
 
 
 def adamw_hyper(lr, beta1, beta2, eps, weight_decay, step, max_norm=-1.0, grad_scale=1.0):

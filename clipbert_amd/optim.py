@@ -56,7 +56,10 @@ class FusedAdamW:
 
     def __init__(self, bank: ParamBank, lr: float = 5e-5, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 1e-3,
                  cnn_lr: Optional[float] = None, cnn_weight_decay: Optional[float] = None, transformer_lr_mul: float = 1.0,
-                 cnn_lr_mul: float = 1.0, max_grad_norm: float = -1.0):
+                 cnn_lr_mul: float = 1.0, max_grad_norm: float = -1.0, fold_norm: bool = True):
+        """fold_norm: after ``zero_grad(lazy=True)`` the weight-gradient launches leave their shares of the squared gradient norm in slots
+        (ParamBank.enable_norm_fold) and ``launch()`` adds them up instead of reading every gradient again -- single-process steps only
+        (with a gradient exchange the norm is taken of the reduced gradients: ``launch(grad16=...)`` / ``pieces`` ignore the shares)."""
         self.bank = bank
         bank.clients += 1
         bank.ensure_state()
@@ -86,7 +89,11 @@ class FusedAdamW:
         self._hp_dev_prev[:, HP_SKIP] = 1.0
         self._prev_live = False              # _hp_dev_prev holds a step's values (not the initial "skip")
         self.deferred_pending = False        # an update of some groups has been left to the next step (flush with launch(..., reuse_norm=True))
-        self._sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.fold_norm = bool(fold_norm) and max_grad_norm > 0 and bank.compute_dtype == torch.bfloat16
+        if self.fold_norm:
+            bank.enable_norm_fold()
+        self._sq_own = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._sq = self._sq_own
         self._sq_ws = torch.zeros(1024, dtype=torch.float32, device=dev)     # partials of the order-independent norm reduction
         self._last_scale = 1.0
 
@@ -146,9 +153,18 @@ class FusedAdamW:
         if getattr(bank, "lazy_fresh", False) and not prev:
             raise RuntimeError("FusedAdamW: zero_grad(lazy=True) was not followed by an encoder backward -- the encoder weight "
                                "gradients were never written")
+        bank.finish_fresh()                          # first-writer ranges nobody wrote (a partial backward) are zeroed before anything reads them
         sq = None
         if self.max_grad_norm > 0:
-            if not reuse_norm:
+            fold = bank.fold_result() if (self.fold_norm and not reuse_norm and grad16 is None and pieces is None) else None
+            if fold is not None:
+                # the weight-gradient launches left their shares of the squared norm in slots (cb_gemm_desc.sq_slots): what remains is the
+                # ranges they do not cover + the slots, added in a fixed order -- no second pass over ~5/6 of the gradient bytes.  The
+                # accumulator was zeroed with the slots by zero_grad(lazy=True).
+                self._sq = bank.sq_buf[:1]
+                ops.sq_sum_fold(bank.grad, fold[0], fold[1], self._sq, self._sq_ws)
+            elif not reuse_norm:
+                self._sq = self._sq_own
                 ops.zero_(self._sq)
                 src = bank.grad if grad16 is None else grad16
                 if pieces is None:

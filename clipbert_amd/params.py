@@ -196,6 +196,98 @@ class ParamBank:
                 return                                  # another parameter sits in between
         self.lazy_span = (spans[0][0], spans[-1][1])
 
+    def set_fresh_params(self, params):
+        """``params``: parameters whose weight gradient is produced by ONE launch per backward that can store instead of accumulate
+        (the ResNet's convolution weights: cb_gemm accumulate = 2, first writer).  If they tile one contiguous range of the flat gradient
+        buffer, ``zero_grad(lazy=True)`` skips it too; ``take_fresh_param`` tells each producer whether it is the first writer of this
+        step, and ``finish_fresh`` zeroes what no producer wrote (a partial backward) before the gradients are read."""
+        self.fresh_span, self.fresh_ids, self.fresh_left = None, {}, set()
+        ps = [p for p in params if id(p) in self.offset]
+        if not ps:
+            return
+        spans = sorted((self.offset[id(p)], self.offset[id(p)] + (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN, id(p)) for p in ps)
+        for (_a0, b0, _i0), (a1, _b1, _i1) in zip(spans, spans[1:]):
+            if b0 != a1:
+                return                                  # another parameter sits in between
+        if any(p.numel() % self.ALIGN for p in ps):
+            return                                      # (padding inside the range would never be written)
+        self.fresh_span = (spans[0][0], spans[-1][1])
+        self.fresh_ids = {i: (a, b) for a, b, i in spans}
+
+    def take_fresh_param(self, p: nn.Parameter) -> bool:
+        """True exactly once per gradient epoch for a parameter of the fresh range: its gradient holds garbage and must be STORED now"""
+        left = getattr(self, "fresh_left", None)
+        if left and id(p) in left:
+            left.discard(id(p))
+            return True
+        return False
+
+    def finish_fresh(self):
+        """zero the gradients of fresh-range parameters no producer wrote since zero_grad(lazy=True) (called before anything reads them)"""
+        left = getattr(self, "fresh_left", None)
+        if left:
+            for i in sorted(left):
+                a, b = self.fresh_ids[i]
+                ops.zero_(self.grad[a:b])
+            left.clear()
+            self.fold_invalidate()
+
+    # ---- squared-norm shares (cb_gemm_desc.sq_slots): the weight-gradient launches of a step leave sum(dW^2) per output tile in slots ----
+    SQ_SLOTS = 1 << 16
+
+    def enable_norm_fold(self):
+        """allocate the accumulator + slots (zeroed by zero_grad(lazy=True) from then on); idempotent"""
+        if getattr(self, "sq_buf", None) is None:
+            self.sq_buf = torch.zeros(1 + self.SQ_SLOTS, dtype=torch.float32, device=self.device)
+            self.fold = None
+        return self.sq_buf
+
+    def fold_take(self, slots: int, covers: str):
+        """``slots`` slots for one weight-gradient launch of the running step (None: no share wanted / possible); ``covers``: what the
+        launch writes completely -- one of the four encoder kinds ("enc:<kind>") or one fresh-range parameter ("cnn")"""
+        f = getattr(self, "fold", None)
+        if f is None or not f["valid"] or getattr(self, "norm_fold_blocked", False):
+            return None
+        if f["next"] + slots > self.SQ_SLOTS:
+            f["valid"] = False
+            return None
+        view = self.sq_buf[1 + f["next"]:1 + f["next"] + slots]
+        f["next"] += slots
+        f["covers"].append(covers)
+        return view
+
+    def fold_invalidate(self):
+        if getattr(self, "fold", None) is not None:
+            self.fold["valid"] = False
+
+    def fold_result(self):
+        """(segments, slots) for ops.sq_sum_fold if the shares of this step are usable: every encoder kind stored once, every fresh-range
+        parameter stored once with a share -- else None (the caller runs the full pass)"""
+        f = getattr(self, "fold", None)
+        if f is None or not f["valid"] or getattr(self, "lazy_fresh", False) or getattr(self, "fresh_left", None) or getattr(self, "norm_fold_blocked", False):
+            return None
+        covered = []
+        enc = [c for c in f["covers"] if c.startswith("enc:")]
+        if self.lazy_span is not None and sorted(enc) == sorted(f"enc:{k}" for k in ("out", "ffn", "att", "qkv")):
+            covered.append(self.lazy_span)
+        elif enc:
+            return None                                  # (a partial set of shares inside the lazy span cannot be subtracted)
+        ncnn = sum(1 for c in f["covers"] if c == "cnn")
+        if getattr(self, "fresh_span", None) is not None and ncnn == len(self.fresh_ids):
+            covered.append(self.fresh_span)
+        elif ncnn:
+            return None
+        if not covered:
+            return None
+        segs, lo = [], 0
+        for a, b in sorted(covered):
+            if a > lo:
+                segs.append((lo, a))
+            lo = b
+        if lo < self.n_train:
+            segs.append((lo, self.n_train))
+        return segs, self.sq_buf[1:1 + f["next"]]
+
     def assert_whole(self, what: str):
         """Owner-only updates (GradSync(shard=True)) leave every rank with ITS pieces of the fp32 masters and AdamW moments: anything
         that reads the whole state (state_dict(), a checkpoint) needs GradSync.gather_state() on all ranks first."""
@@ -209,19 +301,30 @@ class ParamBank:
         self.grad_epoch = getattr(self, "grad_epoch", 0) + 1       # one per gradient group: GradSync.wait() tells a repeated wait()
         span = getattr(self, "lazy_span", None)                   # (nothing to do) from a step whose exchange was never issued
         if lazy and span is not None:
-            a, b = span
-            if a > 0:
-                ops.zero_(self.grad[:a])
-            if b < self.grad.numel():
-                ops.zero_(self.grad[b:])
+            skip = sorted([span] + ([self.fresh_span] if getattr(self, "fresh_span", None) is not None else []))
+            lo = 0
+            for a, b in skip:
+                if a > lo:
+                    ops.zero_(self.grad[lo:a])
+                lo = max(lo, b)
+            if lo < self.grad.numel():
+                ops.zero_(self.grad[lo:])
             self.lazy_fresh = True
+            self.fresh_left = set(getattr(self, "fresh_ids", {}))
+            if getattr(self, "sq_buf", None) is not None:      # the norm accumulator and this step's share slots start at zero
+                ops.zero_(self.sq_buf)
+                self.fold = dict(valid=True, next=0, covers=[])
         else:
             ops.zero_(self.grad)
             self.lazy_fresh = False
+            self.fresh_left = set()
+            self.fold = None
 
     def zero_grad_range(self, lo: int, hi: int, lazy: bool = False):
         """zero_grad restricted to [lo, hi) of the flat gradient buffer (a step whose halves are zeroed at different points, see
         FusedAdamW.launch(groups=...)); ``lazy`` as in zero_grad: the lazy span is skipped.  Does not start a new gradient epoch."""
+        self.fresh_left = set()                                   # (the half-step plans zero every range they own: no first writers)
+        self.fold = None
         span = getattr(self, "lazy_span", None) if lazy else None
         if span is None or span[1] <= lo or span[0] >= hi:
             if hi > lo:

@@ -70,7 +70,10 @@ typedef struct {
     void* C; int64_t ldc;
     const int32_t* c_rowmap;  /* optional: output row m is written at row c_rowmap[m]                */
     int32_t c_f32;            /* 1: C is fp32 regardless of dtype (parameter gradients, logits)      */
-    int32_t accumulate;       /* 1: C += result (plain RMW; with split_k > 1: fp32 atomics, row-coalesced) */
+    int32_t accumulate;       /* 1: C += result (plain RMW; with split_k > 1: fp32 atomics, row-coalesced);
+                                 2: FIRST WRITER -- C holds nothing of value and receives the result (no zero fill before the launch,
+                                 no read-modify-write in it), and the K split stays the library's to choose as with 1, but only
+                                 through the slab scratch (ordered in-launch reduce): without a scratch the problem runs unsplit */
     int32_t split_k;          /* >= 1; > 1 requires c_f32 && accumulate semantics (C pre-initialised) */
     int32_t act;              /* CB_ACT_* applied before the residual add                            */
     const float* scale;       /* optional per-n multiplier (FrozenBN scale)                          */
@@ -127,6 +130,15 @@ typedef struct {
                                  to the launches of ONE stream (or of streams ordered by events): launches that may run concurrently
                                  must carry different buffers.  The library itself allocates nothing and keeps no such state. */
     int64_t splitk_ws_bytes;
+    float* sq_slots;          /* optional, bf16 problems that STORE an fp32 C (accumulate 0 / 2; plain epilogue: weight gradients): every
+                                 output tile also stores the sum of the squares of what it wrote -- its share of the squared gradient
+                                 norm (torch.nn.utils.clip_grad_norm_, run_video_retrieval.py:477-482) -- to one slot of its own,
+                                 sq_slots[t], t < sq_slots_n; the launch writes ceil(M / BM) * ceil(N / BN) * batch of them for the tile
+                                 size it picked and leaves the rest untouched, so the caller zeroes the range once per step, reserves
+                                 sq_slots_n >= ceil(M / 64) * ceil(N / 64) * batch, and adds the slots up in index order
+                                 (cb_sq_sum_fold): a deterministic norm without a second pass over the gradients.  A call that cannot
+                                 honour it (another epilogue, unaligned rows, fp32 operands) FAILS rather than skip it silently. */
+    int64_t sq_slots_n;
 } cb_gemm_desc;
 
 /* GEMM / implicit-GEMM convolution, all forms.  Replaces torch.nn.Linear / F.conv2d (+ apex-amp
@@ -362,6 +374,11 @@ int cb_sq_sum(const float* g, int64_t n, float* out_accum, void* stream);
  * gradients derive the bit-identical clip coefficient (torch.nn.utils.clip_grad_norm_ in run_video_retrieval.py:477-482 is
  * deterministic per rank too).  ws: caller-owned scratch of ws_floats floats. */
 int cb_sq_sum_det(const float* g, int64_t n, float* out_accum, float* ws, int32_t ws_floats, void* stream);
+/* The norm of a step whose weight-gradient launches already left their shares in slots (cb_gemm_desc.sq_slots): out_accum += the squares
+ * of the nseg (<= 4) ranges g[seg_lo_hi[2 i], seg_lo_hi[2 i + 1]) that no such launch covers (seg_lo_hi: HOST array of element
+ * offsets) + the sum of slots[0, nslots), everything added in a fixed order (same determinism contract as cb_sq_sum_det).  Two launches. */
+int cb_sq_sum_fold(const float* g, const int64_t* seg_lo_hi, int32_t nseg, const float* slots, int64_t nslots, float* out_accum, float* ws,
+                   int32_t ws_floats, void* stream);
 /* The same two for bf16 GRADIENTS: in data-parallel runs the all-reduce travels in bf16 (as the reference's apex-O2 fp16 gradients
  * do through Horovod, run_video_retrieval.py:298-301); the optimizer then reads the reduced wire image directly instead of a
  * copy cast back to fp32 (same values: bf16 -> fp32 is exact). */
@@ -385,7 +402,9 @@ const char* cb_last_error(void);
  * 3 = cb_gemm_desc.tile = 8 (the streaming structure; every earlier descriptor means what it meant), cb_head_loss, cb_retrieval_scores;
  * 4 = cb_res2_block, cb_stem_pool (round 5: the frozen front of the backbone as fused launches; nothing else changed);
  * 5 = the K-split arrival counters live in the tail of cb_gemm_desc.splitk_ws (CB_SPLITK_WS_COUNTER_BYTES, zeroed once by the caller)
- *     instead of a library-owned allocation: a caller of version 4 that passes a scratch must zero its last 64 KiB once */
+ *     instead of a library-owned allocation: a caller of version 4 that passes a scratch must zero its last 64 KiB once;
+ * 6 = cb_gemm_desc grew by sq_slots / sq_slots_n at its END (zero = off: older callers that memset the struct they allocate with the
+ *     new size are unaffected), accumulate = 2 (first writer), cb_sq_sum_fold */
 int cb_version(void);
 
 /* ---- gradient exchange (one process per GPU, RCCL over xGMI) ----------------------------------------------------

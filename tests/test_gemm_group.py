@@ -261,3 +261,77 @@ def test_group_slab_counters_live_in_the_callers_scratch(hw):
     refs = [g.float().cpu().t() @ x.float().cpu() for g, x, m, n, k in sets[0]]
     for x, r in zip(alone[0], refs):
         torch.testing.assert_close(x, r, **tol(dt))
+
+
+@pytest.mark.parametrize("grouped", [True, False])
+def test_first_writer_weight_gradients_and_norm_shares(hw, grouped):
+    """round 6: accumulate = 2 (FIRST WRITER: C holds garbage, no zero fill, no read-modify-write; K split only through slabs) and
+    cb_gemm_desc.sq_slots (every output tile leaves sum(C^2) of what it stored in a slot of its own; cb_sq_sum_fold adds slots + the
+    ranges no launch covered).  Outputs start from NaN: any read of C would poison the result.  The folded norm equals the norm of the
+    stored gradients, bit-reproducibly; a call that cannot leave its share fails loudly."""
+    dt = torch.bfloat16
+    lin = _wgrad_problems(hw, dt, [(1100, 136, 200), (700, 264, 136), (330, 128, 128)])
+    conv = _conv_wgrad_problems(hw, dt, [(2, 12, 12, 32, 72, 3, 1, 1), (2, 14, 14, 72, 136, 3, 1, 1)])
+    shapes = [(n, k) for _g, _x, _m, n, k in lin] + [(pr[7], pr[8] * pr[8] * pr[6]) for pr in conv]
+    counts = [ops.sq_slot_count(a, b) for a, b in shapes]
+    refs = [g.float().cpu().t() @ x.float().cpu() for g, x, m, n, k in lin] + [_conv_ref(pr) for pr in conv]
+    ws = ops.new_splitk_workspace(hw.dev, 16 << 20)
+
+    def run():
+        slots = torch.zeros(sum(counts) + 7, device=hw.dev)
+        outs, descs, base = [], [], 0
+        for i, (g, x, m, n, k) in enumerate(lin):
+            o = torch.full((n, k), float("nan"), device=hw.dev)
+            descs.append(ops.gemm_desc(g, x, n, k, m, out=o, a_mode=ops.KROW, b_mode=ops.KROW, accumulate=2, splitk_ws=ws, sq_slots=slots[base:base + counts[i]]))
+            base += counts[i]
+            outs.append(o)
+        for j, pr in enumerate(conv):
+            o = torch.full(shapes[len(lin) + j], float("nan"), device=hw.dev)
+            descs.append(_conv_desc(pr, o, accumulate=2, splitk_ws=ws, sq_slots=slots[base:base + counts[len(lin) + j]]))
+            base += counts[len(lin) + j]
+            outs.append(o)
+        if grouped:
+            ops.gemm_group(descs, outs[0])
+        else:
+            for d in descs:
+                ops.gemm_group([d], outs[0])
+        return outs, slots
+
+    outs, slots = run()
+    outs2, slots2 = run()
+    for o, o2, r in zip(outs, outs2, refs):
+        assert torch.isfinite(o).all()
+        assert torch.equal(o, o2)
+        torch.testing.assert_close(o.cpu(), r, **tol(dt))
+    assert torch.equal(slots, slots2)
+    assert float(slots[-7:].abs().sum()) == 0.0                          # nobody writes past its reservation
+    extra = hw(rnd(1003, seed=77))                                       # a range no launch covered (unaligned length)
+    total = torch.zeros(1, device=hw.dev)
+    scratch = torch.empty(1024, device=hw.dev)
+    ops.sq_sum_fold(extra, [(3, 1003), (0, 3)], slots, total, scratch)
+    want = sum(float((o.double() ** 2).sum()) for o in outs) + float((extra.double() ** 2).sum())
+    assert abs(float(total) - want) <= 1e-5 * want
+    # an epilogue that cannot leave a share is refused, not skipped
+    g, x, m, n, k = lin[0]
+    o = torch.zeros(n, k, device=hw.dev)
+    with pytest.raises(RuntimeError, match="sq_slots"):
+        ops.gemm(g, x, n, k, m, out=o, a_mode=ops.KROW, b_mode=ops.KROW, accumulate=True, sq_slots=slots[:counts[0]])
+    with pytest.raises(RuntimeError, match="sq_slots_n"):
+        ops.gemm(g, x, n, k, m, out=o, a_mode=ops.KROW, b_mode=ops.KROW, accumulate=2, sq_slots=slots[:1])
+
+
+def test_first_writer_batched_weight_gradients_with_bias_row_sums(hw):
+    """the encoder's form: strided-batched weight gradients stored by their first writer, bias gradients as row sums, one norm share per tile"""
+    dt = torch.bfloat16
+    nl, m, n, k = 3, 200, 136, 264
+    g, x = hw(rnd(nl, m, n, seed=1).to(dt)), hw(rnd(nl, m, k, seed=2).to(dt))
+    dw = torch.full((nl, n, k), float("nan"), device=hw.dev)
+    db = torch.zeros(nl, n, device=hw.dev)
+    slots = torch.zeros(ops.sq_slot_count(n, k, nl), device=hw.dev)
+    ops.gemm(g, x, n, k, m, out=dw[0], a_mode=ops.KROW, lda=n, b_mode=ops.KROW, ldb=k, ldc=k, accumulate=False, a_rowsum=db[0], batch=nl,
+             batch_strides=(m * n, m * k, n * k, n), sq_slots=slots)
+    ref = torch.einsum("lmn,lmk->lnk", g.float().cpu(), x.float().cpu())
+    torch.testing.assert_close(dw.cpu(), ref, **tol(dt))
+    torch.testing.assert_close(db.cpu(), g.float().cpu().sum(1), **tol(dt))
+    want = float((dw.double() ** 2).sum())
+    assert abs(float(slots.double().sum()) - want) <= 1e-5 * want

@@ -180,7 +180,7 @@ def main():
                         comm=os.environ.get("CB_COMM", "auto"), pretend_world=dry_dp, loopback=loopback,   # auto: the library's own RCCL entry points on "nccl"
                         shard=os.environ.get("CB_BENCH_SHARD") == "1")      # opt-in: reduce-scatter -> owner-only AdamW -> all-gather
         sync.broadcast_parameters(0)
-        opt = FusedAdamW(bank, lr=5e-5, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0)
+        opt = FusedAdamW(bank, lr=5e-5, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0, fold_norm=os.environ.get("CB_BENCH_NO_FOLD") is None)
     # ---- the pieces of a step: clipbert_amd.bench.step.make_step builds them (tests/test_bench_step.py checks exactly these closures: eager
     # == captured replay, gradients against the oracle's autograd) ------------------------------------------------------------------
     from clipbert_amd.bench import step as bench_step

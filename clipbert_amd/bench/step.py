@@ -57,7 +57,7 @@ def build(videos=16, n_clips=2, frames=2, size=224, txt_len=32, repeat=2, pool="
     counts = [repeat] * videos
     batch = dict(visual_inputs=fr, text_input_ids=ids, text_input_mask=mask, labels=labels, n_examples_list=counts)
     sync = GradSync(bank, compress="bf16", comm="auto")
-    opt = FusedAdamW(bank, lr=5e-5, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0)
+    opt = FusedAdamW(bank, lr=5e-5, betas=(0.9, 0.98), weight_decay=1e-3, max_grad_norm=5.0, fold_norm=os.environ.get("CB_BENCH_NO_FOLD") is None)
     fns = make_step(model, batch, tcfg, opt, sync, labels, counts, n_clips, frames, pool)
 
     def capture(fn=None):

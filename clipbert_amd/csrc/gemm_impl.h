@@ -740,8 +740,9 @@ __device__ __forceinline__ void epilogue_vec(const GP& p, f32x4 v, int m, int64_
         store4(c, p.post_scale ? v * load4(p.post_scale + nb) : v);
         return;
     }
-    if (p.scale) v = v * load4(p.scale + nb);
-    if (p.shift) v = v + load4(p.shift + nb);
+    if (p.scale && p.shift) v = __builtin_elementwise_fma(v, load4(p.scale + nb), load4(p.shift + nb));
+    else if (p.scale) v = v * load4(p.scale + nb);
+    else if (p.shift) v = v + load4(p.shift + nb);
     if (p.act == CB_ACT_GELU_SAVE_GRAD && p.C2) {
         f32x4 dv;
 #pragma unroll
@@ -806,8 +807,9 @@ __device__ __forceinline__ void epilogue_elem(const GP& p, float x, int m, int64
         *c = from_f32<T>(p.post_scale ? x * p.post_scale[n] : x);
         return;
     }
-    if (p.scale) x *= p.scale[n];
-    if (p.shift) x += p.shift[n];
+    if (p.scale && p.shift) x = __builtin_fmaf(x, p.scale[n], p.shift[n]);
+    else if (p.scale) x *= p.scale[n];
+    else if (p.shift) x += p.shift[n];
     if (p.act == CB_ACT_GELU_SAVE_GRAD && p.C2) {
         float dx;
         if constexpr (sizeof(T) == 2) gelu_erf_both_pk(x, x, dx);
@@ -960,11 +962,16 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
         }
         return;
     }
-    if (p.scale) {
+    // scale and shift together are ONE fused multiply-add, written as such in every path of the library (this one, epilogue_vec /
+    // epilogue_elem, fast_epilogue, cb_stem_pool, cb_res2_block): kernels of different structure stay bit-identical whatever
+    // -ffp-contract decides per call site
+    if (p.scale && p.shift) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(v[r], sc[r], sh[r]);
+    } else if (p.scale) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] *= sc[r];
-    }
-    if (p.shift) {
+    } else if (p.shift) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += sh[r];
     }
@@ -1148,8 +1155,13 @@ __device__ __forceinline__ void fast_epilogue(const GP& p, unsigned char* smem, 
             union { f32x4 f; u32x4 r; } ua, ub;
             ua.f = a; ub.f = b;
             const uint32_t off = (uint32_t)m * ldcb + (uint32_t)n * 4u;
-            __builtin_amdgcn_raw_buffer_store_b128(ua.r, rc, off, 0, 16 /* sc1 */);
-            __builtin_amdgcn_raw_buffer_store_b128(ub.r, rc, off + 16u, 0, 16 /* sc1 */);
+            if (p.wt) {                                              // (A/B of round 6, call G: write-through or plain stores for the fp32 gradients)
+                __builtin_amdgcn_raw_buffer_store_b128(ua.r, rc, off, 0, 16 /* sc1 */);
+                __builtin_amdgcn_raw_buffer_store_b128(ub.r, rc, off + 16u, 0, 16 /* sc1 */);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(ua.r, rc, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(ub.r, rc, off + 16u, 0, 0);
+            }
             sq += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]) + (b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]);
             return;
         }
@@ -1173,14 +1185,11 @@ __device__ __forceinline__ void fast_epilogue(const GP& p, unsigned char* smem, 
             __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v), rc, (uint32_t)m * ldcb + nb, 0, 16 /* sc1 */);
             return;
         }
-        {   // scale, then shift, as TWO roundings -- what the generic epilogue8 does behind its runtime branches; the streaming kernel and the
-            // K-split reduce run that one and must stay bit-identical to this path (tests/test_gemm_stream.py)
-#pragma clang fp contract(off)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if constexpr ((FLAGS & EF_SCALE) != 0) v[r] = v[r] * sc[r];
-                if constexpr ((FLAGS & EF_SHIFT) != 0) v[r] = v[r] + sh[r];
-            }
+        for (int r = 0; r < 4; ++r) {                              // (scale and shift together: one fma, as in every path of the library)
+            if constexpr ((FLAGS & EF_SCALE) != 0 && (FLAGS & EF_SHIFT) != 0) v[r] = pk_fma(v[r], sc[r], sh[r]);
+            else if constexpr ((FLAGS & EF_SCALE) != 0) v[r] = v[r] * sc[r];
+            else if constexpr ((FLAGS & EF_SHIFT) != 0) v[r] = v[r] + sh[r];
         }
         if constexpr ((FLAGS & EF_GELU2) != 0) {
             f32x2 dv[4];

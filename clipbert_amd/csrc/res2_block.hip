@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256, 2) res2_block_kernel(Res2P p) {
                     bf16x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float y = acc[u][e] * s1[e] + b1[e];
+                        const float y = __builtin_fmaf(acc[u][e], s1[e], b1[e]);
                         o[e] = (bf16)((in && y > 0.f) ? y : 0.f);
                     }
                     *reinterpret_cast<bf16x4*>(Y1s + row * P64 + cA * 2) = o;
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(256, 2) res2_block_kernel(Res2P p) {
                 bf16x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float y = acc[u][e] * s2[e] + b2[e];
+                    const float y = __builtin_fmaf(acc[u][e], s2[e], b2[e]);
                     o[e] = (bf16)(y > 0.f ? y : 0.f);
                 }
                 *reinterpret_cast<bf16x4*>(Y2s + pix * P64 + cA * 2) = o;
@@ -224,8 +224,8 @@ __global__ void __launch_bounds__(256, 2) res2_block_kernel(Res2P p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         // (the unfused path stores the shortcut branch in bf16 before the residual add: same rounding point)
-                        const float sc = (float)(bf16)(asc[e] * ss[e] + bs[e]);
-                        const float y = acc[e] * s3[e] + b3[e] + sc;
+                        const float sc = (float)(bf16)__builtin_fmaf(asc[e], ss[e], bs[e]);
+                        const float y = __builtin_fmaf(acc[e], s3[e], b3[e]) + sc;
                         o[e] = (bf16)(y > 0.f ? y : 0.f);
                     }
                     *reinterpret_cast<bf16x4*>(Os + pix * POUT + ch * 2) = o;
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(256, 2) res2_block_kernel(Res2P p) {
                     const bf16x4 res = *reinterpret_cast<const bf16x4*>(q);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float y = acc[e] * s3[e] + b3[e] + (float)res[e];
+                        const float y = __builtin_fmaf(acc[e], s3[e], b3[e]) + (float)res[e];
                         o[e] = (bf16)(y > 0.f ? y : 0.f);
                     }
                     *reinterpret_cast<bf16x4*>(q) = o;

@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(NT, 2) stem_pool_kernel(StemP p) {
                     bf16x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float y = acc[u][e] * sc[e] + sh[e];
+                        const float y = __builtin_fmaf(acc[u][e], sc[e], sh[e]);
                         o[e] = (bf16)((in && y > 0.f) ? y : 0.f);     // (>= 0 everywhere: a zero stands in for the pool's -inf padding)
                     }
                     *reinterpret_cast<bf16x4*>(Cs + pix * PC + cA * 2) = o;

@@ -313,10 +313,7 @@ int gemm_prepare(const cb_gemm_desc* d, Prepared& out) {
         const bool wg_store = !fe_off && d->dtype == CB_BF16 && d->c_f32 && d->a_mode == CB_KROW && d->accumulate != 1 && p.alpha == 1.f && !d->scale && !d->shift &&
                               d->act == CB_ACT_NONE && !d->C2 && !d->residual && !d->mask && !d->gelu_grad_pre && d->dropout_p <= 0.f && !d->relu_after && !d->c_rowmap &&
                               !d->zero_fill_pitch && !d->relu_bwd && d->N % 8 == 0 && d->ldc % 8 == 0 && aligned16(d->C) && (int64_t)d->M * d->ldc * 4 < 0xffffffffll;
-        if (wg_store) {
-            p.fast_epi = FAST_EPI_F32;
-            p.wt = getenv("CB_WG_STORE_WT") != nullptr && atoi(getenv("CB_WG_STORE_WT")) != 0;      // TEMPORARY (call G)
-        }
+        if (wg_store) p.fast_epi = FAST_EPI_F32;
         p.sq_slots = nullptr;
         if (d->sq_slots) {
             const int64_t need = (int64_t)((d->M + 63) / 64) * ((d->N + 63) / 64) * p.batch;

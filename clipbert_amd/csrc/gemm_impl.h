@@ -1155,13 +1155,10 @@ __device__ __forceinline__ void fast_epilogue(const GP& p, unsigned char* smem, 
             union { f32x4 f; u32x4 r; } ua, ub;
             ua.f = a; ub.f = b;
             const uint32_t off = (uint32_t)m * ldcb + (uint32_t)n * 4u;
-            if (p.wt) {                                              // (A/B of round 6, call G: write-through or plain stores for the fp32 gradients)
-                __builtin_amdgcn_raw_buffer_store_b128(ua.r, rc, off, 0, 16 /* sc1 */);
-                __builtin_amdgcn_raw_buffer_store_b128(ub.r, rc, off + 16u, 0, 16 /* sc1 */);
-            } else {
-                __builtin_amdgcn_raw_buffer_store_b128(ua.r, rc, off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(ub.r, rc, off + 16u, 0, 0);
-            }
+            // PLAIN stores: the fp32 gradients are read again within the step (norm remainder, AdamW) and a write-through store drops the
+            // line from the XCD's L2 -- measured 7.92 (plain) against 8.04 ms (sc1) per step, profiles/r06g_norm_shares_ab.txt
+            __builtin_amdgcn_raw_buffer_store_b128(ua.r, rc, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(ub.r, rc, off + 16u, 0, 0);
             sq += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]) + (b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]);
             return;
         }

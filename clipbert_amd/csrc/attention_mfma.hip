@@ -215,6 +215,8 @@ __global__ void __launch_bounds__(128 * NT, (NT == 3 ? 5 : 1)) attn_bwd_mfma_ker
     __shared__ __attribute__((aligned(16))) unsigned char Vs[NP * 32 * RS];
     __shared__ __attribute__((aligned(16))) float Dl[NP * 32];      // D_i = rowsum(dO * O)
     __shared__ __attribute__((aligned(16))) float Ll[NP * 32];      // lse_i (+big past L: probabilities of padding rows = 0)
+    __shared__ __attribute__((aligned(16))) float Ml[NP * 32];      // additive key mask (requested with everything else, BEFORE the barrier:
+                                                                    // round 6 -- it used to be a dependent global round trip behind it)
     if (drop_p > 0.f && seed_ptr) seed += *seed_ptr;
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
     const int wave = threadIdx.x >> 6;
@@ -250,6 +252,7 @@ __global__ void __launch_bounds__(128 * NT, (NT == 3 ? 5 : 1)) attn_bwd_mfma_ker
         unsigned char* const dsts[4] = {Ks, Qs, Gs, Vs};
         stage_all<4, NP * 32, NTHR>(bases, strides, dsts, L, threadIdx.x);
     }
+    if (threadIdx.x < NP * 32) Ml[threadIdx.x] = (int)threadIdx.x < L ? (1.0f - key_mask[(int64_t)(blockIdx.x / H) * L + threadIdx.x]) * MASK_NEG : NEG_BIG;
     if (!yph) {
         float part = 0.f;
 #pragma unroll
@@ -267,7 +270,7 @@ __global__ void __launch_bounds__(128 * NT, (NT == 3 ? 5 : 1)) attn_bwd_mfma_ker
     }
     __syncthreads();
 
-    const float cmadd = col < L ? (1.0f - key_mask[(int64_t)b * L + col]) * MASK_NEG : NEG_BIG;   // Y: own key
+    const float cmadd = Ml[col];                                                                     // Y: own key
     const float clse = Ll[col], cD = Dl[col];                                                        // X: own query
     f32x4 pd[NP * 2], ds[NP * 2];
 #pragma unroll
@@ -286,8 +289,7 @@ __global__ void __launch_bounds__(128 * NT, (NT == 3 ? 5 : 1)) attn_bwd_mfma_ker
                 rD = *reinterpret_cast<const f32x4*>(&Dl[row0]);
                 rmadd = f32x4{cmadd, cmadd, cmadd, cmadd};
             } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) rmadd[r] = row0 + r < L ? (1.0f - key_mask[(int64_t)b * L + row0 + r]) * MASK_NEG : NEG_BIG;
+                rmadd = *reinterpret_cast<const f32x4*>(&Ml[row0]);
                 rlse = f32x4{clse, clse, clse, clse};
                 rD = f32x4{cD, cD, cD, cD};
             }

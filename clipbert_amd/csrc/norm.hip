@@ -54,7 +54,9 @@ __device__ __forceinline__ void norm_store(const f32x4 (&v)[MAXCH], const float*
     }
 }
 
-template <typename T, int MAXCH>
+// FULL: D == MAXCH * 256 (the encoder's 768): no column guards, and gamma / beta are requested WITH the row (they used to be a second,
+// dependent round trip behind the two reductions).
+template <typename T, int MAXCH, bool FULL = false>
 __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const T* x, const float* gamma, const float* beta, T* y,
                                                             float* mean_out, float* rstd_out, int64_t rows, int D, float eps,
                                                             int seg_len, int seg_stride, int seg_off) {
@@ -63,6 +65,35 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const T* x, const fl
     if (row >= rows) return;
     if (seg_len > 0) row = (row / seg_len) * seg_stride + seg_off + row % seg_len;
     f32x4 v[MAXCH];
+    if constexpr (FULL) {
+        f32x4 gm[MAXCH], bt[MAXCH];
+        load_row(x + row * D, MAXCH * 256, lane, v);
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) { gm[c] = load4(gamma + (lane + 64 * c) * 4); bt[c] = load4(beta + (lane + 64 * c) * 4); }
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+        const float inv_d = 1.0f / (float)(MAXCH * 256);
+        const float mean = wave_sum(s) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float d = v[c][i] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (v[c][i] - mean) * rstd * gm[c][i] + bt[c][i];
+            store4(y + row * D + (lane + 64 * c) * 4, o);
+        }
+        if (lane == 0) {
+            if (mean_out) mean_out[row] = mean;
+            if (rstd_out) rstd_out[row] = rstd;
+        }
+        return;
+    }
     load_row(x + row * D, D, lane, v);
     float mean, rstd;
     row_stats(v, D, lane, eps, mean, rstd);
@@ -515,8 +546,12 @@ inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per
 template <typename T, int NCH>
 void run_ln_fwd(hipStream_t st, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                 int64_t rows, int D, float eps, int seg_len, int seg_stride, int seg_off) {
-    hipLaunchKernelGGL((layernorm_fwd_kernel<T, NCH>), dim3(nblk(rows, 4)), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y,
-                       mean, rstd, rows, D, eps, seg_len, seg_stride, seg_off);
+    if (D == NCH * 256 && NCH <= 4)
+        hipLaunchKernelGGL((layernorm_fwd_kernel<T, (NCH <= 4 ? NCH : 4), true>), dim3(nblk(rows, 4)), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y,
+                           mean, rstd, rows, D, eps, seg_len, seg_stride, seg_off);
+    else
+        hipLaunchKernelGGL((layernorm_fwd_kernel<T, NCH>), dim3(nblk(rows, 4)), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y,
+                           mean, rstd, rows, D, eps, seg_len, seg_stride, seg_off);
 }
 template <typename T, int NCH>
 void run_ln_bwd(hipStream_t st, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,

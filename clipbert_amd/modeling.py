@@ -208,7 +208,10 @@ class Runtime:
         self.overlap = 0                                 # what runs there (prepare(overlap_wgrad=...)): bit 0 the encoder's batched weight
                                                          # gradients beside the ResNet backward, bit 1 a ResNet stage's grouped weight
                                                          # gradients beside the next stage's data gradients, bit 2 every convolution's
-                                                         # weight gradient on its own (the round-1 form)
+                                                         # weight gradient on its own (the round-1 form), bit 3 the encoder's four batched
+                                                         # weight-gradient launches on four concurrent branches (each one's last wave of
+                                                         # tiles filled by the next one's first)
+        self.fan_streams = []                            # bit 3: three more streams (the fourth branch is the issuing stream)
         self.group_wgrads = os.environ.get("CB_NO_GROUP_WGRAD") is None     # ResNet weight gradients per stage through cb_gemm_group
         self.group_fwd_pairs = os.environ.get("CB_GROUP_FWD_PAIRS", "0") == "1"   # shortcut + conv1 of the strided stage entries in one launch: measured SLOWER (profiles/r04f: +0.1 ms; the grouped gather kernel runs the pair in 106 us against 47 + 24 apart) -- kept as a switch
         self._side_refs = []
@@ -869,15 +872,26 @@ def _encoder_wgrads(model, pk, gs, M):
         fresh = False
     if not fresh:
         bank.fold_invalidate()                       # (a second backward of the step accumulates: the first one's norm shares are void)
-    for g, x, n, k, gws, gbs, kind in kinds:
+    fan = rt.fan_streams if (rt.overlap & 8 and all_batched) else []
+    if fan:
+        fork = torch.cuda.Event()
+        fork.record()
+    for i, (g, x, n, k, gws, gbs, kind) in enumerate(kinds):
         sw, sb = _uniform_stride(gws), _uniform_stride(gbs)
         if sw is not None and sb is not None and n % 8 == 0 and k % 8 == 0:
             slots = bank.fold_take(ops.sq_slot_count(n, k, nl), "enc:" + kind) if (fresh and rt.dtype == torch.bfloat16) else None
-            ops.gemm(g, x, n, k, M, out=gws[0], a_mode=KROW, lda=n, b_mode=KROW, ldb=k, ldc=k, accumulate=not fresh, a_rowsum=gbs[0],
-                     batch=nl, batch_strides=(M * n, M * k, sw, sb), sq_slots=slots)
+            branch = contextlib.nullcontext()
+            if fan and i > 0:
+                fan[i - 1].wait_event(fork)
+                branch = _SideStream(fan[i - 1])            # (no K split on a branch: the scratch belongs to the issuing stream)
+            with branch:
+                ops.gemm(g, x, n, k, M, out=gws[0], a_mode=KROW, lda=n, b_mode=KROW, ldb=k, ldc=k, accumulate=not fresh, a_rowsum=gbs[0],
+                         batch=nl, batch_strides=(M * n, M * k, sw, sb), sq_slots=slots)
         else:
             for li in range(nl):
                 _linear_wgrad(rt, g[li], x[li], None, None, M, n, k, grad_w=gws[li], grad_b=gbs[li])
+    for st in fan:
+        torch.cuda.current_stream().wait_stream(st)
 
 
 def _ln_offsets(model, dev):
@@ -1455,6 +1469,8 @@ class ClipBert(nn.Module):
             rt.side_stream = torch.cuda.Stream(device=device)
             if rt.overlap & 3 and dtype == torch.bfloat16:
                 rt.side_ws = ops.new_splitk_workspace(device)
+            if rt.overlap & 8:
+                rt.fan_streams = [torch.cuda.Stream(device=device) for _ in range(3)]
         for m in self.modules():
             if hasattr(m, "rt"):
                 m.rt = rt

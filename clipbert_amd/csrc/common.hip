@@ -23,4 +23,4 @@ int cb_launch_status(const char* what) {
 }
 
 extern "C" const char* cb_last_error(void) { return g_err; }
-extern "C" int cb_version(void) { return 6; }
+extern "C" int cb_version(void) { return 7; }

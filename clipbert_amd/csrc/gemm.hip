@@ -50,6 +50,9 @@ CB_G8_DECL(256, 256, 2, 4, 2)
 CB_G8_DECL(128, 256, 2, 4, 3)
 CB_G8_DECL(256, 128, 4, 2, 3)
 #undef CB_G8_DECL
+// few rows (tile 9, gemm_skinny.hip)
+bool skinny_covers(const cb_gemm_desc* d, const GP& p);
+int launch_gemm_skinny(const cb_gemm_desc* d, GP& p, hipStream_t st);
 }
 
 // Per-shape launch configurations measured on MI355X (tools/tune_gemm.py sweeps every cb_gemm call of the benchmark
@@ -392,7 +395,7 @@ int gemm_prepare(const cb_gemm_desc* d, Prepared& out) {
     }
     p.a_bytes = (uint32_t)(fast ? d->a_bytes : 0);
     p.b_bytes = (uint32_t)(fast ? d->b_bytes : 0);
-    CB_REQUIRE(d->tile >= 0 && d->tile <= 8, "cb_gemm: bad tile %d", d->tile);
+    CB_REQUIRE(d->tile >= 0 && d->tile <= 9, "cb_gemm: bad tile %d", d->tile);
     CB_REQUIRE(d->xcd_order >= 0 && d->xcd_order <= 2, "cb_gemm: bad xcd_order %d", d->xcd_order);
     CB_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "cb_gemm: dropout_p out of range");
     // vector epilogue: every touched row pointer must be 16-byte (fp32) / 8-byte (bf16) aligned at n%4==0
@@ -430,6 +433,20 @@ int gemm_run(const cb_gemm_desc* d, void* stream, int32_t* plan, bool use_table)
     static const bool no_remap = getenv("CB_GEMM_NO_XCD_REMAP") != nullptr;
     static const bool no_tuned = getenv("CB_GEMM_NO_TUNED") != nullptr;
     int tile = d->tile, xcd = d->xcd_order;
+    // ---- few rows (tile 9): asked for, or M <= 64 -- the heads' products (pooler, classifier MLP, their data gradients), where a 64x64
+    // tile walks the whole reduction as one chain; the four waves of a 32x64 workgroup split it instead (gemm_skinny.hip; in the step
+    // 10-19 us -> 4-6 us per launch, profiles/r06j_skinny_ab.txt).  CB_GEMM_NO_SKINNY=1 restores the tiled kernels.
+    {
+        static const bool no_skinny = getenv("CB_GEMM_NO_SKINNY") != nullptr;
+        const bool covers = skinny_covers(d, p);
+        CB_REQUIRE(tile != 9 || covers, "cb_gemm: tile 9 (few rows) does not cover this problem (bf16, A k-contiguous, B k-contiguous or aligned reduction-major, no batch / K split / row sums)");
+        if (tile == 9 || (tile == 0 && use_table && !no_skinny && covers && d->M <= 64)) {
+            if (plan) { plan[0] = 9; plan[1] = 1; plan[2] = 0; plan[3] = 2; return 0; }
+            static const bool trace_k = getenv("CB_GEMM_TRACE") != nullptr;
+            if (trace_k) fprintf(stderr, "cb_gemm: M=%d N=%d K=%d modes=%d/%d tile=9 (asked %d) few rows\n", d->M, d->N, d->K, d->a_mode, d->b_mode, d->tile);
+            return launch_gemm_skinny(d, p, cb_stream(stream));
+        }
+    }
     // ---- streaming structure (tile 8): asked for, or chosen for the HBM-bound shapes it was built for -- short reduction, many rows
     // (measured on MI355X, profiles/r04c_stream_probe.json; CB_GEMM_NO_STREAM=1 restores the one-workgroup-per-tile kernels)
     {
@@ -573,7 +590,13 @@ extern "C" int cb_gemm(const cb_gemm_desc* d, void* stream) { return gemm_run(d,
 namespace {
 // kernel class of a prepared problem for the grouped kernels, or -1: launched on its own
 int group_class(const cb_gemm_desc* d, const Prepared& pr) {
-    if (!pr.fast || d->batch > 1 || d->a_rowsum || d->zero_fill_pitch || d->tile >= 5 || d->tile == 1 || d->tile == 3) return -1;
+    if (!pr.fast || d->zero_fill_pitch || d->tile >= 5 || d->tile == 1 || d->tile == 3) return -1;
+    if (d->batch > 1 || d->a_rowsum) {
+        // strided batches and bias row sums: the unsplit bf16 weight-gradient form on the 128x128 two-per-CU tile only (GC_WGRAD_RS: the
+        // encoder's four kinds of 12-layer weight gradients share one grid -- their last waves of tiles fill each other's)
+        const bool ok = d->dtype == CB_BF16 && d->a_mode == CB_KROW && d->b_mode == CB_KROW && d->split_k <= 1 && d->tile != 2 && !d->c_rowmap;
+        return ok ? GC_WGRAD_RS : -1;
+    }
     if (d->a_mode == CB_KROW && d->b_mode == CB_KROW) return GC_WGRAD;
     if (d->a_mode == CB_KROW && d->b_mode == CB_KROW_GATHER) return GC_WGRAD_GATHER;
     if (d->a_mode == CB_ROWK && d->b_mode == CB_ROWK) return GC_FWD;
@@ -641,7 +664,10 @@ int launch_group_chunk(std::vector<GroupItem*>& g, int dtype, int cls, hipStream
         const int asked = g[0]->d->tile;
         bool narrow = false;
         for (auto* it : g) narrow = narrow || it->d->N <= 64;
-        if (asked == 2 || asked == 4) {                              // explicit: the caller's tile and splits
+        if (cls == GC_WGRAD_RS) {                                    // (one tile, no K split: see group_class)
+            tile = 4;
+            for (size_t i = 0; i < g.size(); ++i) splits[i] = 1;
+        } else if (asked == 2 || asked == 4) {                       // explicit: the caller's tile and splits
             tile = asked;
             for (size_t i = 0; i < g.size(); ++i) splits[i] = g[i]->d->split_k > 0 ? g[i]->d->split_k : 1;
         } else {
@@ -720,7 +746,7 @@ int launch_group_chunk(std::vector<GroupItem*>& g, int dtype, int cls, hipStream
             cnt_tiles += tiles;
         }
         if (d->xcd_order != 0) xcd = d->xcd_order;
-        acc += (int64_t)((d->M + B - 1) / B) * ((d->N + B - 1) / B) * p.split_k;
+        acc += (int64_t)((d->M + B - 1) / B) * ((d->N + B - 1) / B) * p.split_k * (p.batch > 1 ? p.batch : 1);
         CB_REQUIRE(acc < (1ll << 30), "cb_gemm_group: too many workgroups");
         ga.tile_end[i] = (int)acc;
         CB_STAMP_ASSIGN(p, d, tile, p.split_k, 0, (int)i, (int)g.size());

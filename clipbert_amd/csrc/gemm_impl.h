@@ -726,6 +726,20 @@ __device__ __forceinline__ float act_of(int act, float v) {
     return apply_act(act, v);
 }
 
+// FrozenBN / bias-with-scale: x * scale + shift.  bf16 mode: ONE fused multiply-add, written as such in every path of the library, so that
+// kernels of different structure stay bit-identical whatever -ffp-contract decides per call site.  fp32 parity mode: the product is
+// rounded before the addition -- the two roundings of the reference's `x * self.weight + self.bias` (and of the oracle), so that ReLU
+// masks and max-pool ties downstream are decided on the same bits (tests/test_model_small.py holds the emulator build to 2e-3 per element).
+template <typename T>
+__device__ __forceinline__ float scale_shift(float x, float sc, float sh) {
+    if constexpr (sizeof(T) == 2) return __builtin_fmaf(x, sc, sh);
+    else {
+#pragma clang fp contract(off)
+        const float t = x * sc;
+        return t + sh;
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void epilogue_vec(const GP& p, f32x4 v, int m, int64_t orow, int nb) {
     v = v * p.alpha;
@@ -740,7 +754,11 @@ __device__ __forceinline__ void epilogue_vec(const GP& p, f32x4 v, int m, int64_
         store4(c, p.post_scale ? v * load4(p.post_scale + nb) : v);
         return;
     }
-    if (p.scale && p.shift) v = __builtin_elementwise_fma(v, load4(p.scale + nb), load4(p.shift + nb));
+    if (p.scale && p.shift) {
+        const f32x4 sc = load4(p.scale + nb), sh = load4(p.shift + nb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = scale_shift<T>(v[r], sc[r], sh[r]);
+    }
     else if (p.scale) v = v * load4(p.scale + nb);
     else if (p.shift) v = v + load4(p.shift + nb);
     if (p.act == CB_ACT_GELU_SAVE_GRAD && p.C2) {
@@ -807,7 +825,7 @@ __device__ __forceinline__ void epilogue_elem(const GP& p, float x, int m, int64
         *c = from_f32<T>(p.post_scale ? x * p.post_scale[n] : x);
         return;
     }
-    if (p.scale && p.shift) x = __builtin_fmaf(x, p.scale[n], p.shift[n]);
+    if (p.scale && p.shift) x = scale_shift<T>(x, p.scale[n], p.shift[n]);
     else if (p.scale) x *= p.scale[n];
     else if (p.shift) x += p.shift[n];
     if (p.act == CB_ACT_GELU_SAVE_GRAD && p.C2) {
@@ -967,7 +985,7 @@ __device__ __forceinline__ void epilogue8(const GP& p, float (&v)[8], const floa
     // -ffp-contract decides per call site
     if (p.scale && p.shift) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = __builtin_fmaf(v[r], sc[r], sh[r]);
+        for (int r = 0; r < 8; ++r) v[r] = scale_shift<T>(v[r], sc[r], sh[r]);
     } else if (p.scale) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] *= sc[r];
@@ -1939,12 +1957,20 @@ enum { GC_WGRAD = 0,        // A KROW, B KROW            (weight gradient of a L
        GC_WGRAD_GATHER = 1, // A KROW, B KROW_GATHER     (weight gradient of a convolution: pixels gathered)
        GC_FWD = 2,          // A ROWK, B ROWK            (Linear / 1x1 stride-1 convolution forward)
        GC_FWD_GATHER = 3,   // A ROWK_GATHER, B ROWK     (convolution forward)
-       GC_COUNT = 4 };
+       GC_WGRAD_RS = 4,     // GC_WGRAD whose members may carry a_rowsum (bias gradients as MFMA row sums) and a strided batch: the encoder's
+                            // four kinds of 12-layer weight gradients in ONE launch (bf16, 128x128 two-per-CU tile only)
+       GC_COUNT = 5 };
 
 // stream-K launcher: bf16 weight-gradient classes only (A KROW, B KROW | KROW_GATHER, transpose-read loaders)
 template <typename T, int BM, int BN, int PF, int OCC>
 int launch_gemm_group(const GroupArgs& ga, int cls, hipStream_t st) {
     const dim3 grid((unsigned)ga.tile_end[ga.n - 1]);
+    if constexpr (sizeof(T) == 2 && BM == 128 && BN == 128 && OCC == 2) {
+        if (cls == GC_WGRAD_RS) {
+            hipLaunchKernelGGL((gemm_group_kernel<T, BM, BN, KrowTr<BM, KM_PLAIN>, KrowTr<BN, KM_PLAIN>, PF, true, OCC>), grid, dim3(NTHREADS), 0, st, ga);
+            return cb_launch_status("cb_gemm_group");
+        }
+    }
 #define CB_LAUNCH_GROUP(LA_, LB_)                                                                                     \
     do {                                                                                                              \
         hipLaunchKernelGGL((gemm_group_kernel<T, BM, BN, LA_, LB_, PF, false, OCC>), grid, dim3(NTHREADS), 0, st, ga); \

@@ -213,6 +213,7 @@ class Runtime:
                                                          # tiles filled by the next one's first)
         self.fan_streams = []                            # bit 3: three more streams (the fourth branch is the issuing stream)
         self.group_wgrads = os.environ.get("CB_NO_GROUP_WGRAD") is None     # ResNet weight gradients per stage through cb_gemm_group
+        self.group_enc_wgrads = os.environ.get("CB_NO_GROUP_ENC_WGRAD") is None   # the encoder's four batched weight-gradient kinds in one grouped launch
         self.group_fwd_pairs = os.environ.get("CB_GROUP_FWD_PAIRS", "0") == "1"   # shortcut + conv1 of the strided stage entries in one launch: measured SLOWER (profiles/r04f: +0.1 ms; the grouped gather kernel runs the pair in 106 us against 47 + 24 apart) -- kept as a switch
         self._side_refs = []
 
@@ -872,6 +873,16 @@ def _encoder_wgrads(model, pk, gs, M):
         fresh = False
     if not fresh:
         bank.fold_invalidate()                       # (a second backward of the step accumulates: the first one's norm shares are void)
+    if all_batched and rt.group_enc_wgrads and rt.dtype == torch.bfloat16:
+        # all four kinds in ONE grouped launch (cb_gemm_group's row-sum / strided-batch class): 48 problems' 5184 tiles of 128x128 share a
+        # grid, so only one last wave of tiles runs on a part-filled chip instead of four (profiles/r06k_enc_wgrad_group_ab.txt)
+        descs = []
+        for g, x, n, k, gws, gbs, kind in kinds:
+            slots = bank.fold_take(ops.sq_slot_count(n, k, nl), "enc:" + kind) if fresh else None
+            descs.append(ops.gemm_desc(g, x, n, k, M, out=gws[0], a_mode=KROW, lda=n, b_mode=KROW, ldb=k, ldc=k, accumulate=not fresh, a_rowsum=gbs[0],
+                                       batch=nl, batch_strides=(M * n, M * k, _uniform_stride(gws), _uniform_stride(gbs)), sq_slots=slots, tile=4))
+        ops.gemm_group(descs, gs.out)
+        return
     fan = rt.fan_streams if (rt.overlap & 8 and all_batched) else []
     if fan:
         fork = torch.cuda.Event()

@@ -4,6 +4,7 @@ These are plumbing only: argument marshalling, output allocation with torch (dev
 error propagation.  All arithmetic happens in libclipbert_hip.so.
 """
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -127,6 +128,14 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch
     return out
 
 
+def gemm_plan(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: torch.Tensor, use_table: bool = True, **kw):
+    """cb_gemm_plan: (tile, split_k, schedule, xcd_order) cb_gemm would launch this call with; launches nothing."""
+    d = gemm_desc(a, b, M, N, K, out=out, **kw)
+    plan = (C.c_int32 * 4)()
+    _chk(_lib.get().cb_gemm_plan(C.byref(d), 1 if use_table else 0, plan), "cb_gemm_plan")
+    return tuple(plan)
+
+
 def gemm_group(descs, like: torch.Tensor):
     """cb_gemm_group: the INDEPENDENT problems ``descs`` (gemm_desc results; no output overlaps another problem's output or
     operands) in as few launches as the library manages, on ``like``'s current stream."""
@@ -140,6 +149,23 @@ def gemm_group(descs, like: torch.Tensor):
 
 
 _LAUNCH_OVERRIDE = {}                  # (a_mode, b_mode, M, N, K, batch, taps, split_k) -> (tile, xcd_order, split_k, schedule); tuning only
+_TILE_ID = {"128x128": 1, "64x64": 2, "128x64": 3, "128x128o2": 4, "8w256x256": 5, "8w128x256": 6, "8w256x128": 7}
+
+
+def parse_launch_config(name: str):
+    """'8w256x256/xcd/s1/m0' -> (tile, xcd_order, split_k, schedule): the configuration names of tools/tune_gemm.py"""
+    parts = name.split("/")
+    tile = _TILE_ID[parts[0]]
+    xcd = 1 if parts[1] == "xcd" else 2
+    split = ([int(x[1:]) for x in parts[2:] if x[0] == "s"] or [0])[0]
+    sched = ([int(x[1:]) + 1 for x in parts[2:] if x[0] == "m"] or [0])[0]
+    return (tile, xcd, split or (1 if tile >= 5 else 0), sched)
+
+
+# diagnostics (A/B calls): CB_LAUNCH_OVERRIDE="a_mode,b_mode,M,N,K,batch,taps,split_k=config;..." pins launch configurations of problem shapes
+for _item in filter(None, os.environ.get("CB_LAUNCH_OVERRIDE", "").split(";")):
+    _k, _, _c = _item.partition("=")
+    _LAUNCH_OVERRIDE[tuple(int(x) for x in _k.split(","))] = parse_launch_config(_c)
 _SPLITK_WS = {}
 _SPLITK_OFF = False                    # set while launches go to a SIDE stream (Runtime.side): the buffer belongs to the main stream's launches
 _SPLITK_SIDE = None                    # set while launches go to a side stream that OWNS a scratch of its own (Runtime.side with side_ws)

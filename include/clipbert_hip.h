@@ -97,7 +97,10 @@ typedef struct {
                                  to auto); 8 = the streaming structure for HBM-bound products with K <= 256 and 10^4+
                                  rows (persistent workgroups, weights resident in LDS, next A tile and the epilogue's
                                  operands in flight while a tile is stored: the ResNet's 1x1 convolutions of res2 / res3
-                                 and their data gradients; an error where it does not cover the problem)  */
+                                 and their data gradients; an error where it does not cover the problem); 9 = few rows
+                                 (bf16, A k-contiguous, B k-contiguous or 16-byte-aligned reduction-major, one problem): 32 x 64
+                                 output tiles whose four waves SPLIT the reduction and meet in LDS -- taken by itself for
+                                 M <= 64 (the heads' products and their data gradients); an error where it does not cover the problem */
     int32_t xcd_order;        /* workgroup -> tile order: 0 auto, 1 = XCD-compact (each XCD, with its own L2, owns a
                                  contiguous run of tiles), 2 = dispatch order (consecutive tiles round-robin over XCDs) */
     int64_t a_bytes, b_bytes; /* sizes of the A / B buffers in bytes (0 = unknown).  When both are known, < 2 GiB
@@ -404,7 +407,8 @@ const char* cb_last_error(void);
  * 5 = the K-split arrival counters live in the tail of cb_gemm_desc.splitk_ws (CB_SPLITK_WS_COUNTER_BYTES, zeroed once by the caller)
  *     instead of a library-owned allocation: a caller of version 4 that passes a scratch must zero its last 64 KiB once;
  * 6 = cb_gemm_desc grew by sq_slots / sq_slots_n at its END (zero = off: older callers that memset the struct they allocate with the
- *     new size are unaffected), accumulate = 2 (first writer), cb_sq_sum_fold */
+ *     new size are unaffected), accumulate = 2 (first writer), cb_sq_sum_fold;
+ * 7 = cb_gemm_desc.tile = 9 (few rows), chosen by itself for M <= 64: the same result up to the order of the fp32 additions */
 int cb_version(void);
 
 /* ---- gradient exchange (one process per GPU, RCCL over xGMI) ----------------------------------------------------

@@ -335,3 +335,34 @@ def test_first_writer_batched_weight_gradients_with_bias_row_sums(hw):
     torch.testing.assert_close(db.cpu(), g.float().cpu().sum(1), **tol(dt))
     want = float((dw.double() ** 2).sum())
     assert abs(float(slots.double().sum()) - want) <= 1e-5 * want
+
+
+def test_group_of_batched_weight_gradients_with_bias_row_sums(hw):
+    """round 6: the encoder's FOUR kinds of layer-batched weight gradients (different out x in shapes, same row count) in one grouped launch
+    (the row-sum / strided-batch class, 128x128 two-per-CU tile): every problem bit-equal to its own cb_gemm launch on the same tile,
+    bias gradients and norm shares included"""
+    dt = torch.bfloat16
+    nl, m = 3, 200
+    kinds = [(136, 264), (264, 136), (72, 72), (200, 72)]
+    descs, outs, refs = [], [], []
+    for i, (n, k) in enumerate(kinds):
+        g, x = hw(rnd(nl, m, n, seed=10 + 2 * i).to(dt)), hw(rnd(nl, m, k, seed=11 + 2 * i).to(dt))
+        pair = []
+        for grouped in (True, False):
+            dw = torch.full((nl, n, k), float("nan"), device=hw.dev)
+            db = torch.zeros(nl, n, device=hw.dev)
+            slots = torch.zeros(ops.sq_slot_count(n, k, nl), device=hw.dev)
+            kw = dict(out=dw[0], a_mode=ops.KROW, lda=n, b_mode=ops.KROW, ldb=k, ldc=k, accumulate=False, a_rowsum=db[0], batch=nl,
+                      batch_strides=(m * n, m * k, n * k, n), sq_slots=slots, tile=4)
+            if grouped:
+                descs.append(ops.gemm_desc(g, x, n, k, m, **kw))
+            else:
+                ops.gemm(g, x, n, k, m, **kw)
+            pair.append((dw, db, slots))
+        outs.append(pair)
+        refs.append((torch.einsum("lmn,lmk->lnk", g.float().cpu(), x.float().cpu()), g.float().cpu().sum(1)))
+    ops.gemm_group(descs, outs[0][0][0])
+    for (grp, single), (ref_w, ref_b) in zip(outs, refs):
+        torch.testing.assert_close(grp[0].cpu(), ref_w, **tol(dt))
+        torch.testing.assert_close(grp[1].cpu(), ref_b, **tol(dt))
+        assert torch.equal(grp[0], single[0]) and torch.equal(grp[1], single[1]) and torch.equal(grp[2], single[2])

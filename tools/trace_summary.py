@@ -19,6 +19,8 @@ def gemm_name(n):
             return "cb_gemm streaming"
         bm, bn, kt, epi = m.groups()
         return f"cb_gemm streaming {bm}x{bn} K<={int(kt) * 64} bf16 (persistent, weights resident): fwd 1x1 conv" + ("" if epi == "0" else " + residual")
+    if "gemm_skinny_kernel" in n:                       # few rows (tile 9): <B reduction-major>
+        return "cb_gemm few rows 32x64 bf16 (waves split K): " + ("dgrad linear" if re.search(r"gemm_skinny_kernel(<true>|ILb1E)", n) else "fwd linear")
     if "splitk_reduce_kernel" in n:
         return "cb_gemm split-K reduce (slabs -> epilogue)"
     d8 = re.search(r"gemm8_kernel<(\d+), (\d+), \d+, \d+, \d+, (\d), cbgemm::(\w+)<\d+, (\w+)>, cbgemm::(\w+)<\d+, (\w+)>, (\w+)>", n)

@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 MFMA peak (2:1 sparsity excluded)
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05z_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06y_pmc_traffic.json")
 
 BASE_CONFIG = dict(
     max_temporal_position_embeddings=100, backbone_channel_in_size=2048, max_grid_row_position_embeddings=100,
@@ -359,6 +359,11 @@ def main():
             import tune_instep
             tune_instep.run(lambda: capture(device_step_single)[0], host_prepare, os.environ["CB_BENCH_TUNE"],
                             os.environ.get("CB_BENCH_TUNE_CAND", os.path.join(ROOT, "profiles", "r03f_gemm_tuning_cold.json")), mode=args.mode)
+            g1, loss = capture(device_step_single)
+        if os.environ.get("CB_BENCH_TUNE_WGRAD") and train and chains == 1:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import tune_instep
+            tune_instep.run_wgrad_groups(lambda: capture(device_step_single)[0], host_prepare, os.environ["CB_BENCH_TUNE_WGRAD"])
             g1, loss = capture(device_step_single)
 
         def run_single():

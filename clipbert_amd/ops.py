@@ -88,6 +88,8 @@ def gemm_desc(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, out: 
     d.dropout_p = dropout_p
     d.dropout_seed = dropout_seed
     d.dropout_seed_ptr = _ptr(seed_ptr)
+    if _KEY_LOG is not None:                 # tools/tune_instep.py: the problem shapes of a step
+        _KEY_LOG.append((a_mode, b_mode, M, N, K, batch, R * S, split_k))
     if tile == 0 and _LAUNCH_OVERRIDE:       # tools/tune_instep.py: a launch configuration under test for this problem shape
         ov = _LAUNCH_OVERRIDE.get((a_mode, b_mode, M, N, K, batch, R * S, split_k))
         if ov is not None:
@@ -148,6 +150,7 @@ def gemm_group(descs, like: torch.Tensor):
     _chk(_lib.get().cb_gemm_group(C.cast(arr, C.c_void_p), n, _stream(like)), "cb_gemm_group")
 
 
+_KEY_LOG = None                        # a list while tools/tune_instep.py records the keys of a step's problems
 _LAUNCH_OVERRIDE = {}                  # (a_mode, b_mode, M, N, K, batch, taps, split_k) -> (tile, xcd_order, split_k, schedule); tuning only
 _TILE_ID = {"128x128": 1, "64x64": 2, "128x64": 3, "128x128o2": 4, "8w256x256": 5, "8w128x256": 6, "8w256x128": 7}
 

@@ -101,3 +101,66 @@ def run(capture_step, host_prepare, out_path, cand_path, mode="train", max_shape
     print(f"[instep] table vs table + overrides (ms/step, 3 rounds): {ab}", file=sys.stderr, flush=True)
     json.dump(dict(device=torch.cuda.get_device_name(0), baseline_ms=round(base0, 4), final_ms=round(cur, 4), confirm_ab=ab,
                    overrides=[dict(key=list(k), config=v) for k, v in kept.items()], log=log), open(out_path, "w"), indent=1)
+
+
+def run_wgrad_groups(capture_step, host_prepare, out_path, keep_margin_ms=0.008):
+    """The ResNet's grouped weight gradients (cb_gemm_group): tile and K split of every problem SHAPE judged by the captured step
+    (CB_BENCH_TUNE_WGRAD=<out.json> python bench.py).  An override makes the descriptor explicit (tile 2 / 4 + split_k as given:
+    cb_gemm_group keeps the caller's numbers), so the group's own cost model is bypassed for that shape only."""
+    from clipbert_amd import ops
+    ops._KEY_LOG = []
+    g = capture_step()
+    keys = [k for k in ops._KEY_LOG if k[0] == 2 and k[1] in (2, 4) and k[5] == 1 and k[4] >= 2048]      # A KROW, B KROW / KROW_GATHER, long reductions
+    ops._KEY_LOG = None
+    count = {}
+    for k in keys:
+        count[k] = count.get(k, 0) + 1
+    order = sorted(count, key=lambda k: -count[k] * k[2] * k[3] * k[4])
+    for _ in range(3):
+        cur = time_graph(g, host_prepare)
+    base0 = cur
+    print(f"[wgrad] baseline {cur:.3f} ms/step; {len(order)} shapes: {order}", file=sys.stderr, flush=True)
+    kept, log = {}, []
+    for key in order:
+        tiles128 = ((key[2] + 127) // 128) * ((key[3] + 127) // 128) * count[key]
+        kt = (key[4] + 63) // 64
+        cands = []
+        for tile in (4, 2):
+            for split in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32):
+                wgs = tiles128 * (1 if tile == 4 else 4) * split
+                if split > 1 and (kt // split < 4 or wgs > 4096):
+                    continue
+                if wgs < 96:
+                    continue
+                cands.append((tile, 1, split, 0))
+        best_c, best_t, trials = None, cur, {}
+        for c in cands:
+            ops._LAUNCH_OVERRIDE[key] = c
+            try:
+                g2 = capture_step()
+                t = time_graph(g2, host_prepare, reps=10, best_of=2)
+            except Exception as e:                          # noqa: BLE001
+                trials[f"{c[0]}/s{c[2]}"] = str(e)[:80]
+                ops._LAUNCH_OVERRIDE.pop(key, None)
+                continue
+            trials[f"{c[0]}/s{c[2]}"] = round(t, 4)
+            if t < best_t - keep_margin_ms:
+                best_c, best_t = c, t
+            del g2
+        if best_c is not None:
+            ops._LAUNCH_OVERRIDE[key] = best_c
+            kept[key] = best_c
+            cur = best_t
+        else:
+            ops._LAUNCH_OVERRIDE.pop(key, None)
+        log.append(dict(key=list(key), launches=count[key], trials=trials, kept=best_c, step_ms=round(cur, 4)))
+        print(f"[wgrad] {key} n={count[key]}: {trials} -> {'KEEP ' + str(best_c) if best_c else 'auto'} ({cur:.3f} ms)", file=sys.stderr, flush=True)
+    g_final = capture_step()
+    saved = dict(ops._LAUNCH_OVERRIDE)
+    ops._LAUNCH_OVERRIDE.clear()
+    g_base = capture_step()
+    ops._LAUNCH_OVERRIDE.update(saved)
+    ab = [(round(time_graph(g_base, host_prepare), 4), round(time_graph(g_final, host_prepare), 4)) for _ in range(3)]
+    print(f"[wgrad] auto vs overrides (ms/step, 3 rounds): {ab}", file=sys.stderr, flush=True)
+    json.dump(dict(device=torch.cuda.get_device_name(0), baseline_ms=round(base0, 4), final_ms=round(cur, 4), confirm_ab=ab,
+                   overrides=[dict(key=list(k), config=list(v)) for k, v in kept.items()], log=log), open(out_path, "w"), indent=1)

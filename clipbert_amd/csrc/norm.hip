@@ -458,37 +458,39 @@ __global__ void __launch_bounds__(256) visual_embed_fwd_kernel(const T* grid, co
     }
 }
 
-// one thread per (token, 4 channels): scatter-add into the table gradients
-// Embedding-table gradients.  One block column per sequence position, threads over 4-wide feature chunks, a loop over
-// (a slice of) the batch: the position / token-type / row / column sums accumulate in registers and reach memory as ONE
-// atomic per block and element (the naive one-atomic-per-token form serialises B*L updates on the same few rows: 120 us
-// for the 32x32-token bench batch).  Word rows still take one atomic per token (distinct rows, little contention).
-constexpr int EMB_BSLICES = 4;      // (16 slices were measured in round 4: 2.3x SLOWER -- every extra slice adds a full set of same-address atomics on the position / type rows)
-
+// Embedding-table gradients.  One launch, two kinds of blocks:
+//  * "sum" blocks, one per sequence position: the position / token-type (/ grid row / column) gradients are sums over the batch -- the
+//    block adds its B rows in registers (independent loads, one memory round trip) and reaches memory with ONE atomic per element
+//    (the naive one-atomic-per-token form serialises B*L updates on the same few rows: 120 us for the 32x32-token bench batch);
+//  * "scatter" blocks, one WAVE per token: the word-table row (/ the frames' grid cells) of that token takes the token's gradient
+//    (distinct rows, little contention), B*L/4 blocks in flight instead of a loop over the batch inside L blocks.
+// Round 6: the two roles used to share a block that walked a quarter of the batch in a dependent loop (30 / 21 us for the bench batch).
 template <typename T>
 __global__ void __launch_bounds__(256) text_embed_bwd_kernel(const T* dpre, const int64_t* ids, float* dword, float* dpos,
                                                              float* dtype0, int B, int Lt, int Ltot, int D, int64_t pad_id, int period) {
-    const int t = blockIdx.x;
-    const int per = (B + gridDim.y - 1) / gridDim.y;
-    const int b0 = blockIdx.y * per, b1 = (b0 + per < B) ? b0 + per : B;
-    for (int e = threadIdx.x * 4; e < D; e += blockDim.x * 4) {
-        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-        for (int b = b0; b < b1; ++b) {
-            const f32x4 g = load4(dpre + ((int64_t)b * Ltot + t) * D + e);
-            const int64_t id = ids[(int64_t)(b % period) * Lt + t];
-            sum = sum + g;
-            if (id != pad_id) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) atomicAdd(dword + id * D + e + i, g[i]);
-            }
-        }
-        if (b1 > b0) {
+    if ((int)blockIdx.x < Lt) {                                      // ---- sum block of position t
+        const int t = blockIdx.x;
+        for (int e = threadIdx.x * 4; e < D; e += blockDim.x * 4) {
+            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int b = 0; b < B; ++b) sum = sum + load4(dpre + ((int64_t)b * Ltot + t) * D + e);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 atomicAdd(dpos + (int64_t)t * D + e + i, sum[i]);
                 atomicAdd(dtype0 + e + i, sum[i]);
             }
         }
+        return;
+    }
+    const int tok = ((int)blockIdx.x - Lt) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // ---- scatter: one wave per token
+    if (tok >= B * Lt) return;
+    const int b = tok / Lt, t = tok - b * Lt;
+    const int64_t id = ids[(int64_t)(b % period) * Lt + t];
+    if (id == pad_id) return;
+    for (int e = lane * 4; e < D; e += 256) {
+        const f32x4 g = load4(dpre + ((int64_t)b * Ltot + t) * D + e);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(dword + id * D + e + i, g[i]);
     }
 }
 
@@ -496,31 +498,36 @@ template <typename T>
 __global__ void __launch_bounds__(256) visual_embed_bwd_kernel(const T* dpre, const int32_t* src_row, const int32_t* sel,
                                                                float* dgrid, float* drow, float* dcol, float* dtype0, int B,
                                                                int Tf, int Hg, int Wg, int Lv, int Lt, int Ltot, int D) {
-    const int pidx = blockIdx.x;
-    const int q = sel ? sel[pidx] : pidx;
-    const int h = q / Wg, w = q % Wg;
-    const int per = (B + gridDim.y - 1) / gridDim.y;
-    const int b0 = blockIdx.y * per, b1 = (b0 + per < B) ? b0 + per : B;
-    const float inv = 1.0f / (float)Tf;
-    for (int e = threadIdx.x * 4; e < D; e += blockDim.x * 4) {
-        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-        for (int b = b0; b < b1; ++b) {
-            const int64_t src = src_row ? src_row[b] : b;
-            const f32x4 g = load4(dpre + ((int64_t)b * Ltot + Lt + pidx) * D + e);
-            sum = sum + g;
-            for (int t = 0; t < Tf; ++t) {
-                float* dst = dgrid + (((src * Tf + t) * Hg + h) * Wg + w) * D + e;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) atomicAdd(dst + i, g[i] * inv);
-            }
-        }
-        if (b1 > b0) {
+    if ((int)blockIdx.x < Lv) {                                      // ---- sum block of visual position pidx
+        const int pidx = blockIdx.x;
+        const int q = sel ? sel[pidx] : pidx;
+        const int h = q / Wg, w = q % Wg;
+        for (int e = threadIdx.x * 4; e < D; e += blockDim.x * 4) {
+            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int b = 0; b < B; ++b) sum = sum + load4(dpre + ((int64_t)b * Ltot + Lt + pidx) * D + e);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 atomicAdd(drow + (int64_t)h * D + e + i, sum[i]);
                 atomicAdd(dcol + (int64_t)w * D + e + i, sum[i]);
                 atomicAdd(dtype0 + e + i, sum[i]);
             }
+        }
+        return;
+    }
+    const int tok = ((int)blockIdx.x - Lv) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // ---- scatter: one wave per (b, position)
+    if (tok >= B * Lv) return;
+    const int b = tok / Lv, pidx = tok - b * Lv;
+    const int q = sel ? sel[pidx] : pidx;
+    const int h = q / Wg, w = q % Wg;
+    const int64_t src = src_row ? src_row[b] : b;
+    const float inv = 1.0f / (float)Tf;
+    for (int e = lane * 4; e < D; e += 256) {
+        const f32x4 g = load4(dpre + ((int64_t)b * Ltot + Lt + pidx) * D + e);
+        for (int t = 0; t < Tf; ++t) {
+            float* dst = dgrid + (((src * Tf + t) * Hg + h) * Wg + w) * D + e;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomicAdd(dst + i, g[i] * inv);
         }
     }
 }
@@ -670,7 +677,7 @@ extern "C" int cb_text_embed_bwd(int32_t dtype, const void* dpre, const int64_t*
     CB_REQUIRE(dpre && ids && dword && dpos && dtype0 && D % 4 == 0 && rows_period >= 0 && rows_period <= B, "cb_text_embed_bwd: bad arguments");
     if ((int64_t)B * Lt == 0) return 0;
     const int period = rows_period > 0 ? rows_period : B;
-    dim3 g((unsigned)Lt, (unsigned)(B < EMB_BSLICES ? B : EMB_BSLICES)), b(256);
+    dim3 g((unsigned)(Lt + ((int64_t)B * Lt + 3) / 4)), b(256);
     if (dtype == CB_BF16) hipLaunchKernelGGL((text_embed_bwd_kernel<bf16>), g, b, 0, cb_stream(stream), (const bf16*)dpre, ids, dword, dpos, dtype0, B, Lt, L_total, D, pad_id, period);
     else if (dtype == CB_F32) hipLaunchKernelGGL((text_embed_bwd_kernel<float>), g, b, 0, cb_stream(stream), (const float*)dpre, ids, dword, dpos, dtype0, B, Lt, L_total, D, pad_id, period);
     else return cb_fail("cb_text_embed_bwd: bad dtype");
@@ -682,7 +689,7 @@ extern "C" int cb_visual_embed_bwd(int32_t dtype, const void* dpre, const int32_
                                    int32_t Lv, int32_t Lt, int32_t L_total, int32_t D, void* stream) {
     CB_REQUIRE(dpre && dgrid && drow && dcol && dtype0 && D % 4 == 0 && T > 0, "cb_visual_embed_bwd: bad arguments");
     if ((int64_t)B * Lv == 0) return 0;
-    dim3 g((unsigned)Lv, (unsigned)(B < EMB_BSLICES ? B : EMB_BSLICES)), b(256);
+    dim3 g((unsigned)(Lv + ((int64_t)B * Lv + 3) / 4)), b(256);
     if (dtype == CB_BF16) hipLaunchKernelGGL((visual_embed_bwd_kernel<bf16>), g, b, 0, cb_stream(stream), (const bf16*)dpre, src_row, sel, dgrid, drow, dcol, dtype0, B, T, Hg, Wg, Lv, Lt, L_total, D);
     else if (dtype == CB_F32) hipLaunchKernelGGL((visual_embed_bwd_kernel<float>), g, b, 0, cb_stream(stream), (const float*)dpre, src_row, sel, dgrid, drow, dcol, dtype0, B, T, Hg, Wg, Lv, Lt, L_total, D);
     else return cb_fail("cb_visual_embed_bwd: bad dtype");

@@ -86,7 +86,16 @@ __global__ void __launch_bounds__(1024) sum_two_final_kernel(const float* a, int
     __shared__ float red[16];
     float s = 0.f;
     for (int i = threadIdx.x; i < na; i += 1024) s += a[i];
-    for (int64_t i = threadIdx.x; i < nb; i += 1024) s += b[i];
+    // (eight independent loads per trip: the ~25 k slots of a step used to be a chain of dependent memory round trips, 14 us)
+    int64_t i = threadIdx.x;
+    for (; i + 7 * 1024 < nb; i += 8 * 1024) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = b[i + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; i < nb; i += 1024) s += b[i];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();

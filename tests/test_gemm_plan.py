@@ -46,7 +46,10 @@ def test_large_untuned_shapes_take_the_8_wave_tiles():
 
 
 def test_small_and_narrow_shapes_stay_on_the_4_wave_tiles():
-    assert plan(64, 2, 1536)[0] == 2                             # a head: one 64x64 tile
+    assert plan(64, 2, 1536)[0] == 9                             # a head (M <= 64): the few-rows structure, the waves split K (round 6)
+    assert plan(64, 2, 1536, use_table=0)[0] == 2                # ... the model alone: one 64x64 tile
+    assert plan(64, 768, 1536, b_mode=2)[0] == 9                 # its data gradient (reduction-major weights)
+    assert plan(64, 768, 64, a_mode=2, b_mode=2, c_f32=True, accumulate=True)[0] != 9      # weight-gradient forms stay on the tiles
     assert plan(300, 768, 768)[0] in (2, 3)
     assert plan(200000, 64, 576)[0] in (2, 3)                    # N <= 64 never takes a 128-column tile
 
@@ -123,8 +126,10 @@ def test_random_calls_get_legal_plans():
             continue                                                             # (row-contiguous loads of the KROW forms want 8-element rows)
         tile, split, sched, xcd = plan(M, N, K, a_mode=a_mode, b_mode=b_mode, c_f32=wg, accumulate=wg, ws=ws, use_table=rng.random() < 0.5)
         ktiles = -(-K // 64)
-        assert tile in (1, 2, 3, 4, 5, 6, 7, 8) and 1 <= split <= max(1, ktiles) and xcd in (1, 2), (M, N, K, tile, split)
-        if tile == 8:                                              # the streaming structure: only what it was built for
+        assert tile in (1, 2, 3, 4, 5, 6, 7, 8, 9) and 1 <= split <= max(1, ktiles) and xcd in (1, 2), (M, N, K, tile, split)
+        if tile == 9:                                              # few rows: forward / data-gradient forms of M <= 64, never split
+            assert M <= 64 and not wg and split == 1 and sched == 0 and (b_mode == 0 or N % 8 == 0), (M, N, K)
+        elif tile == 8:                                              # the streaming structure: only what it was built for
             seen_stream += 1
             assert (a_mode, b_mode) == (0, 0) and not wg and K <= 128 and N % 128 == 0 and N <= 512 and M >= 32768 and split == 1, (M, N, K)
             assert sched == (0 if K <= 64 else 1) and (K > 64 or N % 256 == 0)

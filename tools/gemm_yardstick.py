@@ -100,6 +100,41 @@ def encoder_rows(M=2624, nl=12):
     return rows
 
 
+def wgrad_set(M=2624, nl=12):
+    """round 6: ALL weight gradients of the encoder (four kinds x 12 layers) as the step issues them -- one cb_gemm_group launch (row-sum /
+    strided-batch class) -- next to four cb_gemm launches and to the library's four bmm calls, each set timed as a whole (hot)."""
+    from clipbert_amd import ops
+    dev, dt = "cuda", torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(1)
+    rnd = lambda *s: (torch.rand(*s, device=dev, generator=g, dtype=torch.float32) - 0.5).to(dt)
+    kinds, flop = [], 0.0
+    for name, N, K in (("FFN2", 768, 3072), ("FFN1", 3072, 768), ("attn.out", 768, 768), ("QKV", 2304, 768)):
+        xs, gs = rnd(nl, M, K), rnd(nl, M, N)
+        kinds.append(dict(N=N, K=K, xs=xs, gs=gs, dw16=torch.empty(nl, N, K, device=dev, dtype=dt), dw32=torch.empty(nl, N, K, device=dev, dtype=torch.float32),
+                          db=torch.zeros(nl, N, device=dev, dtype=torch.float32)))
+        flop += 2.0 * M * N * K * nl
+
+    def lib():
+        for k in kinds:
+            torch.bmm(k["gs"].transpose(1, 2), k["xs"], out=k["dw16"])
+
+    def kw(k):
+        return dict(out=k["dw32"][0], a_mode=ops.KROW, lda=k["N"], b_mode=ops.KROW, ldb=k["K"], ldc=k["K"], accumulate=False, a_rowsum=k["db"][0], batch=nl,
+                    batch_strides=(M * k["N"], M * k["K"], k["N"] * k["K"], k["N"]))
+
+    def four():
+        for k in kinds:
+            ops.gemm(k["gs"], k["xs"], k["N"], k["K"], M, **kw(k))
+
+    def one():
+        ops.gemm_group([ops.gemm_desc(k["gs"], k["xs"], k["N"], k["K"], M, tile=4, **kw(k)) for k in kinds], kinds[0]["gs"])
+
+    res = dict(gflop=flop / 1e9, hipblaslt_four_bmm=round(graph_time(lib, 8), 1), cb_gemm_four_launches=round(graph_time(four, 8), 1),
+               cb_gemm_group_one_launch=round(graph_time(one, 8), 1))
+    res["tflops"] = {k: round(res["gflop"] / v * 1e3) for k, v in res.items() if k != "gflop"}
+    return res
+
+
 CONVS = [  # (name, cin, cout, k, stride, H_in) at 64 frames of 224 px
     ("stem 7x7 s2", 3, 64, 7, 2, 224),
     ("res2 conv2 3x3", 64, 64, 3, 1, 56), ("res2 conv3 1x1", 64, 256, 1, 1, 56), ("res2 conv1 1x1", 256, 64, 1, 1, 56),
@@ -184,8 +219,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "yardstick"))
     ap.add_argument("--skip-conv", action="store_true")
+    ap.add_argument("--wgrad-set", action="store_true", help="only the encoder's whole weight-gradient set: one grouped launch vs four vs the library")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
+    if a.wgrad_set:
+        res = wgrad_set()
+        print(json.dumps(res))
+        with open(os.path.join(a.out, "wgrad_set.json"), "w") as f:
+            json.dump(res, f, indent=1)
+        return
     enc = encoder_rows()
     with open(os.path.join(a.out, "yardstick.json"), "w") as f:
         json.dump({"encoder": enc}, f, indent=1)

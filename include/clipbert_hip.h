@@ -165,7 +165,9 @@ int cb_gemm_workspace_bytes(const cb_gemm_desc* d, int64_t* bytes);
 /* `n` INDEPENDENT problems in as few launches as possible: the same results as n cb_gemm calls (no problem's output may overlap
  * another problem's output or operands), but problems that run the same kernel class -- weight gradients of Linear / 1x1
  * convolutions, weight gradients of gathered convolutions, plain forward products, gathered forward products; fast path (16-byte
- * aligned operands < 2 GiB), no strided batch, no a_rowsum -- share ONE grid: every workgroup looks its (problem, tile) up in a
+ * aligned operands < 2 GiB); a strided batch and a_rowsum only on unsplit bf16 weight gradients of Linear layers (A and B CB_KROW,
+ * tile 0 / 4: their own class on the 128x128 two-per-CU tile -- the encoder's four kinds of 12-layer weight gradients,
+ * src/modeling/transformers.py:257-381 under autograd, are ONE launch whose last wave of tiles is shared) -- share ONE grid: every workgroup looks its (problem, tile) up in a
  * table that travels in the kernel arguments (capturable as is).  A launch of many small problems fills the 256 CUs where each
  * alone is a fraction of a round of workgroups: the weight gradients of all convolutions of a ResNet stage
  * (src/modeling/grid_feat.py:95 under autograd: one cuDNN call each) become two launches instead of ~13.  Everything else in the

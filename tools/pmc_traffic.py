@@ -43,11 +43,13 @@ def gemm_dispatches(d):
 def xcd_floor(p):
     """Bytes a product must move when 8 non-coherent L2s each serve 1/8 of the tiles: every XCD fetches the operand panels its tiles touch.
     With the tiles of an XCD forming an (M / xm) x (N / xn) block (xm * xn = 8), A is fetched xn times and B xm times; outputs and epilogue
-    operands once.  The best split is the floor; a launch cannot do better without cross-XCD sharing, whatever its tile order.  (1x1 /
-    linear forms only: K = the reduction length, A = M x K, B = N x K in bf16.)"""
-    if p["taps"] != 1:
-        return None
+    operands once.  The best split is the floor; a launch cannot do better without cross-XCD sharing, whatever its tile order.  (K = the reduction length, A = M x K, B = N x K
+    in bf16; round 6: convolutions too, with the pixel operand counted once per tap-free element.)"""
     a, b = 2.0 * p["M"] * p["K"] * p["batch"], 2.0 * p["N"] * p["K"] * p["batch"]
+    if p["taps"] != 1:                        # implicit-GEMM convolution: the pixel operand holds M x K / taps unique elements (halo rows of a tile not
+        if p["form"] == "wgrad":              # counted: a floor); the filter is the N x K operand
+            return p["bytes"]
+        a = a / p["taps"]
     rest = max(0.0, p["bytes"] - a - b)
     if p["form"] == "wgrad":                 # the reduction is the long axis: an XCD can own a K range instead (split-K), no operand re-read
         return p["bytes"]

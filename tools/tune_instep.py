@@ -8,6 +8,7 @@ carry most of the step's GEMM time it overrides the launch configuration (clipbe
 hipGraph and times its replays -- coordinate descent, one shape at a time, a candidate is kept only if the step gets faster by more than
 the noise.  The result is merged into csrc/gemm_tuned.h by tools/gen_tuned.py --instep <out.json>."""
 import json
+import os
 import sys
 
 import torch
@@ -116,6 +117,8 @@ def run_wgrad_groups(capture_step, host_prepare, out_path, keep_margin_ms=0.008)
     for k in keys:
         count[k] = count.get(k, 0) + 1
     order = sorted(count, key=lambda k: -count[k] * k[2] * k[3] * k[4])
+    if os.environ.get("CB_TUNE_WGRAD_8W"):
+        order = [k for k in order if k[6] == 9]              # the 3x3 convolutions' weight gradients
     for _ in range(3):
         cur = time_graph(g, host_prepare)
     base0 = cur
@@ -125,7 +128,14 @@ def run_wgrad_groups(capture_step, host_prepare, out_path, keep_margin_ms=0.008)
         tiles128 = ((key[2] + 127) // 128) * ((key[3] + 127) // 128) * count[key]
         kt = (key[4] + 63) // 64
         cands = []
-        for tile in (4, 2):
+        if os.environ.get("CB_TUNE_WGRAD_8W"):             # the 8-wave LDS-DMA tiles, launched on their own (cb_gemm_group keeps tiles >= 5 out of its grids), slab K split
+            for tile, bm, bn in ((5, 256, 256), (6, 128, 256), (7, 256, 128)):
+                t8 = ((key[2] + bm - 1) // bm) * ((key[3] + bn - 1) // bn)
+                for split in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
+                    if t8 * split < 64 or t8 * split > 1024 or (split > 1 and kt // split < 4):
+                        continue
+                    cands.append((tile, 1, split, 1))
+        for tile in ((4, 2) if not os.environ.get("CB_TUNE_WGRAD_8W") else ()):
             for split in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32):
                 wgs = tiles128 * (1 if tile == 4 else 4) * split
                 if split > 1 and (kt // split < 4 or wgs > 4096):

@@ -205,6 +205,11 @@ __device__ __forceinline__ void tile_epilogue8w(GP& p, f32x4 (&acc)[BM / WGM / 1
                                                 int tid, float* slab, int tile_lin = 0) {
     using T = bf16;
     {
+        // (not on the 256x256 forward / data-gradient kernels: with the sixteen bodies compiled in, that instantiation -- 9 k instructions
+        // instead of 3 k -- ran EVERY epilogue, the generic one included, 1.5-1.7x slower per launch: 10496 x 2304 x 768 + bias 65 -> 100 us,
+        // profiles/r06u_tile5_epilogue_bodies.txt; the metric step has no such launch, the inference row does.  Its weight-gradient
+        // instantiation holds one body only, the fp32 store with the norm share.)
+        if constexpr (!(BM == 256 && BN == 256) || WG)
         if (!slab && p.fast_epi != 0 && (WG == (p.fast_epi == FAST_EPI_F32))) {                         // specialised body for this call's option combination (gemm_impl.h fast_epilogue)
             constexpr int WM_ = BM / WGM, WN_ = BN / WGN, FN_ = WN_ / 16, SROW_ = BN * 4 + 16, SUB_ = WM_ / PR;
             static_assert(WM_ % PR == 0 && PR * SROW_ <= SMEM_BYTES, "epilogue staging");

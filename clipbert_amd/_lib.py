@@ -131,7 +131,8 @@ def load(path: str = LIB_PATH):
 def get():
     global _LIB
     if _LIB is None:
-        _LIB = load()
+        variant = os.environ.get("CB_LIB_VARIANT")        # diagnostics: a copy built by `python -m clipbert_amd.build --variant NAME ...`
+        _LIB = load(os.path.join(os.path.dirname(LIB_PATH), f"libclipbert_hip_{variant}.so")) if variant else load()
     return _LIB
 
 

@@ -200,7 +200,7 @@ template <int ROWS, int KMODE> struct KrowDma8 {
 // executes ONCE, i.e. entirely out of instruction-cache misses: ~1.1 us per chunk, 9 us for a bias-only 128x256 tile, 17 us for FFN1's
 // GELU + two outputs (longer than its 11 us K loop).  The pass loop and the chunk loop are therefore ROLLED: one copy of the body, warm
 // after its first trip.  Only the accumulator -> LDS staging needs compile-time register indices: a switch over the WM / PR row blocks.
-template <int BM, int BN, int WGM, int WGN, int SMEM_BYTES, int PR = 64, bool WG = false>
+template <int BM, int BN, int WGM, int WGN, int SMEM_BYTES, int PR = 64, bool WG = false, int FORM = 0>
 __device__ __forceinline__ void tile_epilogue8w(GP& p, f32x4 (&acc)[BM / WGM / 16][BN / WGN / 16], unsigned char* smem, int m0, int n0,
                                                 int tid, float* slab, int tile_lin = 0) {
     using T = bf16;
@@ -210,7 +210,7 @@ __device__ __forceinline__ void tile_epilogue8w(GP& p, f32x4 (&acc)[BM / WGM / 1
         // profiles/r06u_tile5_epilogue_bodies.txt; the metric step has no such launch, the inference row does.  Its weight-gradient
         // instantiation holds one body only, the fp32 store with the norm share.)
         if constexpr (!(BM == 256 && BN == 256) || WG)
-        if (!slab && p.fast_epi != 0 && (WG == (p.fast_epi == FAST_EPI_F32))) {                         // specialised body for this call's option combination (gemm_impl.h fast_epilogue)
+        if (!slab && p.fast_epi != 0 && (WG == (p.fast_epi == FAST_EPI_F32)) && fe_in_form(p.fast_epi, FORM)) {                         // specialised body for this call's option combination (gemm_impl.h fast_epilogue)
             constexpr int WM_ = BM / WGM, WN_ = BN / WGN, FN_ = WN_ / 16, SROW_ = BN * 4 + 16, SUB_ = WM_ / PR;
             static_assert(WM_ % PR == 0 && PR * SROW_ <= SMEM_BYTES, "epilogue staging");
             const int lane_ = tid & 63, wave_ = tid >> 6;
@@ -232,7 +232,7 @@ __device__ __forceinline__ void tile_epilogue8w(GP& p, f32x4 (&acc)[BM / WGM / 1
                     }
                 }
             };
-            fast_epilogue_dispatch<NT8, BN, PR, BM / PR, WG>(p, smem, m0, n0, tid, stage, nullptr, nullptr, tile_lin);
+            fast_epilogue_dispatch<NT8, BN, PR, BM / PR, WG, FORM>(p, smem, m0, n0, tid, stage, nullptr, nullptr, tile_lin);
             return;
         }
     }
@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(NT8, 2) gemm8_kernel(GP p, float* ws) {
         }
     }
     CB_STAMP(2);
-    tile_epilogue8w<BM, BN, WGM, WGN, SMEM_BYTES, 64, LA::TR>(p, acc, smem, m0, n0, tid, slab, (zbatch * (int)gridDim.y + bid.by) * (int)gridDim.x + bid.bx);
+    tile_epilogue8w<BM, BN, WGM, WGN, SMEM_BYTES, 64, LA::TR, (LA::TR ? 0 : (LB::TR ? 2 : 1))>(p, acc, smem, m0, n0, tid, slab, (zbatch * (int)gridDim.y + bid.by) * (int)gridDim.x + bid.bx);
     CB_STAMP(3);
     CB_STAMP_FLUSH(p, stamp_lin, tid);
 }

@@ -1287,7 +1287,18 @@ __device__ __forceinline__ void fast_epilogue(const GP& p, unsigned char* smem, 
 // runtime index -> compile-time combination (a wave-uniform switch: the kernel argument lives in SGPRs)
 // WG: a weight-gradient kernel (both operands reduction-major): the only combination it ever meets is the stored fp32 C; the other forms
 // never meet that one -- neither instantiates what it cannot run.
-template <int NT, int BN, int PR, int NPASS, bool WG = false, typename StageFn>
+// FORM: what the kernel's loaders say about the product -- 0 unknown, 1 forward (B k-contiguous), 2 data gradient (B reduction-major).
+// fe_in_form: a kernel instantiates only the combinations its form meets in the model (forward: plain, bias, GELU + derivative, bias
+// (+ dropout) + residual, the FrozenBN forms; data gradient: plain, x stored derivative, + residual, x scale under a mask, the fused
+// ReLU x FrozenBN backward); a call with another combination takes the generic epilogue.  Eight bodies per kernel instead of fifteen:
+// 7.718 -> 7.701 ms per step, three alternating pairs (profiles/r06w_epilogue_bodies_per_form.txt) -- and see gemm8_impl.h
+// tile_epilogue8w for what ALL of them did to the 256x256 instantiation.
+__host__ __device__ constexpr bool fe_in_form(int idx, int form) {
+    if (form == 1) return idx == 1 || idx == 2 || idx == 3 || idx == 4 || idx == 5 || idx == 8 || idx == 9 || idx == 10;
+    if (form == 2) return idx == 1 || idx == 6 || idx == 7 || idx >= 11;
+    return true;
+}
+template <int NT, int BN, int PR, int NPASS, bool WG = false, int FORM = 0, typename StageFn>
 __device__ __forceinline__ void fast_epilogue_dispatch(const GP& p, unsigned char* smem, int m0, int n0, int tid, StageFn stage,
                                                        const bf16x8* pre_r = nullptr, const bf16x8* pre_a = nullptr, int tile_lin = 0) {
     if constexpr (WG) {
@@ -1295,7 +1306,7 @@ __device__ __forceinline__ void fast_epilogue_dispatch(const GP& p, unsigned cha
         return;
     }
     switch (p.fast_epi) {
-#define CB_FE_CASE(I) case I: fast_epilogue<FAST_EPI_COMBOS[I], NT, BN, PR, NPASS>(p, smem, m0, n0, tid, stage, pre_r, pre_a); break;
+#define CB_FE_CASE(I) case I: if constexpr (fe_in_form(I, FORM)) fast_epilogue<FAST_EPI_COMBOS[I], NT, BN, PR, NPASS>(p, smem, m0, n0, tid, stage, pre_r, pre_a); break;
         CB_FE_CASE(1) CB_FE_CASE(2) CB_FE_CASE(3) CB_FE_CASE(4) CB_FE_CASE(5) CB_FE_CASE(6) CB_FE_CASE(7) CB_FE_CASE(8) CB_FE_CASE(9) CB_FE_CASE(10)
         CB_FE_CASE(11) CB_FE_CASE(12) CB_FE_CASE(13) CB_FE_CASE(14) CB_FE_CASE(15)
 #undef CB_FE_CASE
@@ -1346,7 +1357,7 @@ __device__ __forceinline__ void epi_prefetch(const GP& p, EpiPre<BM, BN, WITH_R>
 // ---------------------------------------------------------------------------------------------
 // Tile epilogue shared by both kernel structures.  acc[i][j] = 4 consecutive n of row m (swapped MFMA operands).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int SMEM_BYTES, int EPF = 0, bool WG = false>
+template <typename T, int BM, int BN, int SMEM_BYTES, int EPF = 0, bool WG = false, int FORM = 0>
 __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 32], unsigned char* smem, int m0, int n0, int tid,
                                               const EpiPre<BM, BN, EPF != 1>& pre = EpiPre<BM, BN, EPF != 1>{}, bool use_pre = false, int tile_lin = 0) {
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
@@ -1355,7 +1366,7 @@ __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 
     if (p.dropout_p > 0.f && p.seed_ptr) p.seed += *p.seed_ptr;
     const bool fast = p.c_vec && (n0 + BN <= p.N);      // block-uniform
     if constexpr (sizeof(T) == 2) {
-        if (p.c_vec8 && p.fast_epi != 0 && (WG == (p.fast_epi == FAST_EPI_F32))) {                    // specialised body for this call's option combination (block-uniform)
+        if (p.c_vec8 && p.fast_epi != 0 && (WG == (p.fast_epi == FAST_EPI_F32)) && fe_in_form(p.fast_epi, FORM)) {                    // specialised body for this call's option combination (block-uniform)
             static_assert((BM / 2) * (BN * 4 + 16) <= SMEM_BYTES, "staging does not fit");
             auto stage = [&](int h) __attribute__((always_inline)) {
                 if (wm == h) {
@@ -1370,7 +1381,7 @@ __device__ __forceinline__ void tile_epilogue(GP& p, f32x4 (&acc)[BM / 32][BN / 
             const bf16x8* pre_a = nullptr;
             if constexpr (EPF == 2) { if (use_pre) pre_r = pre.r; }
             if constexpr (EPF != 0) { if (use_pre) pre_a = pre.a; }
-            fast_epilogue_dispatch<NTHREADS, BN, BM / 2, 2, WG>(p, smem, m0, n0, tid, stage, pre_r, pre_a, tile_lin);
+            fast_epilogue_dispatch<NTHREADS, BN, BM / 2, 2, WG, FORM>(p, smem, m0, n0, tid, stage, pre_r, pre_a, tile_lin);
             return;
         }
     }
@@ -1748,8 +1759,9 @@ __device__ __forceinline__ void gemm_tile(GP& p, TileId bid, float* slab = nullp
         if (tid == 0) atomicExch(cnt + p.cnt_base + tile_lin, 0);           // ready for the next launch (same stream: ordered)
         p.split_k = 1;                                                      // the epilogue below is the plain one
     }
-    if constexpr (EPF != 0) tile_epilogue<T, BM, BN, SMEM_BYTES, EPF>(p, acc, smem, m0, n0, tid, epre, epf_on);
-    else tile_epilogue<T, BM, BN, SMEM_BYTES, 0, LA::KROW>(p, acc, smem, m0, n0, tid, EpiPre<BM, BN, true>{}, false, tile_lin);
+    constexpr int FORM_ = LA::KROW ? 0 : (LB::KROW ? 2 : 1);
+    if constexpr (EPF != 0) tile_epilogue<T, BM, BN, SMEM_BYTES, EPF, false, FORM_>(p, acc, smem, m0, n0, tid, epre, epf_on);
+    else tile_epilogue<T, BM, BN, SMEM_BYTES, 0, LA::KROW, FORM_>(p, acc, smem, m0, n0, tid, EpiPre<BM, BN, true>{}, false, tile_lin);
     CB_STAMP(3);
     CB_STAMP_FLUSH(p, stamp_lin, tid);
 }

@@ -341,6 +341,7 @@ int gemm_prepare(const cb_gemm_desc* d, Prepared& out) {
             if (d->shift) flags |= EF_SHIFT;
             if (d->act == CB_ACT_RELU) flags |= EF_RELU;
             else if (d->act == CB_ACT_GELU_SAVE_GRAD && d->C2) flags |= EF_GELU2;
+            else if (d->act == CB_ACT_GELU && !d->C2) flags |= EF_GELU1;
             else if (d->act == CB_ACT_SAVED_GRAD && d->gelu_grad_pre) flags |= EF_MULAUX;
             else if (d->act != CB_ACT_NONE) ok = false;
             if (d->C2 && !(flags & EF_GELU2)) ok = false;                    // (a second output only as the stored derivative)

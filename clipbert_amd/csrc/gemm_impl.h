@@ -58,7 +58,8 @@ struct GP {
 enum { EF_SCALE = 1, EF_SHIFT = 2, EF_RELU = 4, EF_GELU2 = 8, EF_DROP = 16, EF_RES = 32, EF_RELU_AFTER = 64, EF_MASK = 128, EF_MULAUX = 256,
        EF_RBWD = 512,      // cb_gemm_desc.relu_bwd: t = (acc [+ residual]) where mask > 0; C2 = t [* post_scale2]; C = t * post_scale
        EF_PS2 = 1024,
-       EF_F32 = 2048 };    // fp32 C STORED (accumulate 0 / 2), nothing else: the weight-gradient forms; + the tile's share of the squared norm
+       EF_F32 = 2048,      // fp32 C STORED (accumulate 0 / 2), nothing else: the weight-gradient forms; + the tile's share of the squared norm
+       EF_GELU1 = 4096 };  // C = gelu(.), no second output (inference)
 constexpr int FAST_EPI_COMBOS[] = {
     -1,                                                  // 0: generic
     0,                                                   // 1: C = acc                                  (data gradients without epilogue, grid conv)
@@ -77,6 +78,7 @@ constexpr int FAST_EPI_COMBOS[] = {
     EF_RBWD | EF_PS2,                                    //        (projection shortcut: second output x its FrozenBN scale)
     EF_RBWD | EF_PS2 | EF_RES,
     EF_F32,                                              // 16: dW stored by its first writer (+ sum of squares to GP::sq_slots) -- weight-gradient kernels only
+    EF_SHIFT | EF_GELU1,                                 // 17: C = gelu(. + bias)                        (BertIntermediate forward, inference)
 };
 constexpr int FAST_EPI_F32 = 16;
 constexpr int FAST_EPI_N = sizeof(FAST_EPI_COMBOS) / sizeof(int);
@@ -1111,7 +1113,7 @@ __device__ __forceinline__ void fast_epilogue(const GP& p, unsigned char* smem, 
     static_assert(PR * CPR % NT == 0 && NT % CPR == 0, "chunk map");
     constexpr bool HAS_RES = (FLAGS & EF_RES) != 0, HAS_AUX = (FLAGS & (EF_MASK | EF_MULAUX | EF_RBWD)) != 0;
     constexpr bool ALL = NCH <= 8;                               // every chunk's operands in flight at once, else pass by pass
-    constexpr bool ROLL = (FLAGS & EF_GELU2) != 0 || NPASS > 2;
+    constexpr bool ROLL = (FLAGS & (EF_GELU2 | EF_GELU1)) != 0 || NPASS > 2;
     const int cc = tid % CPR, n = n0 + cc * 8, rl0 = tid / CPR;
     const bool nok = n < p.N;
     const unsigned char* const read_base = smem + rl0 * SROW + cc * 32;
@@ -1212,6 +1214,10 @@ __device__ __forceinline__ void fast_epilogue(const GP& p, unsigned char* smem, 
             for (int r = 0; r < 4; ++r) gelu_erf_both2(v[r], v[r], dv[r]);
             __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(dv), rc2, (uint32_t)m * ldc2b + nb, 0, 16 /* sc1 */);
         }
+        if constexpr ((FLAGS & EF_GELU1) != 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { f32x2 dv; gelu_erf_both2(v[r], v[r], dv); }
+        }
         if constexpr ((FLAGS & EF_RELU) != 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = f32x2{fmaxf(v[r][0], 0.f), fmaxf(v[r][1], 0.f)};
@@ -1248,7 +1254,7 @@ __device__ __forceinline__ void fast_epilogue(const GP& p, unsigned char* smem, 
         __syncthreads();
         stage(h);
         __syncthreads();
-        if constexpr ((FLAGS & EF_GELU2) != 0) {
+        if constexpr ((FLAGS & (EF_GELU2 | EF_GELU1)) != 0) {
 #pragma unroll 1
             for (int it = 0; it < ITER; ++it) chunk(h, it, 0);
         } else {
@@ -1294,8 +1300,8 @@ __device__ __forceinline__ void fast_epilogue(const GP& p, unsigned char* smem, 
 // 7.718 -> 7.701 ms per step, three alternating pairs (profiles/r06w_epilogue_bodies_per_form.txt) -- and see gemm8_impl.h
 // tile_epilogue8w for what ALL of them did to the 256x256 instantiation.
 __host__ __device__ constexpr bool fe_in_form(int idx, int form) {
-    if (form == 1) return idx == 1 || idx == 2 || idx == 3 || idx == 4 || idx == 5 || idx == 8 || idx == 9 || idx == 10;
-    if (form == 2) return idx == 1 || idx == 6 || idx == 7 || idx >= 11;
+    if (form == 1) return idx == 1 || idx == 2 || idx == 3 || idx == 4 || idx == 5 || idx == 8 || idx == 9 || idx == 10 || idx == 17;
+    if (form == 2) return idx == 1 || idx == 6 || idx == 7 || (idx >= 11 && idx <= 15);
     return true;
 }
 template <int NT, int BN, int PR, int NPASS, bool WG = false, int FORM = 0, typename StageFn>
@@ -1308,12 +1314,12 @@ __device__ __forceinline__ void fast_epilogue_dispatch(const GP& p, unsigned cha
     switch (p.fast_epi) {
 #define CB_FE_CASE(I) case I: if constexpr (fe_in_form(I, FORM)) fast_epilogue<FAST_EPI_COMBOS[I], NT, BN, PR, NPASS>(p, smem, m0, n0, tid, stage, pre_r, pre_a); break;
         CB_FE_CASE(1) CB_FE_CASE(2) CB_FE_CASE(3) CB_FE_CASE(4) CB_FE_CASE(5) CB_FE_CASE(6) CB_FE_CASE(7) CB_FE_CASE(8) CB_FE_CASE(9) CB_FE_CASE(10)
-        CB_FE_CASE(11) CB_FE_CASE(12) CB_FE_CASE(13) CB_FE_CASE(14) CB_FE_CASE(15)
+        CB_FE_CASE(11) CB_FE_CASE(12) CB_FE_CASE(13) CB_FE_CASE(14) CB_FE_CASE(15) CB_FE_CASE(17)
 #undef CB_FE_CASE
         default: break;
     }
 }
-static_assert(FAST_EPI_N == 17 && FAST_EPI_COMBOS[FAST_EPI_F32] == EF_F32, "fast_epilogue_dispatch lists every combination");
+static_assert(FAST_EPI_N == 18 && FAST_EPI_COMBOS[FAST_EPI_F32] == EF_F32, "fast_epilogue_dispatch lists every combination");
 
 // ---------------------------------------------------------------------------------------------
 // Epilogue-operand prefetch (row-contiguous bf16 epilogue only).  The epilogue's global READS -- the residual and the ReLU mask

@@ -250,3 +250,20 @@ def test_lazy_dma_emulation():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "not gpu", "-k",
                         "not lazy_dma", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=3000)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_inference_gelu_body_equals_the_generic_epilogue_bit_for_bit(hw):
+    """round 6: bias + GELU WITHOUT the stored derivative (BertIntermediate in inference) has a specialised epilogue body (combination 17)
+    on the 128x256 / 256x128 8-wave tiles and the 4-wave tiles; the 256x256 forward kernel carries no specialised bodies (generic
+    epilogue8).  Same packed GELU everywhere: all five tiles agree bit for bit, and with PyTorch within the bf16 bound."""
+    M, N, K = 300, 264, 64 * 3 + 8
+    x, w, b = hw(rnd(M, K, seed=1).to(BF)), hw(rnd(N, K, seed=2, scale=0.1).to(BF)), hw(rnd(N, seed=3))
+    ref = F.gelu(x.float() @ w.float().t() + b)
+    outs = []
+    for tile in (5, 6, 7, 4, 2):
+        y = torch.empty(M, N, dtype=BF, device=hw.dev)
+        ops.gemm(x, w, M, N, K, out=y, shift=b, act=ops.ACT_GELU, tile=tile)
+        torch.testing.assert_close(y.float(), ref, **TOL)
+        outs.append(y)
+    for y in outs[1:]:
+        assert torch.equal(y, outs[0])

@@ -359,7 +359,7 @@ def main():
             import tune_instep
             tune_instep.run(lambda: capture(device_step_single)[0], host_prepare, os.environ["CB_BENCH_TUNE"],
                             os.environ.get("CB_BENCH_TUNE_CAND", os.path.join(ROOT, "profiles", "r03f_gemm_tuning_cold.json")),
-                            mode=os.environ.get("CB_BENCH_TUNE_MODE", args.mode), max_shapes=int(os.environ.get("CB_BENCH_TUNE_SHAPES", "45")))
+                            mode=os.environ.get("CB_BENCH_TUNE_MODE", args.mode), max_shapes=int(os.environ.get("CB_BENCH_TUNE_SHAPES", "45")), max_cands=int(os.environ.get("CB_BENCH_TUNE_CANDS", "4")))
             g1, loss = capture(device_step_single)
         if os.environ.get("CB_BENCH_TUNE_WGRAD") and train and chains == 1:
             sys.path.insert(0, os.path.join(ROOT, "tools"))

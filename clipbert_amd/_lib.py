@@ -46,6 +46,7 @@ _SIGNATURES = {
     "cb_gemm": [C.POINTER(GemmDesc), vp],
     "cb_res2_block": [C.POINTER(Res2Desc), vp],
     "cb_stem_pool": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "cb_stem_pool_u8": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "cb_gemm_plan": [vp, i32, vp],
     "cb_gemm_group": [vp, i32, vp],
     "cb_gemm_workspace_bytes": [vp, vp],

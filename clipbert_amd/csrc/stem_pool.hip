@@ -28,11 +28,14 @@ constexpr int PC = 64 * 2 + 16;              // LDS pitch of a 64-channel row
 struct StemP {
     const bf16* img; bf16* out; const bf16* w; const float* scale; const float* shift;
     int N, Hp, Wp, OH, OW, PH, PW, tiles_h, tiles_w, ntiles;
+    // U8 (cb_stem_pool_u8, round 6): the frames themselves, (N, 3, H, W) uint8 RGB planes -- ImageNorm, the RGB -> BGR flip and the zero padding
+    // of cb_stem_pack happen while the input tile moves into LDS (same arithmetic, same bits); Hp / Wp are then the PADDED extents H + 6, W + 8
+    const uint8_t* src8; int H, W; f32x4 mean, istd;
 };
 
 // NT threads: 256 (4 waves: each owns 16 channels and all 19 row fragments) or 512 (8 waves: the two wave groups split the row fragments
 // -- twice the waves per SIMD to hide the LDS / MFMA latency chains of a tile; same LDS footprint).
-template <int NT>
+template <int NT, bool U8 = false>
 __global__ void __launch_bounds__(NT, 2) stem_pool_kernel(StemP p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[IR * IP + NFRAG * 16 * PC];
     unsigned char* const Is = smem;
@@ -68,12 +71,68 @@ __global__ void __launch_bounds__(NT, 2) stem_pool_kernel(StemP p) {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int idx = tid + it * NT;
-            if (idx < TOTAL) *reinterpret_cast<u32x4*>(Is + (idx / ICH) * IP + (idx % ICH) * 16) = v[it];
+            if (idx < TOTAL) {
+                const u32x4 o = v[it];
+                *reinterpret_cast<u32x4*>(Is + (idx / ICH) * IP + (idx % ICH) * 16) = o;
+            }
+        }
+    };
+    // U8: a thread owns 8 consecutive source pixels of one tile row (4 chunks: 39 rows x 5 runs = 195 tasks): three 8-byte loads, one per
+    // colour plane, when the whole run lies inside the frame (unaligned: the run starts 3 pixels left of an even column), guarded byte loads
+    // on the frame's border.  The raw bytes stay in registers while the current tile is convolved; stash8 applies ImageNorm + BGR0 exactly as
+    // cb_stem_pack does -- ((float)byte - mean) * (1 / std), channel c <- plane 2 - c, zeros outside the frame -- on the way into LDS.
+    constexpr int RUNS = ICH / 4;
+    static_assert(ICH % 4 == 0 && IR * RUNS <= NT, "one run of 8 pixels per thread");
+    auto fetch8 = [&](int tile, uint32_t (&raw)[7]) __attribute__((always_inline)) {
+        const int tw = tile % p.tiles_w, rest = tile / p.tiles_w;
+        const int th = rest % p.tiles_h, n = rest / p.tiles_h;
+        const int r = tid / RUNS, g = tid % RUNS;
+        const int sy = 2 * (2 * th * PT - 1) + r - 3, sx0 = 2 * (2 * tw * PT - 1) + 8 * g - 3;
+        const bool row = tile < p.ntiles && tid < IR * RUNS && (unsigned)sy < (unsigned)p.H;
+        uint32_t mask = 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mask |= (row && (unsigned)(sx0 + j) < (unsigned)p.W) ? (1u << j) : 0u;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) raw[i] = 0u;
+        raw[6] = mask;
+        if (mask == 0u) return;
+        const size_t plane = (size_t)p.H * p.W;
+        const uint8_t* q = p.src8 + ((size_t)n * 3 * p.H + sy) * p.W + sx0;
+        if (mask == 0xffu) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) __builtin_memcpy(&raw[2 * c], q + c * plane, 8);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if ((mask >> j) & 1u) raw[2 * c + (j >> 2)] |= (uint32_t)q[c * plane + j] << (8 * (j & 3));
+        }
+    };
+    auto stash8 = [&](const uint32_t (&raw)[7]) __attribute__((always_inline)) {
+        if (tid >= IR * RUNS) return;
+        const int r = tid / RUNS, g = tid % RUNS;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            union { bf16x8 h; u32x4 r; } u;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * k + jj;
+                const bool ok = (raw[6] >> j) & 1u;
+                const float rr = (float)((raw[0 + (j >> 2)] >> (8 * (j & 3))) & 255u), gg = (float)((raw[2 + (j >> 2)] >> (8 * (j & 3))) & 255u),
+                            bb = (float)((raw[4 + (j >> 2)] >> (8 * (j & 3))) & 255u);
+                u.h[4 * jj + 0] = (bf16)(ok ? (bb - p.mean[2]) * p.istd[2] : 0.f);
+                u.h[4 * jj + 1] = (bf16)(ok ? (gg - p.mean[1]) * p.istd[1] : 0.f);
+                u.h[4 * jj + 2] = (bf16)(ok ? (rr - p.mean[0]) * p.istd[0] : 0.f);
+                u.h[4 * jj + 3] = (bf16)0.f;
+            }
+            *reinterpret_cast<u32x4*>(Is + r * IP + (4 * g + k) * 16) = u.r;
         }
     };
     u32x4 nxt[ITERS];
-    fetch(blockIdx.x, nxt);
-    stash(nxt);
+    uint32_t raw8[7];
+    if constexpr (U8) { fetch8(blockIdx.x, raw8); stash8(raw8); }
+    else { fetch(blockIdx.x, nxt); stash(nxt); }
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int tw = tile % p.tiles_w, rest = tile / p.tiles_w;
         const int th = rest % p.tiles_h, n = rest / p.tiles_h;
@@ -81,7 +140,8 @@ __global__ void __launch_bounds__(NT, 2) stem_pool_kernel(StemP p) {
         const int cy0 = 2 * ph0 - 1, cx0 = 2 * pw0 - 1;          // convolution pixel of tile position (0, 0)
         // ---- 1. the input tile is in LDS (stashed behind the previous tile's convolution); the NEXT tile's loads go out now and land
         //         under this tile's convolution
-        fetch(tile + gridDim.x, nxt);
+        if constexpr (U8) fetch8(tile + gridDim.x, raw8);
+        else fetch(tile + gridDim.x, nxt);
         __syncthreads();
         // ---- 2. the 17 x 17 convolution outputs of this wave's 16 channels: FrozenBN + ReLU, zero outside the map, bf16 -> LDS
 #pragma unroll 1
@@ -118,7 +178,8 @@ __global__ void __launch_bounds__(NT, 2) stem_pool_kernel(StemP p) {
             }
         }
         __syncthreads();
-        stash(nxt);                                              // (the convolution is done with the input tile: the next one moves in)
+        if constexpr (U8) stash8(raw8);                          // (the convolution is done with the input tile: the next one moves in)
+        else stash(nxt);
         // ---- 3. 3 x 3 / stride 2 max-pool out of LDS: thread <-> (pooled pixel, 8 channels), 16-byte stores, 128-byte runs per pixel
 #pragma unroll
         for (int it = 0; it < PT * PT * 8 / NT; ++it) {
@@ -148,6 +209,33 @@ __global__ void __launch_bounds__(NT, 2) stem_pool_kernel(StemP p) {
 
 }  // namespace
 
+// cb_stem_pool with cb_stem_pack folded in: uint8 frames -> pooled stem output, one launch (the input pipeline ends in the first
+// convolution's tile loader)
+extern "C" int cb_stem_pool_u8(const uint8_t* frames, const float* mean3, const float* std3, const void* weight, const float* scale,
+                               const float* shift, void* out, int32_t N, int32_t H, int32_t W, int32_t OH, int32_t OW, int32_t PH, int32_t PW,
+                               void* stream) {
+    CB_REQUIRE(frames && mean3 && std3 && weight && scale && shift && out, "cb_stem_pool_u8: null operand");
+    CB_REQUIRE(N > 0 && H > 0 && W > 0 && OH == (H + 6 - 7) / 2 + 1 && OW == (W + 6 - 7) / 2 + 1, "cb_stem_pool_u8: %d x %d frames give a %d x %d convolution output, not %d x %d",
+               H, W, (H + 6 - 7) / 2 + 1, (W + 6 - 7) / 2 + 1, OH, OW);
+    CB_REQUIRE(PH == (OH + 2 - 3) / 2 + 1 && PW == (OW + 2 - 3) / 2 + 1, "cb_stem_pool_u8: pooled size %d x %d does not follow from %d x %d", PH, PW, OH, OW);
+    for (const void* q : {weight, (const void*)scale, (const void*)shift, (const void*)out})
+        CB_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15) == 0, "cb_stem_pool_u8: weight / scale / shift / out must be 16-byte aligned");
+    CB_REQUIRE((int64_t)N * 3 * H * W < (1ll << 40), "cb_stem_pool_u8: too many pixels");
+    StemP p{};
+    p.src8 = frames; p.H = H; p.W = W; p.img = nullptr;
+    for (int c = 0; c < 3; ++c) { p.mean[c] = mean3[c]; p.istd[c] = 1.0f / std3[c]; }
+    p.mean[3] = 0.f; p.istd[3] = 1.f;
+    p.out = (bf16*)out; p.w = (const bf16*)weight; p.scale = scale; p.shift = shift;
+    p.N = N; p.Hp = H + 6; p.Wp = W + 8; p.OH = OH; p.OW = OW; p.PH = PH; p.PW = PW;
+    p.tiles_h = (PH + PT - 1) / PT; p.tiles_w = (PW + PT - 1) / PT;
+    const int64_t nt = (int64_t)N * p.tiles_h * p.tiles_w;
+    CB_REQUIRE(nt < (1ll << 31), "cb_stem_pool_u8: too many tiles");
+    p.ntiles = (int)nt;
+    const int max_wg = cb_persistent_max_workgroups(512);
+    hipLaunchKernelGGL((stem_pool_kernel<512, true>), dim3((unsigned)(nt < max_wg ? nt : max_wg)), dim3(512), 0, cb_stream(stream), p);
+    return cb_launch_status("cb_stem_pool_u8");
+}
+
 extern "C" int cb_stem_pool(const void* packed, const void* weight, const float* scale, const float* shift, void* out, int32_t N,
                             int32_t Hp, int32_t Wp, int32_t OH, int32_t OW, int32_t PH, int32_t PW, void* stream) {
     CB_REQUIRE(packed && weight && scale && shift && out, "cb_stem_pool: null operand");
@@ -155,7 +243,7 @@ extern "C" int cb_stem_pool(const void* packed, const void* weight, const float*
     CB_REQUIRE(Hp >= 2 * (OH - 1) + 7 && Wp >= 2 * (OW - 1) + 8 && Wp % 2 == 0, "cb_stem_pool: packed image %d x %d too small for a %d x %d convolution (cb_stem_pack: pad 3, even width)", Hp, Wp, OH, OW);
     for (const void* q : {packed, weight, (const void*)scale, (const void*)shift, (const void*)out})
         CB_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15) == 0, "cb_stem_pool: operands must be 16-byte aligned");
-    StemP p;
+    StemP p{};
     p.img = (const bf16*)packed; p.out = (bf16*)out; p.w = (const bf16*)weight; p.scale = scale; p.shift = shift;
     p.N = N; p.Hp = Hp; p.Wp = Wp; p.OH = OH; p.OW = OW; p.PH = PH; p.PW = PW;
     p.tiles_h = (PH + PT - 1) / PT; p.tiles_w = (PW + PT - 1) / PT;

@@ -85,6 +85,18 @@ class GemmLog:
             self.launches.append({"problems": [prob], "replay": (lambda: self._stem(packed, weight, scale, shift, oh, ow))})
             return self._stem(packed, weight, scale, shift, oh, ow)
 
+        self._stem8 = ops.stem_pool_u8
+
+        def stem_pool_u8(frames, mean, std, weight, scale, shift):
+            n, _c, h, w = frames.shape
+            oh, ow = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+            m = n * oh * ow
+            pooled = n * ((oh - 1) // 2 + 1) * ((ow - 1) // 2 + 1)
+            prob = {"family": FUSED, "flop": 2.0 * m * 64 * 147, "bytes": float(frames.numel() + pooled * 64 * 2), "M": m, "N": 64, "K": 147, "batch": 1,
+                    "taps": 49, "form": "fwd"}
+            self.launches.append({"problems": [prob], "replay": (lambda: self._stem8(frames, mean, std, weight, scale, shift))})
+            return self._stem8(frames, mean, std, weight, scale, shift)
+
         def res2_block(x, w1, w2, w3, ss1, ss2, ss3, wsc=None, sssc=None):
             n, h, w, cin = x.shape
             m = n * h * w
@@ -106,11 +118,13 @@ class GemmLog:
 
         ops.gemm, ops.gemm_group = gemm, gemm_group
         ops.stem_pool, ops.res2_block = stem_pool, res2_block
+        ops.stem_pool_u8 = stem_pool_u8
         return self
 
     def __exit__(self, *exc):
         ops.gemm, ops.gemm_group = self._gemm, self._group
         ops.stem_pool, ops.res2_block = self._stem, self._res2
+        ops.stem_pool_u8 = self._stem8
         return False
 
     def by_family(self) -> Dict[str, List[dict]]:

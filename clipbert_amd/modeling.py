@@ -414,17 +414,24 @@ def cnn_forward(bb: "GridFeatBackbone", x5: torch.Tensor, save: bool):
     x4 = x5.reshape(n, c, h, w)
     if not x4.is_contiguous():
         x4 = x4.contiguous()
-    if x4.dtype == torch.uint8:
-        packed = ops.stem_pack(x4, rt.dtype, 3, bb.pixel_mean, bb.pixel_std, extra_w=2)
-    else:
-        packed = ops.stem_pack(x4.float(), rt.dtype, 3, extra_w=2)
-    hp, wp = packed.shape[1], packed.shape[2]
     net = bb.feature.backbone
     stem = net.stem.conv1
     oh, ow = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
     m = n * oh * ow
     scale, shift = stem.scale_shift()
-    if rt.dtype == torch.bfloat16 and wp % 2 == 0 and os.environ.get("CB_NO_STEM_FUSE") is None:
+    fuse_stem = rt.dtype == torch.bfloat16 and w % 2 == 0 and os.environ.get("CB_NO_STEM_FUSE") is None
+    packed = None
+    if x4.dtype == torch.uint8 and fuse_stem and os.environ.get("CB_NO_STEM_U8") is None:
+        # uint8 frames straight into the first convolution: ImageNorm, BGR flip and padding inside cb_stem_pool's tile loader (round 6, N4)
+        x = ops.stem_pool_u8(x4, bb.pixel_mean, bb.pixel_std, _stem_weight(rt, stem), scale, shift)
+    elif x4.dtype == torch.uint8:
+        packed = ops.stem_pack(x4, rt.dtype, 3, bb.pixel_mean, bb.pixel_std, extra_w=2)
+    else:
+        packed = ops.stem_pack(x4.float(), rt.dtype, 3, extra_w=2)
+    hp, wp = (packed.shape[1], packed.shape[2]) if packed is not None else (0, 0)
+    if packed is None:
+        pass
+    elif fuse_stem:
         # convolution + FrozenBN + ReLU + max-pool in one launch (the 112 x 112 x 64 map never leaves the CU); CB_NO_STEM_FUSE=1: two launches
         x = ops.stem_pool(packed, _stem_weight(rt, stem), scale, shift, oh, ow)
     else:

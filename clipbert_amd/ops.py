@@ -260,6 +260,19 @@ def stem_pool(packed, weight, scale, shift, oh: int, ow: int) -> torch.Tensor:
     return out
 
 
+def stem_pool_u8(frames: torch.Tensor, mean, std, weight, scale, shift) -> torch.Tensor:
+    """cb_stem_pool_u8: (N, 3, H, W) uint8 RGB frames -> (N, PH, PW, 64) bf16: ImageNorm + BGR flip + zero padding + stem convolution + FrozenBN
+    + ReLU + 3x3/2 max-pool in one launch (cb_stem_pack folded into cb_stem_pool; bit-identical to the two launches)."""
+    n, c, h, w = frames.shape
+    assert frames.dtype == torch.uint8 and frames.is_contiguous() and c == 3 and weight.dtype == torch.bfloat16
+    oh, ow = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+    ph, pw = (oh - 1) // 2 + 1, (ow - 1) // 2 + 1
+    out = torch.empty(n, ph, pw, 64, dtype=torch.bfloat16, device=frames.device)
+    _chk(_lib.get().cb_stem_pool_u8(_ptr(frames), _f3(mean), _f3(std), _ptr(weight), _ptr(scale), _ptr(shift), _ptr(out), n, h, w, oh, ow, ph, pw,
+                                    _stream(frames)), "cb_stem_pool_u8")
+    return out
+
+
 def res2_block(x, w1, w2, w3, ss1, ss2, ss3, wsc=None, sssc=None) -> torch.Tensor:
     """cb_res2_block: one res2 bottleneck block (64 mid channels, stride 1, FrozenBN, forward only) in one launch.  x (N, H, W, cin) bf16
     NHWC; w*: the convolutions' KRSC weight images; ss*: their (scale, shift) fp32 vectors; wsc / sssc: the projection shortcut of the

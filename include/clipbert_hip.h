@@ -220,6 +220,13 @@ int cb_maxpool2_bwd(int32_t dtype, const void* x, const void* y, const void* dy,
  * PH = (OH - 1) / 2 + 1.  Replaces cb_gemm (stem form) + cb_maxpool_fwd: the convolution output never leaves the CU. */
 int cb_stem_pool(const void* packed, const void* weight, const float* scale, const float* shift, void* out, int32_t N, int32_t Hp,
                  int32_t Wp, int32_t OH, int32_t OW, int32_t PH, int32_t PW, void* stream);
+/* cb_stem_pack folded into cb_stem_pool (round 6; SURVEY N4 "GPU input pipeline": the uint8 frames go straight into the first convolution):
+ * frames: (N, 3, H, W) uint8 RGB planes as the loader hands them over; mean3 / std3: HOST arrays of ImageNorm (src/modeling/grid_feat.py /
+ * e2e_model.py: the pixel statistics of the detectron2 config) in RGB order.  (x - mean) / std, the RGB -> BGR flip
+ * (src/modeling/grid_feat.py:92-94) and the convolution's zero padding happen while an input tile moves into LDS -- the same arithmetic
+ * as cb_stem_pack, bit-identical output to cb_stem_pack + cb_stem_pool; one launch and 27 MB of packed image fewer per 64 frames. */
+int cb_stem_pool_u8(const uint8_t* frames, const float* mean3, const float* std3, const void* weight, const float* scale, const float* shift,
+                    void* out, int32_t N, int32_t H, int32_t W, int32_t OH, int32_t OW, int32_t PH, int32_t PW, void* stream);
 
 /* One bottleneck block of the res2 stage in ONE launch, forward only (round 5): detectron2's BottleneckBlock with 64 mid channels,
  * stride 1, FrozenBN (modeling/backbone/resnet.py as built by src/modeling/grid_feat.py:60-70; FREEZE_AT = 2 keeps the stage frozen):
@@ -410,7 +417,8 @@ const char* cb_last_error(void);
  *     instead of a library-owned allocation: a caller of version 4 that passes a scratch must zero its last 64 KiB once;
  * 6 = cb_gemm_desc grew by sq_slots / sq_slots_n at its END (zero = off: older callers that memset the struct they allocate with the
  *     new size are unaffected), accumulate = 2 (first writer), cb_sq_sum_fold;
- * 7 = cb_gemm_desc.tile = 9 (few rows), chosen by itself for M <= 64: the same result up to the order of the fp32 additions */
+ * 7 = cb_gemm_desc.tile = 9 (few rows), chosen by itself for M <= 64: the same result up to the order of the fp32 additions;
+ *     cb_gemm_group takes strided batches / a_rowsum on the unsplit bf16 weight-gradient form; cb_stem_pool_u8 */
 int cb_version(void);
 
 /* ---- gradient exchange (one process per GPU, RCCL over xGMI) ----------------------------------------------------

@@ -124,6 +124,15 @@ def test_stem_pool_equals_conv_then_pool(hw, monkeypatch, n, h, w, maxwg):
     ref_a = ops.maxpool_fwd(y, 3, 2, 1).float().cpu()
     assert got.shape == ref_a.shape
     assert torch.equal(got, ref_a), float((got - ref_a).abs().max())                  # same K order, same rounding points: bit-equal
+    # (a') round 6: the uint8 frames straight into the kernel (cb_stem_pool_u8: ImageNorm + BGR flip + padding in the tile loader): the same bits,
+    # with non-trivial pixel statistics too
+    got8 = ops.stem_pool_u8(frames.to(DEV[0]), mean, std, wk, scale.to(DEV[0]), shift.to(DEV[0])).float().cpu()
+    assert torch.equal(got8, got), float((got8 - got).abs().max())
+    mean2, std2 = (120.0, 110.5, 100.25), (57.0, 58.5, 60.0)
+    packed2 = ops.stem_pack(frames.to(DEV[0]), torch.bfloat16, 3, mean2, std2, extra_w=2)
+    want2 = ops.stem_pool(packed2, wk, scale.to(DEV[0]), shift.to(DEV[0]), oh, ow)
+    got2 = ops.stem_pool_u8(frames.to(DEV[0]), mean2, std2, wk, scale.to(DEV[0]), shift.to(DEV[0]))
+    assert torch.equal(got2, want2)
     # (b) plain PyTorch: BGR, mean-subtracted, bf16 operands, fp32 math
     x = _bf(frames.float()[:, [2, 1, 0]] - torch.tensor(mean)[[2, 1, 0]].view(1, 3, 1, 1))
     conv = F.conv2d(x, _bf(wt), stride=2, padding=3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)

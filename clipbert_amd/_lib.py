@@ -79,6 +79,7 @@ _SIGNATURES = {
     "cb_mean_bwd": [vp, i64, vp, vp],
     "cb_counter_add": [vp, i64, vp],
     "cb_zero": [vp, i64, vp],
+    "cb_zero_ranges": [vp, vp, i32, vp],
     "cb_visual_embed_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "cb_attention_fwd": [i32, vp, vp, vp, vp, i32, i32, i32, f32, u64, vp, vp],
     "cb_attention_bwd": [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, u64, vp, vp],

@@ -480,6 +480,23 @@ __global__ __launch_bounds__(256) void zero_kernel(unsigned char* p, int64_t byt
     if (tid < head) p[tid] = 0;
     if (tid < bytes - tail0) p[tail0 + tid] = 0;
 }
+// up to four ranges in one launch (cb_zero_ranges): blockIdx.y picks the range, the body is zero_kernel's
+struct ZeroRanges { unsigned char* p[4]; int64_t bytes[4]; };
+__global__ __launch_bounds__(256) void zero_ranges_kernel(ZeroRanges zr) {
+    unsigned char* p = zr.p[blockIdx.y];
+    const int64_t bytes = zr.bytes[blockIdx.y];
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    int64_t head = (int64_t)((16 - (a & 15)) & 15);
+    if (head > bytes) head = bytes;
+    const int64_t n16 = (bytes - head) >> 4;
+    u32x4* q = reinterpret_cast<u32x4*>(p + head);
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int64_t i = tid; i < n16; i += stride) q[i] = z;
+    const int64_t tail0 = head + (n16 << 4);
+    if (tid < head) p[tid] = 0;
+    if (tid < bytes - tail0) p[tail0 + tid] = 0;
+}
 }  // namespace
 
 extern "C" int cb_mean_fwd(const float* x, int64_t n, float* out, void* stream) {
@@ -501,6 +518,24 @@ extern "C" int cb_zero(void* p, int64_t bytes, void* stream) {
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, cb_stream(stream), static_cast<unsigned char*>(p), bytes);
     return cb_launch_status("cb_zero");
+}
+extern "C" int cb_zero_ranges(void* const* ptrs, const int64_t* bytes, int32_t n, void* stream) {
+    CB_REQUIRE(n >= 0 && n <= 4 && (n == 0 || (ptrs && bytes)), "cb_zero_ranges: 0..4 ranges");
+    ZeroRanges zr{};
+    int m = 0;
+    int64_t most = 0;
+    for (int i = 0; i < n; ++i) {
+        CB_REQUIRE(bytes[i] >= 0 && (bytes[i] == 0 || ptrs[i]), "cb_zero_ranges: bad range %d", i);
+        if (bytes[i] == 0) continue;
+        zr.p[m] = static_cast<unsigned char*>(ptrs[i]); zr.bytes[m] = bytes[i]; ++m;
+        most = bytes[i] > most ? bytes[i] : most;
+    }
+    if (m == 0) return 0;
+    int64_t blocks = ((most >> 4) + 256 * 4 - 1) / (256 * 4);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)blocks, (unsigned)m), dim3(256), 0, cb_stream(stream), zr);
+    return cb_launch_status("cb_zero_ranges");
 }
 extern "C" int cb_counter_add(int64_t* counter, int64_t inc, void* stream) {
     CB_REQUIRE(counter, "cb_counter_add: null counter");

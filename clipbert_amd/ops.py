@@ -422,6 +422,20 @@ def zero_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def zero_many(tensors) -> None:
+    """every (contiguous) tensor of the list = 0, four per launch (cb_zero_ranges) on the first one's stream"""
+    ts = [t for t in tensors if t is not None and t.numel()]
+    for i in range(0, len(ts), 4):
+        chunk = ts[i:i + 4]
+        if len(chunk) == 1:
+            zero_(chunk[0])
+            continue
+        assert all(t.is_contiguous() for t in chunk)
+        ptrs = (C.c_void_p * len(chunk))(*[_ptr(t) for t in chunk])
+        nbytes = (C.c_int64 * len(chunk))(*[t.numel() * t.element_size() for t in chunk])
+        _chk(_lib.get().cb_zero_ranges(ptrs, nbytes, len(chunk), _stream(chunk[0])), "cb_zero_ranges")
+
+
 def zeros(shape, dtype, device) -> torch.Tensor:
     return zero_(torch.empty(shape, dtype=dtype, device=device))
 

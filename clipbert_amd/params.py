@@ -303,17 +303,19 @@ class ParamBank:
         if lazy and span is not None:
             skip = sorted([span] + ([self.fresh_span] if getattr(self, "fresh_span", None) is not None else []))
             lo = 0
+            fills = []                                         # (the gaps around the first-writer ranges + the norm slots: ONE launch, cb_zero_ranges)
             for a, b in skip:
                 if a > lo:
-                    ops.zero_(self.grad[lo:a])
+                    fills.append(self.grad[lo:a])
                 lo = max(lo, b)
             if lo < self.grad.numel():
-                ops.zero_(self.grad[lo:])
+                fills.append(self.grad[lo:])
             self.lazy_fresh = True
             self.fresh_left = set(getattr(self, "fresh_ids", {}))
             if getattr(self, "sq_buf", None) is not None:      # the norm accumulator and this step's share slots start at zero
-                ops.zero_(self.sq_buf)
+                fills.append(self.sq_buf)
                 self.fold = dict(valid=True, next=0, covers=[])
+            ops.zero_many(fills)
         else:
             ops.zero_(self.grad)
             self.lazy_fresh = False

@@ -380,6 +380,9 @@ int cb_counter_add(int64_t* counter, int64_t inc, void* stream);
  * run_video_retrieval.py:484), scatter targets of the embedding backwards, the squared-norm accumulator -- as a stream-ordered,
  * capturable kernel of this library. */
 int cb_zero(void* p, int64_t bytes, void* stream);
+/* the same for up to FOUR ranges in one launch (round 6): zero_grad() of a step whose weight gradients are stored by their first writers
+ * leaves three gaps of the flat gradient buffer + the norm slots to fill -- one launch instead of four.  ptrs / bytes: HOST arrays. */
+int cb_zero_ranges(void* const* ptrs, const int64_t* bytes, int32_t n, void* stream);
 int cb_sq_sum(const float* g, int64_t n, float* out_accum, void* stream);
 /* The same sum with a result that does not depend on the order in which workgroups retire (fixed grid of <= min(1024, ws_floats)
  * blocks -> `ws` partials -> one block adds them in index order): data-parallel ranks holding bit-identical all-reduced
@@ -418,7 +421,7 @@ const char* cb_last_error(void);
  * 6 = cb_gemm_desc grew by sq_slots / sq_slots_n at its END (zero = off: older callers that memset the struct they allocate with the
  *     new size are unaffected), accumulate = 2 (first writer), cb_sq_sum_fold;
  * 7 = cb_gemm_desc.tile = 9 (few rows), chosen by itself for M <= 64: the same result up to the order of the fp32 additions;
- *     cb_gemm_group takes strided batches / a_rowsum on the unsplit bf16 weight-gradient form; cb_stem_pool_u8 */
+ *     cb_gemm_group takes strided batches / a_rowsum on the unsplit bf16 weight-gradient form; cb_stem_pool_u8; cb_zero_ranges */
 int cb_version(void);
 
 /* ---- gradient exchange (one process per GPU, RCCL over xGMI) ----------------------------------------------------

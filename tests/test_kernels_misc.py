@@ -405,3 +405,17 @@ def test_head_losses_and_retrieval_scores_against_the_oracle(hw):
     two, one = rnd(9, 2, seed=6, scale=2.0), rnd(9, 1, seed=7, scale=2.0)
     assert clips.retrieval_scores(two) == [round(v, 4) for v in torch.softmax(two.cpu(), 1)[:, 1].tolist()]
     assert clips.retrieval_scores(one) == [round(v, 4) for v in torch.sigmoid(one.cpu()).view(-1).tolist()]
+
+
+def test_zero_many_ranges_any_alignment(hw):
+    """cb_zero_ranges: up to four ranges per launch (ops.zero_many chunks longer lists), unaligned heads / tails, neighbours untouched"""
+    base = hw(torch.arange(1, 20001, dtype=torch.float32))
+    buf = base.clone()
+    u8 = hw(torch.full((1000,), 7, dtype=torch.uint8))
+    views = [buf[3:1000], buf[1001:1002], buf[5000:12345], buf[19990:], buf[2000:2003]]
+    ops.zero_many(views + [u8[5:998], None, buf[0:0]])
+    want = base.clone()
+    for a, b in ((3, 1000), (1001, 1002), (5000, 12345), (19990, 20000), (2000, 2003)):
+        want[a:b] = 0
+    assert torch.equal(buf.cpu(), want.cpu())
+    assert u8[:5].eq(7).all() and u8[998:].eq(7).all() and u8[5:998].eq(0).all()
